@@ -1,0 +1,210 @@
+"""Pin the CPU oracle (oracle/torch_ref.py) against golden vectors captured from the reference.
+
+CPU only.  Index / integer outputs must match exactly; fp32 outputs within the tolerance
+written at each assert (the reference fixtures were produced on another host's BLAS, so
+fp32 sums may differ in the last bits).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import torch_ref as R
+from tests import cases, golden_io, synth
+
+RTOL = 1e-5     # fp32 restatement vs reference on (possibly) another CPU
+ATOL = 1e-6
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), f"max abs err {err:.3e} (ref max {b.abs().max().item():.3e})"
+
+
+@pytest.mark.parametrize("name", cases.VQ_CASES)
+def test_vq_forward_backward(name):
+    fx = golden_io.load(name)
+    x, W, g = cases.vq_inputs(fx.meta)
+    q, idx, loss, usage = R.vq_forward(x, W, training=False)
+    assert torch.equal(idx, fx["idx_eval"])                  # bit-exact indices
+    assert torch.equal(q, fx["q_eval"])                      # exact codebook rows (one-hot matmul)
+    assert loss.item() == 0.0 and float(usage) == float(fx["usage_eval"])
+    xr = x.clone().requires_grad_(True)
+    q, idx, loss, usage = R.vq_forward(xr, W, training=True)
+    assert torch.equal(idx, fx["idx_train"])
+    close(q, fx["q_train"], rtol=1e-6, atol=1e-6)            # x + (q - x): one rounding each way
+    close(loss, fx["loss_train"], rtol=1e-5)
+    ((q * g).sum() + fx.meta["grad_loss_scale"] * loss.sum()).backward()
+    close(xr.grad, fx["grad_x"], rtol=1e-5, atol=1e-7)
+    # the analytic backward used by the HIP path agrees with autograd
+    ana = R.vq_backward(x, q.detach(), g, torch.tensor(fx.meta["grad_loss_scale"]), 1.0)
+    close(ana, fx["grad_x"], rtol=1e-5, atol=1e-7)
+    assert bool(fx["w_grad_is_none"])                        # codebook receives no gradient
+
+
+@pytest.mark.parametrize("name", cases.KMEANS_CASES)
+def test_kmeans(name):
+    fx = golden_io.load(name)
+    samples, means0 = cases.kmeans_inputs(fx.meta)
+    means, bins = R.kmeans_lloyd(samples, means0, fx.meta["iters"])
+    assert torch.equal(bins, fx["bins"])
+    close(means, fx["means"], rtol=1e-5, atol=1e-6)
+    if fx.meta["empty"]:
+        assert (bins == 0).any() and torch.equal(means[bins == 0], means0[bins == 0])   # vq_img.py:58-61
+
+
+@pytest.mark.parametrize("name", cases.DEC_CASES)
+def test_decoder(name):
+    fx = golden_io.load(name)
+    feats, sd, g = cases.decoder_inputs(fx.meta)
+    p = {"decoder." + k: v.clone() for k, v in sd.items()}
+    y = R.unet_decoder(p, feats, training=False)
+    close(y, fx["y_eval"], rtol=1e-4, atol=1e-5)
+    for k in p:
+        if p[k].is_floating_point() and "running" not in k:
+            p[k].requires_grad_(True)
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    y = R.unet_decoder(p, fr, training=True)
+    close(y, fx["y_train"], rtol=1e-4, atol=1e-5)
+    (y * g).sum().backward()
+    for i, f in enumerate(fr):
+        close(f.grad, fx[f"grad_feat{i}"], rtol=1e-3, atol=1e-4)
+    close(p["decoder.blocks.0.0.0.weight"].grad, fx["grad_w_first"], rtol=1e-3, atol=1e-4)
+    close(p["decoder.blocks.4.1.0.weight"].grad, fx["grad_w_last"], rtol=1e-3, atol=1e-4)
+    close(p["decoder.blocks.4.1.1.weight"].grad, fx["grad_bn_w_last"], rtol=1e-3, atol=1e-4)
+    close(p["decoder.blocks.4.1.1.bias"].grad, fx["grad_bn_b_last"], rtol=1e-3, atol=1e-4)
+    close(p["decoder.blocks.0.0.1.running_mean"], fx["run_mean_first"], rtol=1e-5)
+    close(p["decoder.blocks.0.0.1.running_var"], fx["run_var_first"], rtol=1e-5)
+    close(p["decoder.blocks.4.1.1.running_mean"], fx["run_mean_last"], rtol=1e-5)
+    close(p["decoder.blocks.4.1.1.running_var"], fx["run_var_last"], rtol=1e-5)
+
+
+def test_prototype_losses():
+    fx = golden_io.load("prototype")
+    feat, gt, scores, protos, entropy = cases.proto_inputs()
+    for tag, margin, scale in (("m0", 0.0, 1.0), ("m05", 0.5, 30.0)):
+        fr = feat.clone().requires_grad_(True)
+        l1 = R.prototype_loss_v1(fr, gt, protos, fx.meta["percent"], entropy, margin, scale)
+        assert l1.dtype == torch.float64                                  # q11
+        close(l1, fx[f"v1_{tag}_loss"], rtol=1e-6)
+        l1.backward()
+        close(fr.grad, fx[f"v1_{tag}_grad"], rtol=1e-4, atol=1e-7)
+        assert bool(fx[f"v1_{tag}_proto_grad_none"])
+        for kind, target in (("gt", gt), ("score", scores)):
+            l2, proto_n = R.prototype_loss_v2(feat, target, protos, fx.meta["th"], margin, scale)
+            close(l2, fx[f"v2_{tag}_{kind}_loss"], rtol=1e-5)
+            close(proto_n, fx[f"v2_{tag}_{kind}_proto_after"], rtol=1e-6)
+    # the out-of-place v2 restatement is differentiable (the reference's in-place form is not, q10)
+    fr = feat.clone().requires_grad_(True)
+    pr = protos.clone().requires_grad_(True)
+    R.prototype_loss_v2(fr, gt, pr, 0.7, 0.5, 30.0)[0].backward()
+    assert torch.isfinite(fr.grad).all() and torch.isfinite(pr.grad).all()
+
+
+def test_losses_metrics_schedule():
+    fx = golden_io.load("losses_metrics")
+    pred, pred2, tgt = cases.loss_inputs()
+    p1 = pred.clone().requires_grad_(True)
+    sup = 0.5 * F.cross_entropy(p1, tgt, ignore_index=255) + R.dice_loss(p1, tgt)
+    close(sup, fx["sup_loss"], rtol=1e-6)
+    sup.backward()
+    close(p1.grad, fx["sup_grad"], rtol=1e-4, atol=1e-8)
+    pa, pb = pred.clone().requires_grad_(True), pred2.clone().requires_grad_(True)
+    fa = R.score_mask(pa, torch.argmax(pa, 1).long(), fx.meta["th"])
+    fb = R.score_mask(pb, torch.argmax(pb, 1).long(), fx.meta["th"])
+    assert torch.equal(fa, fx["filt_a"]) and torch.equal(fb, fx["filt_b"])
+    ce = lambda a, b: F.cross_entropy(a, b, ignore_index=255)
+    cps = 0.5 * ce(pa, fb) + 0.5 * ce(pb, fa) + R.dice_loss(pa, fb) + R.dice_loss(pb, fa)
+    close(cps, fx["cps_loss"], rtol=1e-6)
+    cps.backward()
+    close(pa.grad, fx["cps_grad_a"], rtol=1e-4, atol=1e-8)
+    close(pb.grad, fx["cps_grad_b"], rtol=1e-4, atol=1e-8)
+    conf = R.confusion_matrix(pred.numpy(), tgt.numpy())
+    assert np.array_equal(conf, fx["conf"].numpy())
+    m, ious = R.miou(conf)
+    assert m == pytest.approx(float(fx["miou"]), rel=1e-12)
+    assert np.allclose(ious, fx["ious"].numpy(), rtol=1e-12)
+    lrs = [R.cosine_lr(i, 1e-4, 1e-7, 1000, 0) for i in range(0, 1001, 50)]
+    assert np.allclose(lrs, fx["lr_table"].numpy(), rtol=1e-15)
+
+
+def _model_params(name, seed):
+    shapes = golden_io.layout(name)
+    return synth.synth_state_dict(shapes, seed)
+
+
+@pytest.mark.parametrize("version", [1, 2])
+def test_whole_model(version):
+    """Everything the reference wrote (glue, VQ, decoder, losses) on top of the unpinned ResNet body."""
+    fx = golden_io.load(f"model_v{version}")
+    sd = _model_params("vqreptunet1x1", fx.meta["model_seed"])       # v1 and v2 share the layout
+    assert len(sd) == fx.meta["n_keys"] == 383
+    x, gt, scores = cases.model_inputs()
+    ks = (0, 0, 512, 512, 512)
+    p = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        logits, closs, usage, proto, aux = R.vq_unet_forward(p, x, False, ks, version=version)
+    for j, lvl in enumerate((2, 3, 4)):
+        assert torch.equal(aux["indices"][j], fx[f"eval_idx{lvl}"])
+    close(logits, fx["eval_logits"], rtol=1e-3, atol=1e-4)             # north_star: 1e-3 relative
+    close(usage, fx["eval_usage"], rtol=1e-6)
+    assert proto is None and closs.item() == 0.0
+    # training forward + backward
+    p = {k: v.clone() for k, v in sd.items()}
+    for k, v in p.items():
+        if v.is_floating_point() and "running" not in k and "codebook" not in k:
+            v.requires_grad_(True)
+    kw = dict(percent=fx.meta["percent"]) if version == 1 else dict(th=fx.meta["th"])
+    logits, closs, usage, proto, aux = R.vq_unet_forward(p, x, True, ks, gt=gt, version=version,
+                                                         margin=fx.meta["margin"], scale=fx.meta["scale"], **kw)
+    close(logits, fx["train_logits"], rtol=1e-3, atol=1e-4)
+    close(closs, fx["train_loss"], rtol=1e-4)
+    close(usage, fx["train_usage"], rtol=1e-6)
+    close(proto, fx["train_proto"], rtol=1e-4)
+    total = (logits * cases.logits_cotangent(logits.shape)).sum() + fx.meta["loss_scale"] * closs.sum()
+    if version == 1:
+        total = total + fx.meta["proto_scale"] * proto
+    total.backward()
+    for key in [k[5:] for k in fx if k.startswith("grad/")]:
+        got = golden_io.probe(p[key].grad)
+        ref = fx["grad/" + key]
+        scale = ref.abs().max().item() + 1e-12
+        assert (got - ref).abs().max().item() <= 2e-3 * scale, key
+        assert p[key].grad.double().norm().item() == pytest.approx(float(fx["gradnorm/" + key]), rel=2e-3)
+    for key in [k[5:] for k in fx if k.startswith("post/")]:
+        close(p[key], fx["post/" + key], rtol=1e-4, atol=1e-6)
+    if version == 2:
+        with torch.no_grad():
+            p2 = {k: v.clone() for k, v in sd.items()}
+            out = R.vq_unet_forward(p2, x, True, ks, gt=scores, version=2, th=fx.meta["th"],
+                                    margin=fx.meta["margin"], scale=fx.meta["scale"])
+        close(out[3], fx["train_proto_score"], rtol=1e-4)
+    none_keys = set(fx["grad_none_keys"].tolist())
+    assert {f"codebook.{i}.codebook.embedding.weight" for i in (2, 3, 4)} <= none_keys
+
+
+def test_plain_unet():
+    fx = golden_io.load("model_unet")
+    sd = synth.synth_state_dict(golden_io.layout("unet"), fx.meta["model_seed"])
+    x, gt, _ = cases.model_inputs(b=2, s=64, seed=6500)
+    p = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        y = R.unet_forward(p, x, False)
+    close(y, fx["eval_logits"], rtol=1e-3, atol=1e-4)
+    p = {k: v.clone() for k, v in sd.items()}
+    for k, v in p.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    y = R.unet_forward(p, x, True)
+    close(y, fx["train_logits"], rtol=1e-3, atol=1e-4)
+    loss = R.dice_loss(y, gt) + 0.5 * F.cross_entropy(y, gt, ignore_index=255)
+    close(loss, fx["loss"], rtol=1e-5)
+    loss.backward()
+    for key in [k[5:] for k in fx if k.startswith("grad/")]:
+        ref = fx["grad/" + key]
+        got = golden_io.probe(p[key].grad)
+        assert (got - ref).abs().max().item() <= 2e-3 * (ref.abs().max().item() + 1e-12), key
