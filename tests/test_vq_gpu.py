@@ -1,0 +1,175 @@
+"""GPU parity of the VQ hot path (HIP kernels through the C ABI) against the golden
+fixtures and the CPU oracle.  Indices bit-exact; fp32 values within the tolerance at each assert."""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases, golden_io, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def close(a, b, rtol, atol=0.0):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), f"max abs err {err:.3e} (ref max {b.abs().max().item():.3e})"
+
+
+def make_vq(meta, W, **kw):
+    from vq_seg_amd.vector_quantizer import VectorQuantizer
+    vq = VectorQuantizer(dim=meta["c"], num_embeddings=meta["k"], commitment_weight=1, **kw).to(dev())
+    with torch.no_grad():
+        vq.codebook.embedding.weight.copy_(W)
+    return vq
+
+
+@pytest.mark.parametrize("layout", ["channels_last", "nchw"])
+@pytest.mark.parametrize("name", cases.VQ_CASES)
+def test_vq_module_matches_reference_golden(name, layout):
+    fx = golden_io.load(name)
+    x, W, g = cases.vq_inputs(fx.meta)
+    vq = make_vq(fx.meta, W)
+    xd = x.to(dev())
+    if layout == "channels_last":
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    vq.eval()
+    with torch.no_grad():
+        q, idx, loss, usage = vq(xd)
+    assert idx.dtype == torch.int64 and idx.shape == fx["idx_eval"].shape
+    assert torch.equal(idx.cpu(), fx["idx_eval"]), "argmin indices must be bit-exact"
+    assert torch.equal(q.cpu(), fx["q_eval"]), "eval quantize is an exact gather of codebook rows"
+    assert q.shape == x.shape and loss.shape == (1,) and usage.dim() == 0
+    assert loss.item() == 0.0 and float(usage) == float(fx["usage_eval"])
+    vq.train()
+    xr = xd.clone().requires_grad_(True)
+    q, idx, loss, usage = vq(xr)
+    assert torch.equal(idx.cpu(), fx["idx_train"])
+    close(q, fx["q_train"], rtol=1e-6, atol=1e-6)
+    close(loss, fx["loss_train"], rtol=1e-5)
+    assert float(usage) == float(fx["usage_train"])
+    ((q * g.to(dev())).sum() + fx.meta["grad_loss_scale"] * loss.sum()).backward()
+    close(xr.grad, fx["grad_x"], rtol=1e-5, atol=1e-7)
+    assert vq.codebook.embedding.weight.grad is None          # frozen codebook
+
+
+@pytest.mark.parametrize("name", cases.VQ_CASES)
+def test_distances_bit_exact_against_chain_oracle(name):
+    """The kernel's winning distance equals the C oracle's fmaf chain ('mfma8' order) bit for bit."""
+    from oracle import vq_chain
+    from vq_seg_amd import _hip
+    fx = golden_io.load(name)
+    x, W, _ = cases.vq_inputs(fx.meta)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+    idx, dmin = _hip.vq_assign(rows.to(dev()), W.to(dev()), want_dmin=True)
+    ref_idx, ref_d = vq_chain.assign(rows.numpy(), W.numpy(), vq_chain.ORDER_MFMA8)
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)
+    assert np.array_equal(dmin.cpu().numpy().view(np.uint32), ref_d.view(np.uint32)), "distance bits differ"
+
+
+@pytest.mark.parametrize("n,c,k", [(1, 4, 1), (31, 8, 3), (129, 20, 33), (257, 36, 257), (1000, 64, 1024), (4096, 100, 300)])
+def test_ragged_shapes_against_chain_oracle(n, c, k):
+    """Row counts off the 128-row workgroup tile, channel counts off the 16-channel stage,
+    code counts off the 256-code chunk (including K=1 and K>2 chunks)."""
+    from oracle import vq_chain
+    from vq_seg_amd import _hip
+    rows = synth.uniform(n * 7 + c, (n, c), -1.0, 1.0)
+    W = synth.uniform(k * 13 + c, (k, c), -1.0, 1.0)
+    idx, dmin = _hip.vq_assign(rows.to(dev()), W.to(dev()), want_dmin=True)
+    ref_idx, ref_d = vq_chain.assign(rows.numpy(), W.numpy(), vq_chain.ORDER_MFMA8)
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)
+    assert np.array_equal(dmin.cpu().numpy().view(np.uint32), ref_d.view(np.uint32))
+
+
+def test_full_size_properties():
+    """BASELINE config sizes (512x512 input, K=512, B=8): size-independent properties.
+    L2: N = 8*64*64 rows of 512 ch; L4: N = 8*16*16 rows of 2048 ch."""
+    from vq_seg_amd import _hip
+    for (n, c, k, seed) in [(8 * 4096, 512, 512, 1), (8 * 256, 2048, 512, 2), (2 * 16384, 512, 1024, 3)]:
+        rows = synth.relu_features(seed, (n, c)).to(dev())
+        W = synth.relu_features(seed + 10, (k, c), sparsity=0.3, scale=1.5).to(dev())
+        quant, idx, loss, dead, dmin = _hip.vq_forward(rows, W, True, 1.0, want_dmin=True)
+        assert idx.min() >= 0 and idx.max() < k
+        # (1) the chosen code is an exact minimiser up to fp32 rounding of the distance (fp64 audit)
+        sub = torch.arange(0, n, max(n // 2048, 1), device=dev())
+        d2 = torch.cdist(rows[sub].double(), W.double()).pow(2)
+        best = d2.min(dim=1).values
+        chosen = d2.gather(1, idx[sub, None])[:, 0]
+        assert ((chosen - best) <= 1e-5 * best.clamp_min(1e-6)).all(), "argmin is not a minimiser"
+        # (2) eval gather is exact; training STE value is x + (q - x); commitment = mean sq error
+        q_eval = _hip.vq_forward(rows, W, False, 1.0)[0]
+        assert torch.equal(q_eval, W[idx])
+        assert torch.equal(quant, rows + (W[idx] - rows))
+        ref_loss = ((quant - rows).double() ** 2).mean()
+        assert abs(loss.item() - ref_loss.item()) <= 1e-5 * ref_loss.item()
+        # (3) histogram: dead-code percentage equals the bincount definition
+        cnt = torch.bincount(idx, minlength=k)
+        assert float(dead) == float(100 * ((cnt == 0).sum() / k))
+        # (4) idempotence: quantising codebook rows returns their own index (lowest duplicate)
+        idx_w = _hip.vq_assign(W.contiguous(), W)
+        assert torch.equal(idx_w, torch.arange(k, device=dev()))
+        # (5) permutation equivariance over rows
+        perm = torch.randperm(n, device=dev())
+        assert torch.equal(_hip.vq_assign(rows[perm].contiguous(), W), idx[perm])
+
+
+@pytest.mark.parametrize("name", cases.KMEANS_CASES)
+def test_kmeans_matches_reference_golden(name):
+    from vq_seg_amd import _hip
+    fx = golden_io.load(name)
+    samples, means0 = cases.kmeans_inputs(fx.meta)
+    means, bins = _hip.kmeans(samples.to(dev()), means0.clone().to(dev()), fx.meta["iters"])
+    assert torch.equal(bins.cpu(), fx["bins"])
+    close(means, fx["means"], rtol=1e-5, atol=1e-6)
+    if fx.meta["empty"]:
+        dead = fx["bins"] == 0
+        assert dead.any() and torch.equal(means.cpu()[dead], means0[dead])
+
+
+def test_kmeans_init_runs_once_in_first_training_forward():
+    """with kmeans_init the codebook stays N(0,1) through eval forwards and is replaced by
+    10 Lloyd iterations in the first TRAINING forward only."""
+    from oracle import torch_ref
+    from vq_seg_amd.vector_quantizer import VectorQuantizer
+    torch.manual_seed(0)
+    vq = VectorQuantizer(dim=32, num_embeddings=16, kmeans_init=True).to(dev())
+    w0 = vq.codebook.embedding.weight.detach().clone()
+    x = synth.relu_features(5, (2, 32, 8, 8)).to(dev())
+    vq.eval()
+    vq(x)
+    assert not vq.codebook.initted and torch.equal(vq.codebook.embedding.weight, w0)
+    vq.train()
+    torch.manual_seed(123)
+    pick = torch.randperm(128, device=dev())[:16]
+    torch.manual_seed(123)
+    q, idx, loss, usage = vq(x)
+    assert vq.codebook.initted
+    rows = x.permute(0, 2, 3, 1).reshape(-1, 32)
+    ref_means, _ = torch_ref.kmeans_lloyd(rows.cpu(), rows[pick].cpu(), 10)
+    close(vq.codebook.embedding.weight, ref_means, rtol=1e-5, atol=1e-6)
+    w1 = vq.codebook.embedding.weight.detach().clone()
+    vq(x)
+    assert torch.equal(vq.codebook.embedding.weight, w1)      # not re-initialised
+
+
+def test_half_and_bf16_inputs_are_cast_to_fp32():
+    """vq_img.py:229 forces fp32 inside the quantiser whatever the autocast dtype."""
+    from vq_seg_amd.vector_quantizer import VectorQuantizer
+    x = synth.relu_features(9, (1, 64, 8, 8))
+    W = synth.relu_features(10, (32, 64))
+    vq = VectorQuantizer(dim=64, num_embeddings=32).to(dev())
+    with torch.no_grad():
+        vq.codebook.embedding.weight.copy_(W)
+    vq.eval()
+    for dt in (torch.float16, torch.bfloat16):
+        xh = x.to(dt)
+        q, idx, _, _ = vq(xh.to(dev()))
+        assert q.dtype == torch.float32
+        from oracle import torch_ref
+        _, ref_idx, _, _ = torch_ref.vq_forward(xh, W, training=False)
+        assert torch.equal(idx.cpu(), ref_idx)

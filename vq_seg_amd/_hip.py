@@ -1,0 +1,183 @@
+"""ctypes binding of libvqseg_hip.so (the C ABI declared in include/vqseg.h).
+
+Torch is used only to own device memory and to name the current HIP stream; every
+argument crossing the boundary is a raw pointer or a size.  Fails loudly: a missing
+library, a CPU tensor, a wrong dtype or a non-zero return code raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from typing import Optional, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvqseg_hip.so")
+
+# name -> (restype, argtypes); must list every symbol include/vqseg.h declares
+SYMBOLS = {
+    "vqseg_abi_version": (c_int, []),
+    "vqseg_last_error": (c_char_p, []),
+    "vqseg_kernel_name": (c_char_p, [c_char_p]),
+    "vqseg_vq_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "vqseg_vq_forward_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vqseg_vq_assign_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_size_t, c_void_p]),
+    "vqseg_vq_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p,
+                                      c_void_p]),
+    "vqseg_kmeans_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "vqseg_kmeans_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_size_t,
+                                 c_void_p]),
+    "vqseg_kmeans_accumulate_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                            c_size_t, c_void_p]),
+    "vqseg_kmeans_finalize_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the HIP library; raise if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(or `make -C vq_seg_amd/csrc`). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)          # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        if handle.vqseg_abi_version() != 1:
+            raise HipLibraryError("libvqseg_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().vqseg_last_error().decode(errors="replace")
+        raise HipLibraryError(f"{what} failed (code {rc}): {msg}")
+
+
+def _dev(t: torch.Tensor, dtype: torch.dtype, name: str) -> int:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise HipLibraryError(f"{name}: the HIP path needs a tensor on a 'cuda' (ROCm) device; got "
+                              f"{getattr(t, 'device', type(t))}. There is no CPU fallback.")
+    if t.dtype != dtype:
+        raise HipLibraryError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise HipLibraryError(f"{name}: expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------
+def vq_forward(rows: torch.Tensor, codebook: torch.Tensor, training: bool, commitment_weight: float,
+               want_dmin: bool = False):
+    """rows (N, C) f32, codebook (K, C) f32 -> quant (N, C), idx (N,) i64, loss (1,), dead_pct (), [dmin (N,)]."""
+    L = lib()
+    n, c = rows.shape
+    k = codebook.shape[0]
+    xp, wp = _dev(rows, torch.float32, "rows"), _dev(codebook, torch.float32, "codebook")
+    dev = rows.device
+    quant = torch.empty_like(rows)
+    idx = torch.empty(n, dtype=torch.int64, device=dev)
+    scal = torch.empty(2, dtype=torch.float32, device=dev)
+    dmin = torch.empty(n, dtype=torch.float32, device=dev) if want_dmin else None
+    nbytes = L.vqseg_vq_workspace_bytes(n, c, k)
+    ws = _workspace(nbytes, dev)
+    with torch.cuda.device(dev):
+        rc = L.vqseg_vq_forward_f32(xp, wp, n, c, k, int(bool(training)), float(commitment_weight), quant.data_ptr(),
+                                    idx.data_ptr(), scal.data_ptr(), scal.data_ptr() + 4,
+                                    dmin.data_ptr() if want_dmin else None, ws.data_ptr(), nbytes, _stream())
+    _check(rc, "vqseg_vq_forward_f32")
+    out = (quant, idx, scal[0:1], scal[1])
+    return out + (dmin,) if want_dmin else out
+
+
+def vq_assign(rows: torch.Tensor, codebook: torch.Tensor, want_dmin: bool = False):
+    L = lib()
+    n, c = rows.shape
+    k = codebook.shape[0]
+    xp, wp = _dev(rows, torch.float32, "rows"), _dev(codebook, torch.float32, "codebook")
+    dev = rows.device
+    idx = torch.empty(n, dtype=torch.int64, device=dev)
+    dmin = torch.empty(n, dtype=torch.float32, device=dev) if want_dmin else None
+    nbytes = L.vqseg_vq_workspace_bytes(n, c, k)
+    ws = _workspace(nbytes, dev)
+    with torch.cuda.device(dev):
+        rc = L.vqseg_vq_assign_f32(xp, wp, n, c, k, idx.data_ptr(), dmin.data_ptr() if want_dmin else None,
+                                   ws.data_ptr(), nbytes, _stream())
+    _check(rc, "vqseg_vq_assign_f32")
+    return (idx, dmin) if want_dmin else idx
+
+
+def vq_backward(grad_quant: torch.Tensor, grad_loss: Optional[torch.Tensor], rows: torch.Tensor, quant: torch.Tensor,
+                commitment_weight: float) -> torch.Tensor:
+    L = lib()
+    n, c = rows.shape
+    gq = _dev(grad_quant, torch.float32, "grad_quant")
+    gl = _dev(grad_loss, torch.float32, "grad_loss") if grad_loss is not None else None
+    gx = torch.empty_like(rows)
+    with torch.cuda.device(rows.device):
+        rc = L.vqseg_vq_backward_f32(gq, gl, _dev(rows, torch.float32, "rows"), _dev(quant, torch.float32, "quant"),
+                                     n, c, float(commitment_weight), gx.data_ptr(), _stream())
+    _check(rc, "vqseg_vq_backward_f32")
+    return gx
+
+
+def kmeans(samples: torch.Tensor, means: torch.Tensor, iters: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Lloyd iterations in place on `means` (K, C); returns (means, bins (K,) i64)."""
+    L = lib()
+    n, c = samples.shape
+    k = means.shape[0]
+    sp, mp = _dev(samples, torch.float32, "samples"), _dev(means, torch.float32, "means")
+    bins = torch.zeros(k, dtype=torch.int64, device=samples.device)
+    nbytes = L.vqseg_kmeans_workspace_bytes(n, c, k)
+    ws = _workspace(nbytes, samples.device)
+    with torch.cuda.device(samples.device):
+        rc = L.vqseg_kmeans_f32(sp, mp, bins.data_ptr(), n, c, k, int(iters), ws.data_ptr(), nbytes, _stream())
+    _check(rc, "vqseg_kmeans_f32")
+    return means, bins
+
+
+def kmeans_accumulate(samples: torch.Tensor, means: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """This rank's per-cluster sums (K, C) f32 and counts (K,) i64 for one Lloyd iteration."""
+    L = lib()
+    n, c = samples.shape
+    k = means.shape[0]
+    sp, mp = _dev(samples, torch.float32, "samples"), _dev(means, torch.float32, "means")
+    sums = torch.empty(k, c, dtype=torch.float32, device=samples.device)
+    counts = torch.empty(k, dtype=torch.int64, device=samples.device)
+    nbytes = L.vqseg_kmeans_workspace_bytes(n, c, k)
+    ws = _workspace(nbytes, samples.device)
+    with torch.cuda.device(samples.device):
+        rc = L.vqseg_kmeans_accumulate_f32(sp, mp, n, c, k, sums.data_ptr(), counts.data_ptr(), ws.data_ptr(), nbytes,
+                                           _stream())
+    _check(rc, "vqseg_kmeans_accumulate_f32")
+    return sums, counts
+
+
+def kmeans_finalize(sums: torch.Tensor, counts: torch.Tensor, means: torch.Tensor) -> torch.Tensor:
+    L = lib()
+    k, c = means.shape
+    with torch.cuda.device(means.device):
+        rc = L.vqseg_kmeans_finalize_f32(_dev(sums, torch.float32, "sums"), _dev(counts, torch.int64, "counts"),
+                                         _dev(means, torch.float32, "means"), c, k, _stream())
+    _check(rc, "vqseg_kmeans_finalize_f32")
+    return means

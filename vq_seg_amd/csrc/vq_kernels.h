@@ -1,0 +1,33 @@
+// Internal launch-helper declarations shared by the kernels and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace vqseg {
+
+struct VqPlan {
+    int Cp, Kp;                 // channels / codes padded to the kernel's stage / chunk size
+    size_t off_ET, off_enorm, off_hist, off_partial, bytes;
+    int gather_blocks;
+};
+struct KmPlan {
+    VqPlan vq;
+    size_t off_idx, off_counts, off_offsets, off_members, off_sums, off_counts64, bytes;
+};
+
+VqPlan vq_plan(int64_t N, int C, int K);
+KmPlan km_plan(int64_t N, int C, int K);
+
+hipError_t launch_prep(const float* W, int K, int C, const VqPlan& p, char* ws, hipStream_t st);
+hipError_t launch_assign(const float* x, int64_t N, int C, const VqPlan& p, char* ws, int64_t* idx, float* dmin,
+                         hipStream_t st);
+hipError_t launch_gather(const float* x, const float* W, const int64_t* idx, int64_t N, int C, int K, int training,
+                         float cw, const VqPlan& p, char* ws, float* quant, float* loss, float* dead, hipStream_t st);
+hipError_t launch_backward(const float* gq, const float* gloss, const float* x, const float* q, int64_t N, int C,
+                           float cw, float* gx, hipStream_t st);
+hipError_t launch_km_accumulate(const float* samples, const float* means, int64_t N, int C, int K, const KmPlan& p,
+                                char* ws, float* sums, int64_t* counts64, hipStream_t st);
+hipError_t launch_km_finalize(const float* sums, const int64_t* counts64, float* means, int C, int K, hipStream_t st);
+
+}  // namespace vqseg

@@ -1,0 +1,532 @@
+// vq_kernels.hip -- vector-quantiser hot path for gfx950 (MI355X, CDNA4).
+//
+// Reference algorithm: vector_quantizer/vq_img.py:160-177 (EuclideanCodebook.forward) and
+// :228-244 (VectorQuantizer.forward); k-means init :29-63.  Nothing here is translated
+// from the reference (which is stock ATen calls); the design is MI355X-first:
+//
+//   * the (N, K) distance matrix is never materialised: a wave owns a 32-row strip and
+//     keeps 32 x 256 distances in 128 accumulator registers (8 tiles of
+//     v_mfma_f32_32x32x2_f32, exact fp32 == a k-ordered fmaf chain), reduces them to a
+//     running (min, index) per row in registers, and walks the codebook in 256-code
+//     chunks;
+//   * the codebook is pre-transposed once per call to ET[c][k] so that the MFMA B
+//     fragment is a conflict-free 128-byte ds_read_b32 per half-wave, streamed through
+//     LDS with direct global->LDS loads (global_load_lds_dwordx4), double buffered;
+//   * pixel rows (A fragments) go global -> registers in fragment shape (each lane one
+//     16-byte load per 8 channels); they are read once per 256-code chunk;
+//   * 2 workgroups (8 waves) per CU: one wave's VALU epilogue (|x|^2 + |e|^2 - 2x.e,
+//     clamp, sqrt, compare) overlaps the partner wave's MFMAs on the same SIMD.
+//
+// Arithmetic contract (shared with oracle/vq_chain.c, order "mfma8"):
+//   dot(x, e)  = fmaf chain over channels in the order, per block of 8 channels 8j..8j+7:
+//                8j, 8j+4, 8j+1, 8j+5, 8j+2, 8j+6, 8j+3, 8j+7
+//   |x|^2      = (chain over channels with (c & 7) < 4, ascending) + (chain over the rest)
+//   |e|^2      = chain over channels ascending
+//   d          = sqrt(max(fmaf(-2, dot, |x|^2) + |e|^2, 0))        (correctly rounded sqrt)
+//   idx        = lowest k attaining min d
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vq_kernels.h"
+
+namespace vqseg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------
+// codebook preparation: ET[c][k] (Cp x Kp, zero padded), enorm[k] (+inf for k >= K)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_transpose_codebook(const float* __restrict__ W, int K, int C,
+                                                             float* __restrict__ ET, int Kp, int Cp) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int k = k0 + i, c = c0 + tx;
+        tile[i][tx] = (k < K && c < C) ? W[(size_t)k * C + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, k = k0 + tx;
+        if (c < Cp && k < Kp) ET[(size_t)c * Kp + k] = tile[tx][i];
+    }
+}
+
+__global__ __launch_bounds__(256) void vq_code_norms(const float* __restrict__ ET, int K, int C, int Kp,
+                                                     float* __restrict__ enorm) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= Kp) return;
+    float s = 0.0f;
+    if (k < K) {
+        for (int c = 0; c < C; ++c) {
+            const float v = ET[(size_t)c * Kp + k];
+            s = __builtin_fmaf(v, v, s);
+        }
+    } else {
+        s = __builtin_inff();
+    }
+    enorm[k] = s;
+}
+
+// ------------------------------------------------------------------------------------
+// fused distance + argmin
+// ------------------------------------------------------------------------------------
+constexpr int BK = 16;             // channels per LDS stage
+constexpr int CHUNK = 256;         // codes per pass (8 MFMA tiles of 32)
+constexpr int TILES = CHUNK / 32;
+constexpr int ROWS_PER_WAVE = 32;
+constexpr int WAVES = 4;
+constexpr int ROWS_PER_WG = ROWS_PER_WAVE * WAVES;
+
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+    // one wave-instruction: 64 lanes x 16 B -> 1 KiB contiguous in LDS at lds_wave_base
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <bool WRITE_DMIN>
+__global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ ET,
+                                                               const float* __restrict__ enorm, long N,
+                                                               int C, int Cp, int Kp,
+                                                               long long* __restrict__ idx_out,
+                                                               float* __restrict__ dmin_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Bs = reinterpret_cast<float*>(smem);                 // [2][BK][CHUNK]
+    float* xn_s = Bs + 2 * BK * CHUNK;                          // [WAVES][32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const long row0 = (long)blockIdx.x * ROWS_PER_WG + wave * ROWS_PER_WAVE;
+    long row = row0 + r;
+    if (row > N - 1) row = N - 1;                               // clamp: loads stay in bounds
+    const float* xrow = x + row * (long)C + 4 * h;
+
+    const int n_stage = Cp / BK;
+    const int n_chunk = Kp / CHUNK;
+
+    float best_d[16];
+    int best_i[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        best_d[i] = __builtin_inff();
+        best_i[i] = 0;
+    }
+    float xn_part = 0.0f;
+
+    // LDS read base for this lane: Bs[buf][4h + t + 8j][32*tile + r]
+    const float* bs_lane = Bs + (4 * h) * CHUNK + r;
+
+    for (int chunk = 0; chunk < n_chunk; ++chunk) {
+        f32x16 acc[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+        const float* et_chunk = ET + chunk * CHUNK + lane * 4;  // + c * Kp
+
+        // ---- prologue: stage 0 -> buffer 0, A fragments of stage 0
+        __syncthreads();                                       // previous chunk's readers are done
+#pragma unroll
+        for (int q = 0; q < BK / WAVES; ++q) {
+            const int cr = wave * (BK / WAVES) + q;
+            glds16(et_chunk + (size_t)cr * Kp, Bs + cr * CHUNK);
+        }
+        f32x4 a_cur[2], a_nxt[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = 8 * j + 4 * h;
+            a_cur[j] = (col < C) ? *reinterpret_cast<const f32x4*>(xrow + 8 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();                                       // (compiler drains vmcnt before the barrier)
+
+        int cur = 0;
+        for (int s = 0; s < n_stage; ++s) {
+            const int c0n = (s + 1) * BK;
+            if (s + 1 < n_stage) {
+                float* dst = Bs + (cur ^ 1) * (BK * CHUNK);
+#pragma unroll
+                for (int q = 0; q < BK / WAVES; ++q) {
+                    const int cr = wave * (BK / WAVES) + q;
+                    glds16(et_chunk + (size_t)(c0n + cr) * Kp, dst + cr * CHUNK);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = c0n + 8 * j + 4 * h;
+                    a_nxt[j] = (col < C) ? *reinterpret_cast<const f32x4*>(xrow + c0n + 8 * j)
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            const float* bsrc = bs_lane + cur * (BK * CHUNK);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float a = a_cur[j][t];
+                    if (chunk == 0) xn_part = __builtin_fmaf(a, a, xn_part);
+                    const float* bp = bsrc + (8 * j + t) * CHUNK;
+#pragma unroll
+                    for (int tile = 0; tile < TILES; ++tile) {
+                        const float b = bp[tile * 32];
+                        acc[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tile], 0, 0, 0);
+                    }
+                }
+            }
+            a_cur[0] = a_nxt[0];
+            a_cur[1] = a_nxt[1];
+            __syncthreads();                                   // next buffer landed; this one free
+            cur ^= 1;
+        }
+
+        // ---- epilogue for this chunk: distances -> running (min, idx) per row
+        if (chunk == 0) {
+            const float xn = xn_part + __shfl_xor(xn_part, 32);
+            if (h == 0) xn_s[wave * 32 + r] = xn;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): xn_s visible within the wave
+        __builtin_amdgcn_wave_barrier();
+        float xnr[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xn_s + wave * 32 + 8 * g + 4 * h);
+            xnr[4 * g + 0] = v[0];
+            xnr[4 * g + 1] = v[1];
+            xnr[4 * g + 2] = v[2];
+            xnr[4 * g + 3] = v[3];
+        }
+#pragma unroll
+        for (int tile = 0; tile < TILES; ++tile) {
+            const int code = chunk * CHUNK + tile * 32 + r;
+            const float en = enorm[code];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float d = __builtin_fmaf(-2.0f, acc[tile][i], xnr[i]);
+                d = d + en;
+                d = __builtin_fmaxf(d, 0.0f);
+                d = __builtin_sqrtf(d);
+                if (d < best_d[i]) {
+                    best_d[i] = d;
+                    best_i[i] = code;
+                }
+            }
+        }
+    }
+
+    // ---- reduce over the 32 lanes of each half (codes live on lanes), lowest index wins ties
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float d = best_d[i];
+        int k = best_i[i];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+            const float od = __shfl_xor(d, m);
+            const int ok = __shfl_xor(k, m);
+            const bool take = (od < d) || (od == d && ok < k);
+            d = take ? od : d;
+            k = take ? ok : k;
+        }
+        best_d[i] = d;
+        best_i[i] = k;
+    }
+    if (r == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long orow = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (orow < N) {
+                idx_out[orow] = best_i[i];
+                if (WRITE_DMIN) dmin_out[orow] = best_d[i];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// gather + straight-through + commitment partial sums + code histogram (HBM-bound)
+// ------------------------------------------------------------------------------------
+constexpr int GATHER_BLOCKS_MAX = 2048;
+
+__global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                        const long long* __restrict__ idx, long N, int C,
+                                                        int training, float* __restrict__ quant,
+                                                        int* __restrict__ hist, float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = C >> 2;
+    float sq = 0.0f;
+    // one wave per row, grid-stride over rows
+    for (long row = (long)blockIdx.x * 4 + wave; row < N; row += (long)gridDim.x * 4) {
+        const long long k = idx[row];
+        if (lane == 0) atomicAdd(hist + k, 1);
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * (long)C);
+        const f32x4* wr = reinterpret_cast<const f32x4*>(W + k * (long)C);
+        f32x4* qr = reinterpret_cast<f32x4*>(quant + row * (long)C);
+        for (int v = lane; v < c4; v += 64) {
+            const f32x4 e = wr[v];
+            if (training) {
+                const f32x4 xv = xr[v];
+                f32x4 q;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    q[i] = xv[i] + (e[i] - xv[i]);             // vq_img.py:236, fp32
+                    const float dlt = q[i] - xv[i];
+                    sq = __builtin_fmaf(dlt, dlt, sq);
+                }
+                qr[v] = q;
+            } else {
+                qr[v] = e;
+            }
+        }
+    }
+    // deterministic block reduction (fixed shuffle tree, fixed wave order)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
+    __shared__ float wsum[4];
+    if (lane == 0) wsum[wave] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restrict__ partial, int n_partial,
+                                                          const int* __restrict__ hist, int K, int training,
+                                                          float commitment_weight, double numel,
+                                                          float* __restrict__ loss, float* __restrict__ dead_pct) {
+    __shared__ double sd[256];
+    __shared__ int sz[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_partial; i += 256) s += (double)partial[i];
+    int z = 0;
+    for (int k = threadIdx.x; k < K; k += 256) z += (hist[k] == 0);
+    sd[threadIdx.x] = s;
+    sz[threadIdx.x] = z;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) {
+            sd[threadIdx.x] += sd[threadIdx.x + m];
+            sz[threadIdx.x] += sz[threadIdx.x + m];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float l = 0.0f;
+        if (training && commitment_weight > 0.0f) l = (float)(sd[0] / numel) * commitment_weight;
+        loss[0] = l;
+        dead_pct[0] = 100.0f * ((float)sz[0] / (float)K);       // vq_img.py:174-175
+    }
+}
+
+__global__ __launch_bounds__(256) void vq_backward_kernel(const float* __restrict__ gq, const float* __restrict__ gloss,
+                                                          const float* __restrict__ x, const float* __restrict__ q,
+                                                          long n4, float coef, float* __restrict__ gx) {
+    const float k = gloss ? gloss[0] * coef : 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 g = reinterpret_cast<const f32x4*>(gq)[i];
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 qv = reinterpret_cast<const f32x4*>(q)[i];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf(k, xv[j] - qv[j], g[j]);
+        reinterpret_cast<f32x4*>(gx)[i] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k-means: per-cluster member lists in row order, sequential sums (== CPU scatter_add_ order)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void km_count_kernel(const long long* __restrict__ idx, long N, int* __restrict__ counts) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) atomicAdd(counts + idx[i], 1);
+}
+
+__global__ __launch_bounds__(1024) void km_scan_kernel(const int* __restrict__ counts, int K, int* __restrict__ offsets) {
+    // single block exclusive scan, K <= 1024 * items
+    __shared__ int part[1024];
+    const int per = (K + 1023) / 1024;
+    const int b = threadIdx.x * per;
+    int s = 0;
+    for (int i = 0; i < per; ++i)
+        if (b + i < K) s += counts[b + i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 1; m < 1024; m <<= 1) {
+        const int v = (threadIdx.x >= m) ? part[threadIdx.x - m] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - s;
+    for (int i = 0; i < per; ++i)
+        if (b + i < K) {
+            offsets[b + i] = run;
+            run += counts[b + i];
+        }
+    if (threadIdx.x == 1023) offsets[K] = part[1023];
+}
+
+__global__ __launch_bounds__(64) void km_lists_kernel(const long long* __restrict__ idx, long N,
+                                                      const int* __restrict__ offsets, int* __restrict__ members) {
+    // one wave per cluster: stable (row-ordered) member list
+    const int k = blockIdx.x;
+    const int lane = threadIdx.x;
+    int pos = offsets[k];
+    for (long base = 0; base < N; base += 64) {
+        const long i = base + lane;
+        const bool hit = (i < N) && (idx[i] == k);
+        const unsigned long long m = __ballot(hit);
+        if (hit) members[pos + __popcll(m & ((1ull << lane) - 1ull))] = (int)i;
+        pos += __popcll(m);
+    }
+}
+
+__global__ __launch_bounds__(256) void km_sums_kernel(const float* __restrict__ samples, int C,
+                                                      const int* __restrict__ offsets, const int* __restrict__ members,
+                                                      float* __restrict__ sums) {
+    const int k = blockIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int b = offsets[k], e = offsets[k + 1];
+    float s = 0.0f;
+    for (int m = b; m < e; ++m) s += samples[(size_t)members[m] * C + c];   // row order
+    sums[(size_t)k * C + c] = s;
+}
+
+__global__ __launch_bounds__(256) void km_counts64_kernel(const int* __restrict__ counts, int K, long long* __restrict__ out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < K) out[k] = counts[k];
+}
+
+__global__ __launch_bounds__(256) void km_finalize_kernel(const float* __restrict__ sums, const long long* __restrict__ counts,
+                                                          float* __restrict__ means, int C) {
+    const int k = blockIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long long n = counts[k];
+    if (n > 0) means[(size_t)k * C + c] = sums[(size_t)k * C + c] / (float)n;      // vq_img.py:53; :58-61 keep if empty
+}
+
+// ------------------------------------------------------------------------------------
+// host-side launch helpers (called by the C ABI in vqseg_abi.cpp)
+// ------------------------------------------------------------------------------------
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+VqPlan vq_plan(int64_t N, int C, int K) {
+    VqPlan p;
+    p.Cp = round_up(C, BK);
+    p.Kp = round_up(K, CHUNK);
+    size_t off = 0;
+    p.off_ET = off;
+    off += (size_t)p.Cp * p.Kp * sizeof(float);
+    p.off_enorm = off;
+    off += (size_t)p.Kp * sizeof(float);
+    p.off_hist = off;
+    off += (size_t)p.Kp * sizeof(int);
+    p.off_partial = off;
+    off += (size_t)GATHER_BLOCKS_MAX * sizeof(float);
+    p.bytes = (off + 255) & ~(size_t)255;
+    long blocks = (N + 3) / 4;
+    p.gather_blocks = (int)(blocks < GATHER_BLOCKS_MAX ? (blocks > 0 ? blocks : 1) : GATHER_BLOCKS_MAX);
+    return p;
+}
+
+hipError_t launch_prep(const float* W, int K, int C, const VqPlan& p, char* ws, hipStream_t st) {
+    float* ET = reinterpret_cast<float*>(ws + p.off_ET);
+    float* en = reinterpret_cast<float*>(ws + p.off_enorm);
+    dim3 g(p.Kp / 32, p.Cp / 32 + (p.Cp % 32 ? 1 : 0));
+    hipLaunchKernelGGL(vq_transpose_codebook, g, dim3(256), 0, st, W, K, C, ET, p.Kp, p.Cp);
+    hipLaunchKernelGGL(vq_code_norms, dim3((p.Kp + 255) / 256), dim3(256), 0, st, ET, K, C, p.Kp, en);
+    return hipGetLastError();
+}
+
+hipError_t launch_assign(const float* x, int64_t N, int C, const VqPlan& p, char* ws, int64_t* idx, float* dmin,
+                         hipStream_t st) {
+    const float* ET = reinterpret_cast<const float*>(ws + p.off_ET);
+    const float* en = reinterpret_cast<const float*>(ws + p.off_enorm);
+    const size_t lds = (size_t)(2 * BK * CHUNK + WAVES * 32) * sizeof(float);
+    const dim3 grid((unsigned)((N + ROWS_PER_WG - 1) / ROWS_PER_WG));
+    if (dmin)
+        hipLaunchKernelGGL(vq_assign_f32_kernel<true>, grid, dim3(256), lds, st, x, ET, en, (long)N, C, p.Cp, p.Kp,
+                           reinterpret_cast<long long*>(idx), dmin);
+    else
+        hipLaunchKernelGGL(vq_assign_f32_kernel<false>, grid, dim3(256), lds, st, x, ET, en, (long)N, C, p.Cp, p.Kp,
+                           reinterpret_cast<long long*>(idx), dmin);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather(const float* x, const float* W, const int64_t* idx, int64_t N, int C, int K, int training,
+                         float cw, const VqPlan& p, char* ws, float* quant, float* loss, float* dead, hipStream_t st) {
+    int* hist = reinterpret_cast<int*>(ws + p.off_hist);
+    float* partial = reinterpret_cast<float*>(ws + p.off_partial);
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)p.Kp * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(vq_gather_kernel, dim3(p.gather_blocks), dim3(256), 0, st, x, W,
+                       reinterpret_cast<const long long*>(idx), (long)N, C, training, quant, hist, partial);
+    hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, partial, p.gather_blocks, hist, K, training, cw,
+                       (double)N * (double)C, loss, dead);
+    return hipGetLastError();
+}
+
+hipError_t launch_backward(const float* gq, const float* gloss, const float* x, const float* q, int64_t N, int C,
+                           float cw, float* gx, hipStream_t st) {
+    const long n4 = (long)N * C / 4;
+    const float coef = (float)((double)cw * 2.0 / ((double)N * (double)C));
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(vq_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gq, gloss, x, q, n4, coef, gx);
+    return hipGetLastError();
+}
+
+KmPlan km_plan(int64_t N, int C, int K) {
+    KmPlan p;
+    p.vq = vq_plan(N, C, K);
+    size_t off = p.vq.bytes;
+    p.off_idx = off;
+    off += (size_t)N * sizeof(int64_t);
+    p.off_counts = off;
+    off += (size_t)round_up(K + 1, 64) * sizeof(int);
+    p.off_offsets = off;
+    off += (size_t)round_up(K + 1, 64) * sizeof(int);
+    p.off_members = off;
+    off += (size_t)N * sizeof(int);
+    p.off_sums = off;
+    off += (size_t)K * C * sizeof(float);
+    p.off_counts64 = off;
+    off += (size_t)round_up(K, 32) * sizeof(int64_t);
+    p.bytes = (off + 255) & ~(size_t)255;
+    return p;
+}
+
+hipError_t launch_km_accumulate(const float* samples, const float* means, int64_t N, int C, int K, const KmPlan& p,
+                                char* ws, float* sums, int64_t* counts64, hipStream_t st) {
+    hipError_t e = launch_prep(means, K, C, p.vq, ws, st);
+    if (e != hipSuccess) return e;
+    int64_t* idx = reinterpret_cast<int64_t*>(ws + p.off_idx);
+    e = launch_assign(samples, N, C, p.vq, ws, idx, nullptr, st);
+    if (e != hipSuccess) return e;
+    int* counts = reinterpret_cast<int*>(ws + p.off_counts);
+    int* offsets = reinterpret_cast<int*>(ws + p.off_offsets);
+    int* members = reinterpret_cast<int*>(ws + p.off_members);
+    e = hipMemsetAsync(counts, 0, (size_t)(K + 1) * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    long cb = (N + 255) / 256;
+    if (cb > 2048) cb = 2048;
+    if (cb < 1) cb = 1;
+    hipLaunchKernelGGL(km_count_kernel, dim3((unsigned)cb), dim3(256), 0, st, reinterpret_cast<const long long*>(idx),
+                       (long)N, counts);
+    hipLaunchKernelGGL(km_scan_kernel, dim3(1), dim3(1024), 0, st, counts, K, offsets);
+    hipLaunchKernelGGL(km_lists_kernel, dim3(K), dim3(64), 0, st, reinterpret_cast<const long long*>(idx), (long)N,
+                       offsets, members);
+    hipLaunchKernelGGL(km_sums_kernel, dim3(K, (C + 255) / 256), dim3(256), 0, st, samples, C, offsets, members, sums);
+    hipLaunchKernelGGL(km_counts64_kernel, dim3((K + 255) / 256), dim3(256), 0, st, counts, K,
+                       reinterpret_cast<long long*>(counts64));
+    return hipGetLastError();
+}
+
+hipError_t launch_km_finalize(const float* sums, const int64_t* counts64, float* means, int C, int K, hipStream_t st) {
+    hipLaunchKernelGGL(km_finalize_kernel, dim3(K, (C + 255) / 256), dim3(256), 0, st, sums,
+                       reinterpret_cast<const long long*>(counts64), means, C);
+    return hipGetLastError();
+}
+
+}  // namespace vqseg

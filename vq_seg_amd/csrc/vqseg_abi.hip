@@ -1,0 +1,137 @@
+// vqseg_abi.hip -- extern "C" entry points declared in include/vqseg.h.
+// Argument validation + workspace carving + kernel enqueue; never allocates, never syncs.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vqseg.h"
+#include "vq_kernels.h"
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int hip_fail(hipError_t e, const char* where) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return (int)e;
+}
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_shape(int64_t n, int c, int k) {
+    if (n <= 0 || c <= 0 || k <= 0) return fail(VQSEG_EINVAL, "n_rows, channels and n_codes must be positive (got %lld, %d, %d)", (long long)n, c, k);
+    if (c % 4) return fail(VQSEG_EINVAL, "channels must be a multiple of 4 (got %d)", c);
+    if (n > (int64_t)1 << 31) return fail(VQSEG_EINVAL, "n_rows too large (%lld)", (long long)n);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int vqseg_abi_version(void) { return VQSEG_ABI_VERSION; }
+const char* vqseg_last_error(void) { return g_err; }
+
+const char* vqseg_kernel_name(const char* entry) {
+    if (!entry) return "";
+    if (!strcmp(entry, "vqseg_vq_forward_f32") || !strcmp(entry, "vqseg_vq_assign_f32") ||
+        !strcmp(entry, "vqseg_kmeans_f32") || !strcmp(entry, "vqseg_kmeans_accumulate_f32"))
+        return "vq_assign_f32_kernel";
+    if (!strcmp(entry, "vqseg_vq_backward_f32")) return "vq_backward_kernel";
+    if (!strcmp(entry, "vqseg_kmeans_finalize_f32")) return "km_finalize_kernel";
+    return "";
+}
+
+size_t vqseg_vq_workspace_bytes(int64_t n, int c, int k) {
+    if (n <= 0 || c <= 0 || k <= 0) return 0;
+    return vqseg::vq_plan(n, c, k).bytes;
+}
+
+int vqseg_vq_assign_f32(const float* x, const float* codebook, int64_t n, int c, int k, int64_t* idx, float* dmin,
+                        void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = check_shape(n, c, k)) return rc;
+    if (!x || !codebook || !idx || !ws) return fail(VQSEG_EINVAL, "null pointer argument");
+    if (!aligned16(x) || !aligned16(ws)) return fail(VQSEG_EINVAL, "x and workspace must be 16-byte aligned");
+    const vqseg::VqPlan p = vqseg::vq_plan(n, c, k);
+    if (ws_bytes < p.bytes) return fail(VQSEG_ENOSPC, "workspace %zu < %zu bytes", ws_bytes, p.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = vqseg::launch_prep(codebook, k, c, p, static_cast<char*>(ws), st);
+    if (e != hipSuccess) return hip_fail(e, "vq codebook prep");
+    e = vqseg::launch_assign(x, n, c, p, static_cast<char*>(ws), idx, dmin, st);
+    if (e != hipSuccess) return hip_fail(e, "vq_assign_f32_kernel");
+    return 0;
+}
+
+int vqseg_vq_forward_f32(const float* x, const float* codebook, int64_t n, int c, int k, int training, float cw,
+                         float* quant, int64_t* idx, float* loss, float* dead_pct, float* dmin, void* ws,
+                         size_t ws_bytes, void* stream) {
+    if (!quant || !loss || !dead_pct) return fail(VQSEG_EINVAL, "null output pointer");
+    if (!aligned16(quant) || !aligned16(codebook)) return fail(VQSEG_EINVAL, "quant and codebook must be 16-byte aligned");
+    if (int rc = vqseg_vq_assign_f32(x, codebook, n, c, k, idx, dmin, ws, ws_bytes, stream)) return rc;
+    const vqseg::VqPlan p = vqseg::vq_plan(n, c, k);
+    hipError_t e = vqseg::launch_gather(x, codebook, idx, n, c, k, training, cw, p, static_cast<char*>(ws), quant, loss,
+                                        dead_pct, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "vq_gather_kernel");
+    return 0;
+}
+
+int vqseg_vq_backward_f32(const float* gq, const float* gloss, const float* x, const float* quant, int64_t n, int c,
+                          float cw, float* gx, void* stream) {
+    if (int rc = check_shape(n, c, 1)) return rc;
+    if (!gq || !x || !quant || !gx) return fail(VQSEG_EINVAL, "null pointer argument");
+    if (!aligned16(gq) || !aligned16(x) || !aligned16(quant) || !aligned16(gx))
+        return fail(VQSEG_EINVAL, "tensors must be 16-byte aligned");
+    hipError_t e = vqseg::launch_backward(gq, gloss, x, quant, n, c, cw, gx, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "vq_backward_kernel");
+    return 0;
+}
+
+size_t vqseg_kmeans_workspace_bytes(int64_t n, int c, int k) {
+    if (n <= 0 || c <= 0 || k <= 0) return 0;
+    return vqseg::km_plan(n, c, k).bytes;
+}
+
+int vqseg_kmeans_accumulate_f32(const float* samples, const float* means, int64_t n, int c, int k, float* sums,
+                                int64_t* counts, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = check_shape(n, c, k)) return rc;
+    if (!samples || !means || !sums || !counts || !ws) return fail(VQSEG_EINVAL, "null pointer argument");
+    if (!aligned16(samples) || !aligned16(ws)) return fail(VQSEG_EINVAL, "samples and workspace must be 16-byte aligned");
+    const vqseg::KmPlan p = vqseg::km_plan(n, c, k);
+    if (ws_bytes < p.bytes) return fail(VQSEG_ENOSPC, "workspace %zu < %zu bytes", ws_bytes, p.bytes);
+    hipError_t e = vqseg::launch_km_accumulate(samples, means, n, c, k, p, static_cast<char*>(ws), sums, counts,
+                                               static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "kmeans accumulate");
+    return 0;
+}
+
+int vqseg_kmeans_finalize_f32(const float* sums, const int64_t* counts, float* means, int c, int k, void* stream) {
+    if (c <= 0 || k <= 0 || !sums || !counts || !means) return fail(VQSEG_EINVAL, "bad argument");
+    hipError_t e = vqseg::launch_km_finalize(sums, counts, means, c, k, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "km_finalize_kernel");
+    return 0;
+}
+
+int vqseg_kmeans_f32(const float* samples, float* means, int64_t* bins, int64_t n, int c, int k, int iters, void* ws,
+                     size_t ws_bytes, void* stream) {
+    if (int rc = check_shape(n, c, k)) return rc;
+    if (!samples || !means || !bins || !ws) return fail(VQSEG_EINVAL, "null pointer argument");
+    if (iters < 0) return fail(VQSEG_EINVAL, "iters must be >= 0");
+    const vqseg::KmPlan p = vqseg::km_plan(n, c, k);
+    if (ws_bytes < p.bytes) return fail(VQSEG_ENOSPC, "workspace %zu < %zu bytes", ws_bytes, p.bytes);
+    char* w = static_cast<char*>(ws);
+    float* sums = reinterpret_cast<float*>(w + p.off_sums);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int it = 0; it < iters; ++it) {
+        if (int rc = vqseg_kmeans_accumulate_f32(samples, means, n, c, k, sums, bins, ws, ws_bytes, stream)) return rc;
+        hipError_t e = vqseg::launch_km_finalize(sums, bins, means, c, k, st);
+        if (e != hipSuccess) return hip_fail(e, "km_finalize_kernel");
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+"""VectorQuantizer / EuclideanCodebook with the reference's module surface, computed by
+the gfx950 HIP kernels behind include/vqseg.h.
+
+Mirrors vector_quantizer/vq_img.py of the reference: constructor keywords (:194-205), the
+submodule path `.codebook.embedding.weight`, the `initted` flag, train/eval switching and
+the 4-tuple returned by forward (:228-244).  The arithmetic is NOT the reference's op
+sequence: distance + argmin + gather + straight-through + commitment + dead-code
+histogram run as fused kernels (vq_seg_amd/csrc/vq_kernels.hip), and backward is the
+analytic gradient instead of an autograd graph over cdist.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import _hip
+from ..dist import world_size as _world_size, broadcast0 as _broadcast0, all_reduce_sum as _all_reduce_sum
+
+
+class _VQFunction(torch.autograd.Function):
+    """rows (N, C) -> quant (N, C), idx (N,), loss (1,), dead_pct ()."""
+
+    @staticmethod
+    def forward(ctx, rows, codebook, training, commitment_weight):
+        quant, idx, loss, dead = _hip.vq_forward(rows, codebook, training, commitment_weight)
+        ctx.commitment_weight = float(commitment_weight)
+        ctx.training = bool(training)
+        if training:
+            ctx.save_for_backward(rows, quant)
+        ctx.mark_non_differentiable(idx, dead)
+        return quant, idx, loss, dead
+
+    @staticmethod
+    def backward(ctx, g_quant, _g_idx, g_loss, _g_dead):
+        if not ctx.training:
+            return g_quant, None, None, None                # eval: quant is a pure gather (constant in x)
+        rows, quant = ctx.saved_tensors
+        if g_quant is None:
+            g_quant = torch.zeros_like(rows)
+        g_quant = g_quant.contiguous()
+        gl = g_loss.contiguous() if (g_loss is not None and ctx.commitment_weight > 0) else None
+        gx = _hip.vq_backward(g_quant, gl, rows, quant, ctx.commitment_weight)
+        return gx, None, None, None                         # the codebook receives no gradient (vq_img.py:236-239)
+
+
+def _rows_of(x: torch.Tensor):
+    """(B, C, H, W) any float -> contiguous fp32 (B*H*W, C) rows (free for channels_last input)."""
+    b, c, h, w = x.shape
+    rows = x.to(torch.float32).permute(0, 2, 3, 1)          # vq_img.py:229,232
+    if not rows.is_contiguous():
+        rows = rows.contiguous()
+    return rows.reshape(b * h * w, c)
+
+
+def kmeans_init_means(rows: torch.Tensor, num_clusters: int) -> torch.Tensor:
+    """sample_vectors (vq_img.py:10-17): pick the initial means with the device RNG."""
+    n = rows.shape[0]
+    if n >= num_clusters:
+        pick = torch.randperm(n, device=rows.device)[:num_clusters]
+    else:
+        pick = torch.randint(0, n, (num_clusters,), device=rows.device)
+    return rows[pick].contiguous()
+
+
+def kmeans(rows: torch.Tensor, num_clusters: int, num_iters: int, init_means: torch.Tensor = None):
+    """kmeans (vq_img.py:29-63) on the HIP path.  With torch.distributed initialised and more
+    than one rank, every rank ends with the same means: rank 0's initial draw is broadcast
+    and the per-iteration cluster sums / counts are all-reduced over RCCL."""
+    means = (kmeans_init_means(rows, num_clusters) if init_means is None else init_means.clone()).contiguous()
+    if _world_size() == 1:
+        return _hip.kmeans(rows, means, num_iters)
+    _broadcast0(means)
+    counts = torch.zeros(num_clusters, dtype=torch.int64, device=rows.device)
+    for _ in range(num_iters):
+        sums, counts = _hip.kmeans_accumulate(rows, means)
+        _all_reduce_sum(sums)
+        _all_reduce_sum(counts)
+        _hip.kmeans_finalize(sums, counts, means)
+    return means, counts
+
+
+class EuclideanCodebook(nn.Module):
+    def __init__(self, embedding_dim, num_embeddings, kmeans_init, kmeans_iters, decay, eps, num_codebook):
+        super().__init__()
+        self.kmeans_init = kmeans_init
+        self.kmeans_iters = kmeans_iters
+        self.initted = False
+        self.num_codebook = num_codebook
+        self.decay = decay                                   # accepted, unused -- as in the reference
+        self.embedding = nn.Embedding(num_embeddings, embedding_dim)
+        self.num_embeddings = num_embeddings
+        self.embedding_dim = embedding_dim
+        if not kmeans_init:
+            self.embedding.weight.data.uniform_(-1 / num_embeddings, 1 / num_embeddings)   # vq_img.py:156-158
+            self.initted = True
+
+    @torch.no_grad()
+    def _kmeans_init(self, rows: torch.Tensor):
+        if self.initted:
+            return
+        means, _ = kmeans(rows, self.num_embeddings, self.kmeans_iters)
+        self.embedding.weight.data.copy_(means)
+        self.initted = True
+
+    def forward(self, x: torch.Tensor):
+        """x (B, HW, C) -> quantized (B, HW, C), embed_idx (B, HW), code_usage (dead-code %)."""
+        b, hw, c = x.shape
+        rows = x.float().reshape(b * hw, c).contiguous()
+        if self.kmeans_init and self.training:
+            self._kmeans_init(rows.detach())
+        quant, idx, _loss, dead = _VQFunction.apply(rows.detach(), self.embedding.weight.detach(), False, 0.0)
+        return quant.reshape(b, hw, c), idx.reshape(b, hw), dead
+
+
+class VectorQuantizer(nn.Module):
+    def __init__(self, dim, num_embeddings, embedding_dim=None, decay=0.8, eps=1e-5, kmeans_init=False,
+                 kmeans_iters=10, distance="euclidean", commitment_weight=1, num_codebook=1):
+        super().__init__()
+        embedding_dim = embedding_dim if embedding_dim is not None else dim
+        self.num_embeddings = num_embeddings
+        self.eps = eps
+        self.commitment_weight = commitment_weight
+        if distance != "euclidean":
+            raise NotImplementedError(
+                f"distance={distance!r}: only the euclidean codebook is on the accelerated path (SURVEY 2 #1; the "
+                "cosine codebook is unused by the target configs)")
+        self.codebook = EuclideanCodebook(embedding_dim=embedding_dim, num_embeddings=num_embeddings,
+                                          kmeans_init=kmeans_init, kmeans_iters=kmeans_iters, decay=decay, eps=eps,
+                                          num_codebook=num_codebook)
+
+    def forward(self, x: torch.Tensor):
+        """x (B, C, H, W) -> (quantize (B, C, H, W) f32, embed_index (B, H, W) i64, loss (1,), code_usage ())."""
+        b, c, h, w = x.shape
+        rows = _rows_of(x)
+        cb = self.codebook
+        if cb.kmeans_init and self.training:
+            cb._kmeans_init(rows.detach())                                   # vq_img.py:165-166
+        quant, idx, loss, dead = _VQFunction.apply(rows, cb.embedding.weight.detach(), self.training,
+                                                   float(self.commitment_weight))
+        quantize = quant.reshape(b, h, w, c).permute(0, 3, 1, 2)             # vq_img.py:242 (channels_last view)
+        return quantize, idx.reshape(b, h, w), loss, dead
