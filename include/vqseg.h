@@ -57,15 +57,25 @@ const char* vqseg_kernel_name(const char* entry_point);
  *   dmin      [N]    f32   optional out (may be NULL): the winning distance, for tests
  * ---------------------------------------------------------------------------------- */
 size_t vqseg_vq_workspace_bytes(int64_t n_rows, int channels, int n_codes);
-int vqseg_vq_forward_f32(const float* x, const float* codebook, int64_t n_rows, int channels,
-                         int n_codes, int training, float commitment_weight, float* quant,
-                         int64_t* idx, float* loss, float* dead_pct, float* dmin,
-                         void* workspace, size_t workspace_bytes, void* stream);
+int vqseg_vq_forward_f32(const float* x, const float* codebook, const void* prepared,
+                         int64_t n_rows, int channels, int n_codes, int training,
+                         float commitment_weight, float* quant, int64_t* idx, float* loss,
+                         float* dead_pct, float* dmin, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* Assignment only (no gather): used by k-means and by tests. */
-int vqseg_vq_assign_f32(const float* x, const float* codebook, int64_t n_rows, int channels,
-                        int n_codes, int64_t* idx, float* dmin, void* workspace,
-                        size_t workspace_bytes, void* stream);
+int vqseg_vq_assign_f32(const float* x, const float* codebook, const void* prepared,
+                        int64_t n_rows, int channels, int n_codes, int64_t* idx, float* dmin,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Prepared codebook: the kernel-side image of an nn.Embedding weight (4-channel
+ * interleaved, code-padded copy + |e_k|^2).  The reference's codebook never changes after
+ * its k-means init (no gradient, no EMA -- vq_img.py:236-239), so callers prepare once
+ * and pass the blob to every forward; `prepared == NULL` makes forward/assign prepare
+ * into the workspace on every call instead. */
+size_t vqseg_vq_prepared_bytes(int channels, int n_codes);
+int vqseg_vq_prepare_f32(const float* codebook, int channels, int n_codes, void* prepared,
+                         size_t prepared_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------- *
  * Vector quantiser backward (analytic; autograd of vq_img.py:236-240):

@@ -34,9 +34,9 @@ def test_workspace_and_argument_validation_without_gpu():
     assert L.vqseg_vq_workspace_bytes(0, 512, 512) == 0
     assert L.vqseg_kmeans_workspace_bytes(8192, 512, 512) > L.vqseg_vq_workspace_bytes(8192, 512, 512)
     # null pointers / bad shapes are rejected before anything touches a device
-    rc = L.vqseg_vq_assign_f32(None, None, 16, 6, 8, None, None, None, 0, None)
+    rc = L.vqseg_vq_assign_f32(None, None, None, 16, 6, 8, None, None, None, 0, None)
     assert rc == -1 and b"multiple of 4" in L.vqseg_last_error()
-    rc = L.vqseg_vq_assign_f32(None, None, 16, 8, 8, None, None, None, 0, None)
+    rc = L.vqseg_vq_assign_f32(None, None, None, 16, 8, 8, None, None, None, 0, None)
     assert rc == -1 and b"null" in L.vqseg_last_error()
     assert L.vqseg_kernel_name(b"vqseg_vq_forward_f32") == b"vq_assign_f32_kernel"
 

@@ -22,10 +22,12 @@ SYMBOLS = {
     "vqseg_last_error": (c_char_p, []),
     "vqseg_kernel_name": (c_char_p, [c_char_p]),
     "vqseg_vq_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
-    "vqseg_vq_forward_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
-                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "vqseg_vq_assign_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+    "vqseg_vq_forward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vqseg_vq_assign_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_size_t, c_void_p]),
+    "vqseg_vq_prepared_bytes": (c_size_t, [c_int, c_int]),
+    "vqseg_vq_prepare_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "vqseg_vq_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p,
                                       c_void_p]),
     "vqseg_kmeans_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
@@ -87,8 +89,21 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------
+def vq_prepare(codebook: torch.Tensor) -> torch.Tensor:
+    """Build the kernel-side image of a codebook (K, C); reuse it until the codebook changes."""
+    L = lib()
+    k, c = codebook.shape
+    wp = _dev(codebook, torch.float32, "codebook")
+    nbytes = L.vqseg_vq_prepared_bytes(c, k)
+    blob = _workspace(nbytes, codebook.device)
+    with torch.cuda.device(codebook.device):
+        rc = L.vqseg_vq_prepare_f32(wp, c, k, blob.data_ptr(), nbytes, _stream())
+    _check(rc, "vqseg_vq_prepare_f32")
+    return blob
+
+
 def vq_forward(rows: torch.Tensor, codebook: torch.Tensor, training: bool, commitment_weight: float,
-               want_dmin: bool = False):
+               want_dmin: bool = False, prepared: Optional[torch.Tensor] = None):
     """rows (N, C) f32, codebook (K, C) f32 -> quant (N, C), idx (N,) i64, loss (1,), dead_pct (), [dmin (N,)]."""
     L = lib()
     n, c = rows.shape
@@ -102,7 +117,8 @@ def vq_forward(rows: torch.Tensor, codebook: torch.Tensor, training: bool, commi
     nbytes = L.vqseg_vq_workspace_bytes(n, c, k)
     ws = _workspace(nbytes, dev)
     with torch.cuda.device(dev):
-        rc = L.vqseg_vq_forward_f32(xp, wp, n, c, k, int(bool(training)), float(commitment_weight), quant.data_ptr(),
+        rc = L.vqseg_vq_forward_f32(xp, wp, prepared.data_ptr() if prepared is not None else None, n, c, k,
+                                    int(bool(training)), float(commitment_weight), quant.data_ptr(),
                                     idx.data_ptr(), scal.data_ptr(), scal.data_ptr() + 4,
                                     dmin.data_ptr() if want_dmin else None, ws.data_ptr(), nbytes, _stream())
     _check(rc, "vqseg_vq_forward_f32")
@@ -110,7 +126,8 @@ def vq_forward(rows: torch.Tensor, codebook: torch.Tensor, training: bool, commi
     return out + (dmin,) if want_dmin else out
 
 
-def vq_assign(rows: torch.Tensor, codebook: torch.Tensor, want_dmin: bool = False):
+def vq_assign(rows: torch.Tensor, codebook: torch.Tensor, want_dmin: bool = False,
+              prepared: Optional[torch.Tensor] = None):
     L = lib()
     n, c = rows.shape
     k = codebook.shape[0]
@@ -121,7 +138,8 @@ def vq_assign(rows: torch.Tensor, codebook: torch.Tensor, want_dmin: bool = Fals
     nbytes = L.vqseg_vq_workspace_bytes(n, c, k)
     ws = _workspace(nbytes, dev)
     with torch.cuda.device(dev):
-        rc = L.vqseg_vq_assign_f32(xp, wp, n, c, k, idx.data_ptr(), dmin.data_ptr() if want_dmin else None,
+        rc = L.vqseg_vq_assign_f32(xp, wp, prepared.data_ptr() if prepared is not None else None, n, c, k,
+                                   idx.data_ptr(), dmin.data_ptr() if want_dmin else None,
                                    ws.data_ptr(), nbytes, _stream())
     _check(rc, "vqseg_vq_assign_f32")
     return (idx, dmin) if want_dmin else idx

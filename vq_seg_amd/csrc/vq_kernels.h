@@ -7,8 +7,9 @@
 namespace vqseg {
 
 struct VqPlan {
-    int Cp, Kp;                 // channels / codes padded to the kernel's stage / chunk size
-    size_t off_ET, off_enorm, off_hist, off_partial, bytes;
+    int Cp, Kp;                 // channels; codes padded to a multiple of 32
+    int T;                      // accumulator tiles (32 codes each) per wave chosen for this shape
+    size_t off_prepared, off_keys, off_hist, off_partial, bytes;
     int gather_blocks;
 };
 struct KmPlan {
@@ -19,9 +20,10 @@ struct KmPlan {
 VqPlan vq_plan(int64_t N, int C, int K);
 KmPlan km_plan(int64_t N, int C, int K);
 
-hipError_t launch_prep(const float* W, int K, int C, const VqPlan& p, char* ws, hipStream_t st);
-hipError_t launch_assign(const float* x, int64_t N, int C, const VqPlan& p, char* ws, int64_t* idx, float* dmin,
-                         hipStream_t st);
+size_t prepared_bytes(int C, int K);
+hipError_t launch_prepare(const float* W, int K, int C, void* prepared, hipStream_t st);
+hipError_t launch_assign(const float* x, int64_t N, int C, int K, const void* prepared, const VqPlan& p, char* ws,
+                         int64_t* idx, float* dmin, hipStream_t st);
 hipError_t launch_gather(const float* x, const float* W, const int64_t* idx, int64_t N, int C, int K, int training,
                          float cw, const VqPlan& p, char* ws, float* quant, float* loss, float* dead, hipStream_t st);
 hipError_t launch_backward(const float* gq, const float* gloss, const float* x, const float* q, int64_t N, int C,

@@ -35,49 +35,68 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------
-// codebook preparation: ET[c][k] (Cp x Kp, zero padded), enorm[k] (+inf for k >= K)
+// codebook preparation ("prepared codebook" blob, valid until the codebook changes):
+//   E4[c/4][k][4]  (Cp/4 x Kp x 4, zero padded)  -- 4 channels of one code are one 16-byte
+//                  LDS/HBM word, so one ds_read_b128 feeds four MFMAs
+//   enorm[k]       |e_k|^2 as an ascending fmaf chain; +inf for k >= K (never selected)
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vq_transpose_codebook(const float* __restrict__ W, int K, int C,
-                                                             float* __restrict__ ET, int Kp, int Cp) {
-    __shared__ float tile[32][33];
-    const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
-    for (int i = ty; i < 32; i += 8) {
-        const int k = k0 + i, c = c0 + tx;
-        tile[i][tx] = (k < K && c < C) ? W[(size_t)k * C + c] : 0.0f;
-    }
-    __syncthreads();
-    for (int i = ty; i < 32; i += 8) {
-        const int c = c0 + i, k = k0 + tx;
-        if (c < Cp && k < Kp) ET[(size_t)c * Kp + k] = tile[tx][i];
+__global__ __launch_bounds__(256) void vq_pack_codebook(const float* __restrict__ W, int K, int C,
+                                                        float* __restrict__ E4, int Kp, int Cp) {
+    // one thread per (c4, k): reads 16 B of row k, writes 16 B
+    const long total = (long)(Cp / 4) * Kp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % Kp);
+        const int c = (int)(i / Kp) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < K && c < C) v = *reinterpret_cast<const f32x4*>(W + (size_t)k * C + c);   // C % 4 == 0
+        reinterpret_cast<f32x4*>(E4)[i] = v;
     }
 }
 
-__global__ __launch_bounds__(256) void vq_code_norms(const float* __restrict__ ET, int K, int C, int Kp,
-                                                     float* __restrict__ enorm) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(64) void vq_code_norms(const float* __restrict__ W, int K, int C, int Kp,
+                                                    float* __restrict__ enorm) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= Kp) return;
-    float s = 0.0f;
+    float s = __builtin_inff();
     if (k < K) {
-        for (int c = 0; c < C; ++c) {
-            const float v = ET[(size_t)c * Kp + k];
-            s = __builtin_fmaf(v, v, s);
+        s = 0.0f;
+        const f32x4* row = reinterpret_cast<const f32x4*>(W + (size_t)k * C);
+        const int n4 = C >> 2;
+        int i = 0;
+        for (; i + 8 <= n4; i += 8) {                            // 8 independent 16-B loads in flight
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = row[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = __builtin_fmaf(v[u][e], v[u][e], s);
         }
-    } else {
-        s = __builtin_inff();
+        for (; i < n4; ++i) {
+            const f32x4 v = row[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = __builtin_fmaf(v[e], v[e], s);
+        }
     }
     enorm[k] = s;
 }
 
 // ------------------------------------------------------------------------------------
 // fused distance + argmin
+//
+// Work item (one workgroup, 4 waves): 128 pixel rows x (32*T) codes, all channels.
+//   wave w owns rows [32w, 32w+32): T accumulator tiles of 32x32 (16 VGPRs each);
+//   the code slab E4[:, code0 : code0+32T, :] streams through LDS in stages of BK channels
+//   (BK*T = 128, i.e. 16 KiB per stage, double buffered, filled by global_load_lds);
+//   B fragments are fetched one 8-channel block ahead of the MFMAs that use them.
+// Results of different code groups of the same row are merged with a 64-bit atomicMin on
+//   key = (float_bits(d) << 32) | code   (d >= 0, so unsigned order == float order and the
+//   low word breaks ties towards the lowest code) -- order independent, hence deterministic.
 // ------------------------------------------------------------------------------------
-constexpr int BK = 16;             // channels per LDS stage
-constexpr int CHUNK = 256;         // codes per pass (8 MFMA tiles of 32)
-constexpr int TILES = CHUNK / 32;
 constexpr int ROWS_PER_WAVE = 32;
 constexpr int WAVES = 4;
 constexpr int ROWS_PER_WG = ROWS_PER_WAVE * WAVES;
+constexpr int STAGE_FLOATS = 4096;   // BK * 32T floats = 16 KiB
 
 __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
     // one wave-instruction: 64 lanes x 16 B -> 1 KiB contiguous in LDS at lds_wave_base
@@ -85,16 +104,18 @@ __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <bool WRITE_DMIN>
+template <int T>
 __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const float* __restrict__ x,
-                                                               const float* __restrict__ ET,
+                                                               const float* __restrict__ E4,
                                                                const float* __restrict__ enorm, long N,
                                                                int C, int Cp, int Kp,
-                                                               long long* __restrict__ idx_out,
-                                                               float* __restrict__ dmin_out) {
+                                                               unsigned long long* __restrict__ keys) {
+    constexpr int CODES = 32 * T;                // codes per workgroup
+    constexpr int BK = 128 / T;                  // channels per stage
+    constexpr int JB = BK / 8;                   // 8-channel blocks per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Bs = reinterpret_cast<float*>(smem);                 // [2][BK][CHUNK]
-    float* xn_s = Bs + 2 * BK * CHUNK;                          // [WAVES][32]
+    float* Bs = reinterpret_cast<float*>(smem);                 // [2][BK/4][CODES][4]
+    float* xn_s = Bs + 2 * STAGE_FLOATS;                        // [WAVES][32]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -104,119 +125,123 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const float* __re
     long row = row0 + r;
     if (row > N - 1) row = N - 1;                               // clamp: loads stay in bounds
     const float* xrow = x + row * (long)C + 4 * h;
+    const int code0 = blockIdx.y * CODES;
+    const int n_stage = (Cp + BK - 1) / BK;
 
-    const int n_stage = Cp / BK;
-    const int n_chunk = Kp / CHUNK;
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    float xn_part = 0.0f;
 
+    // stage fill: the stage is (BK/4) slabs of CODES*4 floats; one wave-instruction moves 256 floats
+    // (64 codes x 4 channels).  A stage is 16 wave-instructions, 4 per wave.
+    auto fill = [&](int stage, int buf) {
+        float* dst = Bs + buf * STAGE_FLOATS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = wave * 4 + q;                     // 0..15, 256 floats each
+            const int fl = piece * 256 + lane * 4;              // float offset inside the stage
+            const int c4 = fl / (CODES * 4);                    // slab (4-channel group) inside the stage
+            const int code = (fl % (CODES * 4)) >> 2;
+            int slab = stage * (BK / 4) + c4;
+            if (slab > Cp / 4 - 1) slab = Cp / 4 - 1;           // past the last channel: A is zero there, any finite B works
+            const float* src = E4 + ((size_t)slab * Kp + code0 + code) * 4;
+            glds16(src, dst + piece * 256);
+        }
+    };
+    auto load_a = [&](int stage, f32x4 (&a)[JB]) {
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const int col = stage * BK + 8 * j + 4 * h;
+            a[j] = (col < C) ? *reinterpret_cast<const f32x4*>(xrow + stage * BK + 8 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    f32x4 a_cur[JB], a_nxt[JB];
+    fill(0, 0);
+    load_a(0, a_cur);
+#pragma unroll
+    for (int j = 0; j < JB; ++j) a_nxt[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                           // drains vmcnt, then barrier
+
+    // B fragment of lane (r, h) for block j, tile t: Bs[buf][2j + h][32 t + r][0..3]
+    const float* bs_lane = Bs + (h * CODES + r) * 4;
+    int cur = 0;
+    for (int s = 0; s < n_stage; ++s) {
+        if (s + 1 < n_stage) {
+            fill(s + 1, cur ^ 1);
+            load_a(s + 1, a_nxt);
+        }
+        const float* bsrc = bs_lane + cur * STAGE_FLOATS;
+        f32x4 b_cur[T], b_nxt[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) b_cur[t] = *reinterpret_cast<const f32x4*>(bsrc + t * 128);
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            if (j + 1 < JB) {
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    b_nxt[t] = *reinterpret_cast<const f32x4*>(bsrc + (2 * (j + 1)) * CODES * 4 + t * 128);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = a_cur[j][e];
+                xn_part = __builtin_fmaf(a, a, xn_part);
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b_cur[t][e], acc[t], 0, 0, 0);
+            }
+            if (j + 1 < JB) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) b_cur[t] = b_nxt[t];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) a_cur[j] = a_nxt[j];
+        __syncthreads();                                       // next buffer landed; this one is free
+        cur ^= 1;
+    }
+
+    // ---- epilogue: distances -> (min, code) per row over this workgroup's codes
+    {
+        const float xn = xn_part + __shfl_xor(xn_part, 32);
+        if (h == 0) xn_s[wave * 32 + r] = xn;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): xn_s visible within the wave
+    __builtin_amdgcn_wave_barrier();
+    float xnr[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xn_s + wave * 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xnr[4 * g + e] = v[e];
+    }
     float best_d[16];
     int best_i[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         best_d[i] = __builtin_inff();
-        best_i[i] = 0;
+        best_i[i] = 0x7fffffff;
     }
-    float xn_part = 0.0f;
-
-    // LDS read base for this lane: Bs[buf][4h + t + 8j][32*tile + r]
-    const float* bs_lane = Bs + (4 * h) * CHUNK + r;
-
-    for (int chunk = 0; chunk < n_chunk; ++chunk) {
-        f32x16 acc[TILES];
 #pragma unroll
-        for (int t = 0; t < TILES; ++t)
+    for (int t = 0; t < T; ++t) {
+        const int code = code0 + t * 32 + r;
+        const float en = enorm[code];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-
-        const float* et_chunk = ET + chunk * CHUNK + lane * 4;  // + c * Kp
-
-        // ---- prologue: stage 0 -> buffer 0, A fragments of stage 0
-        __syncthreads();                                       // previous chunk's readers are done
-#pragma unroll
-        for (int q = 0; q < BK / WAVES; ++q) {
-            const int cr = wave * (BK / WAVES) + q;
-            glds16(et_chunk + (size_t)cr * Kp, Bs + cr * CHUNK);
-        }
-        f32x4 a_cur[2], a_nxt[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = 8 * j + 4 * h;
-            a_cur[j] = (col < C) ? *reinterpret_cast<const f32x4*>(xrow + 8 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        __syncthreads();                                       // (compiler drains vmcnt before the barrier)
-
-        int cur = 0;
-        for (int s = 0; s < n_stage; ++s) {
-            const int c0n = (s + 1) * BK;
-            if (s + 1 < n_stage) {
-                float* dst = Bs + (cur ^ 1) * (BK * CHUNK);
-#pragma unroll
-                for (int q = 0; q < BK / WAVES; ++q) {
-                    const int cr = wave * (BK / WAVES) + q;
-                    glds16(et_chunk + (size_t)(c0n + cr) * Kp, dst + cr * CHUNK);
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = c0n + 8 * j + 4 * h;
-                    a_nxt[j] = (col < C) ? *reinterpret_cast<const f32x4*>(xrow + c0n + 8 * j)
-                                         : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            const float* bsrc = bs_lane + cur * (BK * CHUNK);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float a = a_cur[j][t];
-                    if (chunk == 0) xn_part = __builtin_fmaf(a, a, xn_part);
-                    const float* bp = bsrc + (8 * j + t) * CHUNK;
-#pragma unroll
-                    for (int tile = 0; tile < TILES; ++tile) {
-                        const float b = bp[tile * 32];
-                        acc[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tile], 0, 0, 0);
-                    }
-                }
-            }
-            a_cur[0] = a_nxt[0];
-            a_cur[1] = a_nxt[1];
-            __syncthreads();                                   // next buffer landed; this one free
-            cur ^= 1;
-        }
-
-        // ---- epilogue for this chunk: distances -> running (min, idx) per row
-        if (chunk == 0) {
-            const float xn = xn_part + __shfl_xor(xn_part, 32);
-            if (h == 0) xn_s[wave * 32 + r] = xn;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): xn_s visible within the wave
-        __builtin_amdgcn_wave_barrier();
-        float xnr[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xn_s + wave * 32 + 8 * g + 4 * h);
-            xnr[4 * g + 0] = v[0];
-            xnr[4 * g + 1] = v[1];
-            xnr[4 * g + 2] = v[2];
-            xnr[4 * g + 3] = v[3];
-        }
-#pragma unroll
-        for (int tile = 0; tile < TILES; ++tile) {
-            const int code = chunk * CHUNK + tile * 32 + r;
-            const float en = enorm[code];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float d = __builtin_fmaf(-2.0f, acc[tile][i], xnr[i]);
-                d = d + en;
-                d = __builtin_fmaxf(d, 0.0f);
-                d = __builtin_sqrtf(d);
-                if (d < best_d[i]) {
-                    best_d[i] = d;
-                    best_i[i] = code;
-                }
+        for (int i = 0; i < 16; ++i) {
+            float d = __builtin_fmaf(-2.0f, acc[t][i], xnr[i]);
+            d = d + en;
+            d = __builtin_fmaxf(d, 0.0f);
+            d = __builtin_sqrtf(d);
+            if (d < best_d[i]) {
+                best_d[i] = d;
+                best_i[i] = code;
             }
         }
     }
-
-    // ---- reduce over the 32 lanes of each half (codes live on lanes), lowest index wins ties
+    // reduce over the 32 lanes of each half (codes live on lanes); lowest code wins ties
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         float d = best_d[i];
@@ -232,15 +257,26 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const float* __re
         best_d[i] = d;
         best_i[i] = k;
     }
-    if (r == 0) {
+    // every lane now holds the result of its half's 16 rows; lane r == i publishes row i
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < 16; ++i) {
+        if (r == i) {
             const long orow = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
             if (orow < N) {
-                idx_out[orow] = best_i[i];
-                if (WRITE_DMIN) dmin_out[orow] = best_d[i];
+                const unsigned long long key =
+                    ((unsigned long long)__float_as_uint(best_d[i]) << 32) | (unsigned int)best_i[i];
+                atomicMin(keys + orow, key);
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void vq_unpack_keys(const unsigned long long* __restrict__ keys, long N,
+                                                      long long* __restrict__ idx, float* __restrict__ dmin) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) {
+        const unsigned long long k = keys[i];
+        idx[i] = (long long)(k & 0xffffffffull);
+        if (dmin) dmin[i] = __uint_as_float((unsigned int)(k >> 32));
     }
 }
 
@@ -248,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const float* __re
 // gather + straight-through + commitment partial sums + code histogram (HBM-bound)
 // ------------------------------------------------------------------------------------
 constexpr int GATHER_BLOCKS_MAX = 2048;
+constexpr int GATHER_ROWS_PER_BLOCK = 4;
 
 __global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                         const long long* __restrict__ idx, long N, int C,
@@ -410,46 +447,79 @@ __global__ __launch_bounds__(256) void km_finalize_kernel(const float* __restric
 // ------------------------------------------------------------------------------------
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+size_t prepared_bytes(int C, int K) {
+    const int Kp = round_up(K, 32);
+    return (((size_t)C * Kp + Kp) * sizeof(float) + 255) & ~(size_t)255;
+}
+
 VqPlan vq_plan(int64_t N, int C, int K) {
     VqPlan p;
-    p.Cp = round_up(C, BK);
-    p.Kp = round_up(K, CHUNK);
+    p.Cp = C;
+    p.Kp = round_up(K, 32);
     size_t off = 0;
-    p.off_ET = off;
-    off += (size_t)p.Cp * p.Kp * sizeof(float);
-    p.off_enorm = off;
-    off += (size_t)p.Kp * sizeof(float);
+    p.off_prepared = off;
+    off += prepared_bytes(C, K);
+    p.off_keys = off;
+    off += ((size_t)N * sizeof(unsigned long long) + 255) & ~(size_t)255;
     p.off_hist = off;
-    off += (size_t)p.Kp * sizeof(int);
+    off += ((size_t)p.Kp * sizeof(int) + 255) & ~(size_t)255;
     p.off_partial = off;
     off += (size_t)GATHER_BLOCKS_MAX * sizeof(float);
     p.bytes = (off + 255) & ~(size_t)255;
-    long blocks = (N + 3) / 4;
+    long blocks = (N + GATHER_ROWS_PER_BLOCK - 1) / GATHER_ROWS_PER_BLOCK;
     p.gather_blocks = (int)(blocks < GATHER_BLOCKS_MAX ? (blocks > 0 ? blocks : 1) : GATHER_BLOCKS_MAX);
+    // tiles per wave: the largest T in {8,4,2,1} dividing Kp/32 that still yields >= 2 workgroups per CU;
+    // if none does, the smallest (most workgroups).
+    const long row_blocks = (N + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    const int tiles = p.Kp / 32;
+    p.T = 1;
+    for (int t = 8; t >= 1; t >>= 1) {
+        if (tiles % t) continue;
+        if (row_blocks * (tiles / t) >= 512 || t == 1) {
+            p.T = t;
+            break;
+        }
+    }
     return p;
 }
 
-hipError_t launch_prep(const float* W, int K, int C, const VqPlan& p, char* ws, hipStream_t st) {
-    float* ET = reinterpret_cast<float*>(ws + p.off_ET);
-    float* en = reinterpret_cast<float*>(ws + p.off_enorm);
-    dim3 g(p.Kp / 32, p.Cp / 32 + (p.Cp % 32 ? 1 : 0));
-    hipLaunchKernelGGL(vq_transpose_codebook, g, dim3(256), 0, st, W, K, C, ET, p.Kp, p.Cp);
-    hipLaunchKernelGGL(vq_code_norms, dim3((p.Kp + 255) / 256), dim3(256), 0, st, ET, K, C, p.Kp, en);
+hipError_t launch_prepare(const float* W, int K, int C, void* prepared, hipStream_t st) {
+    const int Kp = round_up(K, 32);
+    float* E4 = reinterpret_cast<float*>(prepared);
+    float* en = E4 + (size_t)C * Kp;
+    long total = (long)(C / 4) * Kp;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(vq_pack_codebook, dim3((unsigned)blocks), dim3(256), 0, st, W, K, C, E4, Kp, C);
+    hipLaunchKernelGGL(vq_code_norms, dim3((Kp + 63) / 64), dim3(64), 0, st, W, K, C, Kp, en);
     return hipGetLastError();
 }
 
-hipError_t launch_assign(const float* x, int64_t N, int C, const VqPlan& p, char* ws, int64_t* idx, float* dmin,
-                         hipStream_t st) {
-    const float* ET = reinterpret_cast<const float*>(ws + p.off_ET);
-    const float* en = reinterpret_cast<const float*>(ws + p.off_enorm);
-    const size_t lds = (size_t)(2 * BK * CHUNK + WAVES * 32) * sizeof(float);
-    const dim3 grid((unsigned)((N + ROWS_PER_WG - 1) / ROWS_PER_WG));
-    if (dmin)
-        hipLaunchKernelGGL(vq_assign_f32_kernel<true>, grid, dim3(256), lds, st, x, ET, en, (long)N, C, p.Cp, p.Kp,
-                           reinterpret_cast<long long*>(idx), dmin);
-    else
-        hipLaunchKernelGGL(vq_assign_f32_kernel<false>, grid, dim3(256), lds, st, x, ET, en, (long)N, C, p.Cp, p.Kp,
-                           reinterpret_cast<long long*>(idx), dmin);
+template <int T>
+static void launch_assign_t(const float* x, const float* E4, const float* en, int64_t N, int C, int Kp,
+                            unsigned long long* keys, hipStream_t st) {
+    const size_t lds = (size_t)(2 * STAGE_FLOATS + WAVES * 32) * sizeof(float);
+    const dim3 grid((unsigned)((N + ROWS_PER_WG - 1) / ROWS_PER_WG), (unsigned)(Kp / (32 * T)));
+    hipLaunchKernelGGL(vq_assign_f32_kernel<T>, grid, dim3(256), lds, st, x, E4, en, (long)N, C, C, Kp, keys);
+}
+
+hipError_t launch_assign(const float* x, int64_t N, int C, int K, const void* prepared, const VqPlan& p, char* ws,
+                         int64_t* idx, float* dmin, hipStream_t st) {
+    const float* E4 = reinterpret_cast<const float*>(prepared);
+    const float* en = E4 + (size_t)C * p.Kp;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws + p.off_keys);
+    hipError_t e = hipMemsetAsync(keys, 0xff, (size_t)N * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return e;
+    switch (p.T) {
+        case 8: launch_assign_t<8>(x, E4, en, N, C, p.Kp, keys, st); break;
+        case 4: launch_assign_t<4>(x, E4, en, N, C, p.Kp, keys, st); break;
+        case 2: launch_assign_t<2>(x, E4, en, N, C, p.Kp, keys, st); break;
+        default: launch_assign_t<1>(x, E4, en, N, C, p.Kp, keys, st); break;
+    }
+    long blocks = (N + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(vq_unpack_keys, dim3((unsigned)blocks), dim3(256), 0, st, keys, (long)N,
+                       reinterpret_cast<long long*>(idx), dmin);
     return hipGetLastError();
 }
 
@@ -499,10 +569,10 @@ KmPlan km_plan(int64_t N, int C, int K) {
 
 hipError_t launch_km_accumulate(const float* samples, const float* means, int64_t N, int C, int K, const KmPlan& p,
                                 char* ws, float* sums, int64_t* counts64, hipStream_t st) {
-    hipError_t e = launch_prep(means, K, C, p.vq, ws, st);
+    hipError_t e = launch_prepare(means, K, C, ws + p.vq.off_prepared, st);
     if (e != hipSuccess) return e;
     int64_t* idx = reinterpret_cast<int64_t*>(ws + p.off_idx);
-    e = launch_assign(samples, N, C, p.vq, ws, idx, nullptr, st);
+    e = launch_assign(samples, N, C, K, ws + p.vq.off_prepared, p.vq, ws, idx, nullptr, st);
     if (e != hipSuccess) return e;
     int* counts = reinterpret_cast<int*>(ws + p.off_counts);
     int* offsets = reinterpret_cast<int*>(ws + p.off_offsets);

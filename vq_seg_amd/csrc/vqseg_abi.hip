@@ -52,27 +52,48 @@ size_t vqseg_vq_workspace_bytes(int64_t n, int c, int k) {
     return vqseg::vq_plan(n, c, k).bytes;
 }
 
-int vqseg_vq_assign_f32(const float* x, const float* codebook, int64_t n, int c, int k, int64_t* idx, float* dmin,
-                        void* ws, size_t ws_bytes, void* stream) {
+size_t vqseg_vq_prepared_bytes(int c, int k) {
+    if (c <= 0 || k <= 0) return 0;
+    return vqseg::prepared_bytes(c, k);
+}
+
+int vqseg_vq_prepare_f32(const float* codebook, int c, int k, void* prepared, size_t prepared_bytes, void* stream) {
+    if (int rc = check_shape(1, c, k)) return rc;
+    if (!codebook || !prepared) return fail(VQSEG_EINVAL, "null pointer argument");
+    if (!aligned16(codebook) || !aligned16(prepared)) return fail(VQSEG_EINVAL, "codebook and prepared must be 16-byte aligned");
+    if (prepared_bytes < vqseg::prepared_bytes(c, k))
+        return fail(VQSEG_ENOSPC, "prepared buffer %zu < %zu bytes", prepared_bytes, vqseg::prepared_bytes(c, k));
+    hipError_t e = vqseg::launch_prepare(codebook, k, c, prepared, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "vq codebook prepare");
+    return 0;
+}
+
+int vqseg_vq_assign_f32(const float* x, const float* codebook, const void* prepared, int64_t n, int c, int k,
+                        int64_t* idx, float* dmin, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_shape(n, c, k)) return rc;
-    if (!x || !codebook || !idx || !ws) return fail(VQSEG_EINVAL, "null pointer argument");
-    if (!aligned16(x) || !aligned16(ws)) return fail(VQSEG_EINVAL, "x and workspace must be 16-byte aligned");
+    if (!x || !idx || !ws || (!codebook && !prepared)) return fail(VQSEG_EINVAL, "null pointer argument");
+    if (!aligned16(x) || !aligned16(ws) || !aligned16(prepared) || !aligned16(codebook))
+        return fail(VQSEG_EINVAL, "x, codebook, prepared and workspace must be 16-byte aligned");
     const vqseg::VqPlan p = vqseg::vq_plan(n, c, k);
     if (ws_bytes < p.bytes) return fail(VQSEG_ENOSPC, "workspace %zu < %zu bytes", ws_bytes, p.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipError_t e = vqseg::launch_prep(codebook, k, c, p, static_cast<char*>(ws), st);
-    if (e != hipSuccess) return hip_fail(e, "vq codebook prep");
-    e = vqseg::launch_assign(x, n, c, p, static_cast<char*>(ws), idx, dmin, st);
+    char* w = static_cast<char*>(ws);
+    if (!prepared) {
+        hipError_t e = vqseg::launch_prepare(codebook, k, c, w + p.off_prepared, st);
+        if (e != hipSuccess) return hip_fail(e, "vq codebook prepare");
+        prepared = w + p.off_prepared;
+    }
+    hipError_t e = vqseg::launch_assign(x, n, c, k, prepared, p, w, idx, dmin, st);
     if (e != hipSuccess) return hip_fail(e, "vq_assign_f32_kernel");
     return 0;
 }
 
-int vqseg_vq_forward_f32(const float* x, const float* codebook, int64_t n, int c, int k, int training, float cw,
-                         float* quant, int64_t* idx, float* loss, float* dead_pct, float* dmin, void* ws,
-                         size_t ws_bytes, void* stream) {
-    if (!quant || !loss || !dead_pct) return fail(VQSEG_EINVAL, "null output pointer");
-    if (!aligned16(quant) || !aligned16(codebook)) return fail(VQSEG_EINVAL, "quant and codebook must be 16-byte aligned");
-    if (int rc = vqseg_vq_assign_f32(x, codebook, n, c, k, idx, dmin, ws, ws_bytes, stream)) return rc;
+int vqseg_vq_forward_f32(const float* x, const float* codebook, const void* prepared, int64_t n, int c, int k,
+                         int training, float cw, float* quant, int64_t* idx, float* loss, float* dead_pct, float* dmin,
+                         void* ws, size_t ws_bytes, void* stream) {
+    if (!quant || !loss || !dead_pct || !codebook) return fail(VQSEG_EINVAL, "null pointer argument");
+    if (!aligned16(quant)) return fail(VQSEG_EINVAL, "quant must be 16-byte aligned");
+    if (int rc = vqseg_vq_assign_f32(x, codebook, prepared, n, c, k, idx, dmin, ws, ws_bytes, stream)) return rc;
     const vqseg::VqPlan p = vqseg::vq_plan(n, c, k);
     hipError_t e = vqseg::launch_gather(x, codebook, idx, n, c, k, training, cw, p, static_cast<char*>(ws), quant, loss,
                                         dead_pct, static_cast<hipStream_t>(stream));

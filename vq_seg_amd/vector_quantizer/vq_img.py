@@ -21,8 +21,8 @@ class _VQFunction(torch.autograd.Function):
     """rows (N, C) -> quant (N, C), idx (N,), loss (1,), dead_pct ()."""
 
     @staticmethod
-    def forward(ctx, rows, codebook, training, commitment_weight):
-        quant, idx, loss, dead = _hip.vq_forward(rows, codebook, training, commitment_weight)
+    def forward(ctx, rows, codebook, training, commitment_weight, prepared=None):
+        quant, idx, loss, dead = _hip.vq_forward(rows, codebook, training, commitment_weight, prepared=prepared)
         ctx.commitment_weight = float(commitment_weight)
         ctx.training = bool(training)
         if training:
@@ -33,14 +33,14 @@ class _VQFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_quant, _g_idx, g_loss, _g_dead):
         if not ctx.training:
-            return g_quant, None, None, None                # eval: quant is a pure gather (constant in x)
+            return None, None, None, None, None             # eval: quant is a pure gather (constant in x)
         rows, quant = ctx.saved_tensors
         if g_quant is None:
             g_quant = torch.zeros_like(rows)
         g_quant = g_quant.contiguous()
         gl = g_loss.contiguous() if (g_loss is not None and ctx.commitment_weight > 0) else None
         gx = _hip.vq_backward(g_quant, gl, rows, quant, ctx.commitment_weight)
-        return gx, None, None, None                         # the codebook receives no gradient (vq_img.py:236-239)
+        return gx, None, None, None, None                   # the codebook receives no gradient (vq_img.py:236-239)
 
 
 def _rows_of(x: torch.Tensor):
@@ -94,6 +94,16 @@ class EuclideanCodebook(nn.Module):
             self.embedding.weight.data.uniform_(-1 / num_embeddings, 1 / num_embeddings)   # vq_img.py:156-158
             self.initted = True
 
+    def prepared(self) -> torch.Tensor:
+        """Kernel-side image of the codebook (include/vqseg.h: vqseg_vq_prepare_f32), rebuilt only
+        when the weight tensor changes (version counter / storage / device)."""
+        w = self.embedding.weight
+        key = (w._version, w.data_ptr(), str(w.device))
+        if getattr(self, "_prep_key", None) != key:
+            self._prep_blob = _hip.vq_prepare(w.detach())
+            self._prep_key = key
+        return self._prep_blob
+
     @torch.no_grad()
     def _kmeans_init(self, rows: torch.Tensor):
         if self.initted:
@@ -108,7 +118,8 @@ class EuclideanCodebook(nn.Module):
         rows = x.float().reshape(b * hw, c).contiguous()
         if self.kmeans_init and self.training:
             self._kmeans_init(rows.detach())
-        quant, idx, _loss, dead = _VQFunction.apply(rows.detach(), self.embedding.weight.detach(), False, 0.0)
+        quant, idx, _loss, dead = _VQFunction.apply(rows.detach(), self.embedding.weight.detach(), False, 0.0,
+                                                    self.prepared())
         return quant.reshape(b, hw, c), idx.reshape(b, hw), dead
 
 
@@ -136,6 +147,6 @@ class VectorQuantizer(nn.Module):
         if cb.kmeans_init and self.training:
             cb._kmeans_init(rows.detach())                                   # vq_img.py:165-166
         quant, idx, loss, dead = _VQFunction.apply(rows, cb.embedding.weight.detach(), self.training,
-                                                   float(self.commitment_weight))
+                                                   float(self.commitment_weight), cb.prepared())
         quantize = quant.reshape(b, h, w, c).permute(0, 3, 1, 2)             # vq_img.py:242 (channels_last view)
         return quantize, idx.reshape(b, h, w), loss, dead
