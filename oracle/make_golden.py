@@ -259,6 +259,46 @@ def model_inputs(b=2, s=64, seed=6000):
     return x, gt, scores
 
 
+def set_bn_momentum(model, m):
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.momentum = m
+
+
+def prepare_model(model, x, gt, version):
+    """Shared preparation recipe (also executed by the tests on their own side):
+    1. encoder BN running stats := batch stats of x (train-mode encoder pass, momentum 1)
+    2. codebooks := function of the eval-mode encoder features (install_codebooks)
+    3. all BN running stats := batch stats of a full train-mode forward (momentum 1)
+    so that activations stay O(1) and eval / train features are close to each other."""
+    set_bn_momentum(model, 1.0)
+    model.train()
+    with torch.no_grad():
+        model.encoder(x)
+    model.eval()
+    install_codebooks(model, x)
+    model.train()
+    with torch.no_grad():
+        if version == 1:
+            model(x, gt, percent=80.0)
+        elif version == 2:
+            model(x, gt, th=0.7)
+        else:
+            model(x)
+    set_bn_momentum(model, 0.1)
+
+
+def install_codebooks(model, x):
+    """Codebooks derived from the model's own eval-mode encoder features (tests/cases.py recipe)."""
+    from tests import cases
+    with torch.no_grad():
+        feats = model.encoder(x)[1:]
+        for i in (2, 3, 4):
+            cb = model.codebook[i].codebook
+            cb.embedding.weight.copy_(cases.codebook_from_rows(cases.rows_of(feats[i]), cb.num_embeddings, 900 + i))
+            cb.initted = True
+
+
 PROBE_KEYS = ["segmentation_head.weight", "encoder.conv1.weight", "decoder.blocks.4.1.0.weight",
               "decoder.blocks.0.0.0.weight", "encoder.layer4.2.conv3.weight", "encoder.layer2.0.downsample.0.weight",
               "encoder.layer1.0.bn1.weight", "decoder.blocks.2.0.1.bias"]
@@ -272,11 +312,10 @@ def gen_models(ref):
         shapes = synth.shapes_of(model.state_dict())
         sd = synth.synth_state_dict(shapes, MODEL_SEED)
         model.load_state_dict(sd)
-        for i in (2, 3, 4):
-            model.codebook[i].codebook.initted = True        # codebooks come from the fixture recipe
         model.prototype_loss.initted = True
-        out = {}
+        prepare_model(model, x, gt, version)
         model.eval()
+        out = {}
         with torch.no_grad():
             o = model(x)
         out.update(eval_logits=o[0], eval_loss=o[1], eval_usage=o[2])
@@ -295,7 +334,7 @@ def gen_models(ref):
             total = (logits * synth.uniform(6100, tuple(logits.shape), -1.0, 1.0)).sum() + 2.0 * closs.sum()
             with torch.no_grad():
                 model2 = ref.networks.make_model(model_cfg(ref, name, margin=margin, scale=scale))
-                model2.load_state_dict(sd)
+                model2.load_state_dict(model.state_dict())
                 for i in (2, 3, 4):
                     model2.codebook[i].codebook.initted = True
                 model2.prototype_loss.initted = True
@@ -330,6 +369,11 @@ def gen_unet(ref):
     sd = synth.synth_state_dict(shapes, MODEL_SEED + 1)
     model.load_state_dict(sd)
     x, gt, _ = model_inputs(b=2, s=64, seed=6500)
+    set_bn_momentum(model, 1.0)
+    model.train()
+    with torch.no_grad():
+        model(x)
+    set_bn_momentum(model, 0.1)
     model.eval()
     with torch.no_grad():
         y_eval = model(x)

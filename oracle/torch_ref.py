@@ -53,7 +53,7 @@ def vq_forward(x: Tensor, codebook: Tensor, training: bool, commitment_weight: f
     b, c, h, w = x.shape
     rows = x.permute(0, 2, 3, 1).reshape(b, h * w, c)              # :232
     quant, idx, dead_pct = vq_lookup(rows, codebook)               # :233
-    loss = torch.tensor([0.0], requires_grad=training)            # :234
+    loss = torch.tensor([0.0], requires_grad=training, device=x.device)   # :234
     if training:
         quant = rows + (quant - rows).detach()                    # :236 straight-through
         if commitment_weight > 0:
@@ -106,7 +106,7 @@ def _bn(x: Tensor, p: Dict[str, Tensor], prefix: str, training: bool, eps: float
 
 
 def conv3x3_bn_relu(x: Tensor, p: Dict[str, Tensor], prefix: str, training: bool,
-                    eps: float = 1e-5, momentum: float = 0.1) -> Tensor:
+                    eps: float = 1e-5, momentum: float = 0.1) -> Tensor:  # `training` = the BN module's mode
     """conv_bn_relu, decoder.py:7-10: Conv3x3(pad 1, zeros, no bias) -> BatchNorm2d -> ReLU.
     Keys: `<prefix>.0.weight` (conv), `<prefix>.1.*` (bn).  Running stats in `p` are
     updated in place in training mode exactly like nn.BatchNorm2d does.
@@ -116,7 +116,7 @@ def conv3x3_bn_relu(x: Tensor, p: Dict[str, Tensor], prefix: str, training: bool
 
 
 def unet_decoder(p: Dict[str, Tensor], features: Sequence[Tensor], training: bool, prefix: str = "decoder",
-                 eps: float = 1e-5, momentum: float = 0.1) -> Tensor:
+                 eps: float = 1e-5, momentum: float = 0.1) -> Tensor:  # `training` = mode of the BatchNorm modules
     """UnetDecoder.forward, decoder.py:30-39.  `features` shallow -> deep (5 maps)."""
     feats = list(features)[::-1]                                   # :31
     n_blocks = len(feats)
@@ -200,7 +200,7 @@ def prototype_loss_v1(feat: Tensor, gt: Tensor, prototypes: Tensor, percent: flo
     n_cls = prototypes.shape[0]
     rows = feat.permute(0, 2, 3, 1).reshape(-1, c)
     labels = gt.permute(0, 2, 3, 1).reshape(-1, 1)
-    onehot = torch.zeros(rows.shape[0], n_cls, dtype=torch.float64).scatter_(1, labels, 1.0) + 1e-6   # seg_tools.py:23-34
+    onehot = torch.zeros(rows.shape[0], n_cls, dtype=torch.float64, device=rows.device).scatter_(1, labels, 1.0) + 1e-6   # seg_tools.py:23-34
     proto = F.normalize(prototypes.detach(), p=2, dim=-1)                          # :556
     rows = F.normalize(rows, p=2, dim=-1)                                           # :557
     cosine = F.linear(rows, proto)                                                  # :562
@@ -209,7 +209,7 @@ def prototype_loss_v1(feat: Tensor, gt: Tensor, prototypes: Tensor, percent: flo
         cosine = (onehot * phi) + ((1.0 - onehot) * cosine)                         # :573
     if scale != 1:
         cosine = scale * cosine                                                     # :577
-    thresh = np.percentile(entropy.detach().cpu().numpy().flatten(), percent)       # :582
+    thresh = float(np.percentile(entropy.detach().cpu().numpy().flatten(), percent))   # :582
     keep = torch.le(entropy, thresh)                                                # :585
     positive = torch.exp(torch.sum(cosine * onehot, dim=-1))                        # :591
     total = torch.sum(torch.exp(cosine), dim=-1)                                    # :592
@@ -308,7 +308,7 @@ def vq_unet_forward(p: Dict[str, Tensor], x: Tensor, training: bool, num_embeddi
                     gt: Optional[Tensor] = None, version: int = 1, percent: Optional[float] = None,
                     th: Optional[float] = None, margin: float = 0.0, scale: float = 1.0,
                     commitment_weight: float = 1.0, eps: float = 1e-5, momentum: float = 0.1,
-                    features: Optional[Sequence[Tensor]] = None):
+                    features: Optional[Sequence[Tensor]] = None, bn_training: Optional[bool] = None):
     """VQRePTUnet1x1.forward (net.py:1174-1209) / VQRePTUnet1x1v2.forward (:217-247).
 
     Codebooks and prototypes are taken as already initialised (k-means init is RNG
@@ -316,8 +316,9 @@ def vq_unet_forward(p: Dict[str, Tensor], x: Tensor, training: bool, num_embeddi
     everything downstream of it).  Returns (logits, commitment (1,), dead_pct (n_vq,),
     prototype_loss | None, aux dict with per-level indices and decoder output).
     """
-    feats = list(features) if features is not None else resnet_encoder(p, x, training, eps=eps, momentum=momentum)[1:]
-    loss = torch.zeros(1)
+    bn_tr = training if bn_training is None else bn_training      # BatchNorm modules may be frozen (.eval()) in a training model
+    feats = list(features) if features is not None else resnet_encoder(p, x, bn_tr, eps=eps, momentum=momentum)[1:]
+    loss = torch.zeros(1, device=x.device)
     usage, indices = [], []
     for i, k in enumerate(num_embeddings):
         if k == 0:
@@ -328,7 +329,7 @@ def vq_unet_forward(p: Dict[str, Tensor], x: Tensor, training: bool, num_embeddi
         usage.append(dead.detach())
         indices.append(idx)
     loss = loss / len(feats)                                             # :1195 (divides by 5, q2)
-    dec = unet_decoder(p, feats, training, eps=eps, momentum=momentum)
+    dec = unet_decoder(p, feats, bn_tr, eps=eps, momentum=momentum)
     logits = F.conv2d(dec, p["segmentation_head.weight"])               # 1x1, no bias
     proto = None
     if training:

@@ -82,3 +82,50 @@ def model_inputs(b=2, s=64, seed=6000):
 
 def logits_cotangent(shape):
     return synth.uniform(6100, tuple(shape), -1.0, 1.0)
+
+
+def codebook_from_rows(rows: torch.Tensor, k: int, seed: int) -> torch.Tensor:
+    """Codebook with WELL SEPARATED winners for model-level fixtures: the first N codes are copies of
+    the N feature rows (in a scrambled order), later codes are increasingly perturbed copies.  Built from
+    whatever features the caller's own encoder produced, so tiny cross-device rounding differences in
+    the features move the codes along with them instead of flipping near-tied argmins."""
+    n, c = rows.shape
+    ar = torch.arange(k)
+    pick = (ar * 7) % n
+    mult = (ar // n).float()[:, None]
+    u = synth.uniform(seed, (k, c), -1.0, 1.0)
+    rms = rows.detach().float().pow(2).mean().sqrt()            # perturbation relative to the feature scale
+    return (rows.detach()[pick.to(rows.device)] + (0.5 * mult * u).to(rows.device) * rms).contiguous()
+
+
+def rows_of(feat: torch.Tensor) -> torch.Tensor:
+    return feat.permute(0, 2, 3, 1).reshape(-1, feat.shape[1])
+
+
+def set_bn_momentum(model, m):
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.momentum = m
+
+
+def prepare_module_model(model, x, gt, version, to_input=lambda t: t):
+    """The preparation recipe of oracle/make_golden.py::prepare_model for an nn.Module model:
+    calibrate encoder BN (momentum 1) -> codebooks from eval features -> calibrate all BN."""
+    set_bn_momentum(model, 1.0)
+    model.train()
+    with torch.no_grad():
+        model.encoder(to_input(x))
+    model.eval()
+    with torch.no_grad():
+        feats = model.encoder(to_input(x))[1:]
+        for i in (2, 3, 4):
+            cb = model.codebook[i].codebook
+            cb.embedding.weight.copy_(codebook_from_rows(rows_of(feats[i]), cb.num_embeddings, 900 + i))
+            cb.initted = True
+    model.train()
+    with torch.no_grad():
+        if version == 1:
+            model(x, gt, percent=80.0)
+        else:
+            model(x, gt, th=0.7)
+    set_bn_momentum(model, 0.1)

@@ -44,7 +44,8 @@ def synth_state_dict(shapes: Mapping[str, Tuple[int, ...]], seed: int) -> "Order
     """Fill a state_dict layout (name -> shape) with deterministic, sanely scaled values.
 
     conv / linear weights: U(-b, b), b = sqrt(6 / fan_in)  (variance 2/fan_in, He-like)
-    BN weight U(0.5, 1.5), bias U(-0.1, 0.1), running_mean U(-0.1, 0.1), running_var U(0.5, 1.5)
+    BN weight U(0.5, 1.5) (the last BN of a bottleneck, `bn3`: U(0.05, 0.25), so that perturbations are
+    not amplified ~4x per encoder stage), bias U(-0.1, 0.1), running_mean U(-0.1, 0.1), running_var U(0.5, 1.5)
     codebooks (`...codebook.embedding.weight`): U(0, 0.5)  (features are non-negative)
     prototypes (`prototype_loss.embedding.weight`): U(-1, 1)
     """
@@ -62,7 +63,9 @@ def synth_state_dict(shapes: Mapping[str, Tuple[int, ...]], seed: int) -> "Order
             out[name] = uniform(s, shape, 0.0, 0.5)
         elif name.startswith("prototype_loss."):
             out[name] = uniform(s, shape, -1.0, 1.0)
-        elif len(shape) == 1 and name.endswith(".weight"):
+        elif name.endswith(".bn3.weight"):
+            out[name] = uniform(s, shape, 0.05, 0.25)            # damped residual branches (zero_init_residual-like):
+        elif len(shape) == 1 and name.endswith(".weight"):       # keeps a random-weight ResNet out of the chaotic regime
             out[name] = uniform(s, shape, 0.5, 1.5)
         elif len(shape) == 1:
             out[name] = uniform(s, shape, -0.1, 0.1)

@@ -1,0 +1,209 @@
+"""GPU parity of the model surface (encoder -> VQ -> decoder -> head -> losses) against the golden
+vectors captured from the reference, fp32 mode.  Tolerance for logits: 1e-3 relative (north_star)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import cases, golden_io, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def close(a, b, rtol, atol=0.0, what=""):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), f"{what}: max abs err {err:.3e} (ref max {b.abs().max().item():.3e})"
+
+
+def rel_close(a, b, tol, what=""):
+    """max |a-b| <= tol * max |b|  (the 'relative to the tensor scale' reading of the 1e-3 logit bar)"""
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} > {tol:g} * {scale:.3e}"
+
+
+def build(name, margin, scale, seed):
+    from vq_seg_amd.models.networks import make_model
+    cfg = {"name": name, "params": {"encoder_name": "resnet50", "num_classes": 3, "depth": 5,
+                                    "vq_cfg": {"num_embeddings": [0, 0, 512, 512, 512], "distance": "euclidean",
+                                               "kmeans_init": True},
+                                    "margin": margin, "scale": scale, "use_feature": False, "encoder_weights": None}}
+    model = make_model(cfg)
+    sd = synth.synth_state_dict(golden_io.layout("vqreptunet1x1"), seed)
+    model.load_state_dict(sd)
+    model.prototype_loss.initted = True
+    model = model.to(dev())
+    x, gt, _ = cases.model_inputs()
+    version = 1 if name == "vqreptunet1x1" else 2
+    cases.prepare_module_model(model, x.to(dev()), gt.to(dev()), version,
+                               to_input=lambda t: t.contiguous(memory_format=torch.channels_last))
+    return model
+
+
+@pytest.mark.parametrize("version", [1, 2])
+def test_whole_model_matches_reference_golden(version):
+    fx = golden_io.load(f"model_v{version}")
+    model = build(fx.meta["name"], fx.meta["margin"], fx.meta["scale"], fx.meta["model_seed"])
+    x, gt, scores = cases.model_inputs()
+    x, gt, scores = x.to(dev()), gt.to(dev()), scores.to(dev())
+    model.eval()
+    with torch.no_grad():
+        logits, closs, usage, proto = model(x)
+        feats = model.encoder(x.contiguous(memory_format=torch.channels_last))[1:]
+        for lvl in (2, 3, 4):
+            idx = model.codebook[lvl](feats[lvl])[1]
+            assert torch.equal(idx.cpu(), fx[f"eval_idx{lvl}"]), f"level {lvl} code indices differ"
+    rel_close(logits, fx["eval_logits"], 1e-3, "eval logits")
+    assert usage.device.type == "cpu" and usage.shape == (3,)
+    close(usage, fx["eval_usage"], rtol=1e-6, what="usage")
+    assert proto is None and closs.shape == (1,) and closs.item() == 0.0
+
+    model.train()
+    kw = dict(percent=fx.meta["percent"]) if version == 1 else dict(th=fx.meta["th"])
+    logits, closs, usage, proto = model(x, gt, **kw)
+    rel_close(logits, fx["train_logits"], 1e-3, "train logits")
+    close(closs, fx["train_loss"], rtol=1e-4, what="commitment")
+    close(usage, fx["train_usage"], rtol=1e-6, what="usage")
+    close(proto, fx["train_proto"], rtol=1e-4, what="prototype loss")
+    total = (logits * cases.logits_cotangent(logits.shape).to(dev())).sum() + fx.meta["loss_scale"] * closs.sum()
+    if version == 1:
+        total = total + fx.meta["proto_scale"] * proto
+    total.backward()
+    named = dict(model.named_parameters())
+    # Tolerance: a 1e-6 perturbation of the INPUT moves these gradients by up to 5e-3 of their scale on the CPU
+    # oracle itself (53 convs + train-mode BN; tools/conditioning.py), so cross-device agreement is asserted at 2e-2.
+    for key in [k[5:] for k in fx if k.startswith("grad/")]:
+        rel_close(golden_io.probe(named[key].grad), fx["grad/" + key], 2e-2, "grad " + key)
+    for i in (2, 3, 4):
+        assert named[f"codebook.{i}.codebook.embedding.weight"].grad is None
+    post = model.state_dict()
+    for key in [k[5:] for k in fx if k.startswith("post/")]:
+        close(post[key], fx["post/" + key], rtol=1e-4, atol=1e-6, what=key)
+    if version == 2:
+        model2 = build(fx.meta["name"], fx.meta["margin"], fx.meta["scale"], fx.meta["model_seed"])
+        model2.load_state_dict(post)
+        model2.train()
+        with torch.no_grad():
+            out = model2(x, scores, th=fx.meta["th"])
+        close(out[3], fx["train_proto_score"], rtol=1e-4, what="prototype loss (pseudo scores)")
+        # the reference's in-place margin makes its fp32 backward raise (q10); ours is differentiable
+        model2.zero_grad()
+        out = model2(x, gt, th=fx.meta["th"])
+        out[3].backward()
+        assert torch.isfinite(model2.prototype_loss.embedding.weight.grad).all()
+
+
+def test_plain_unet_matches_reference_golden():
+    from vq_seg_amd.loss import make_loss
+    from vq_seg_amd.models.networks import make_model
+    fx = golden_io.load("model_unet")
+    model = make_model({"name": "unet", "params": {"encoder_name": "resnet50", "num_classes": 3, "depth": 5,
+                                                     "encoder_weights": "imagenet_swsl"}})
+    model.load_state_dict(synth.synth_state_dict(golden_io.layout("unet"), fx.meta["model_seed"]))
+    model = model.to(dev())
+    x, gt, _ = cases.model_inputs(b=2, s=64, seed=6500)
+    x, gt = x.to(dev()), gt.to(dev())
+    cases.set_bn_momentum(model, 1.0)                             # BN calibration, as in make_golden.gen_unet
+    model.train()
+    with torch.no_grad():
+        model(x)
+    cases.set_bn_momentum(model, 0.1)
+    model.eval()
+    with torch.no_grad():
+        y = model(x)
+    assert isinstance(y, torch.Tensor)                               # bare tensor (unet/net.py:833-838)
+    rel_close(y, fx["eval_logits"], 1e-3, "unet eval logits")
+    model.train()
+    y = model(x)
+    rel_close(y, fx["train_logits"], 1e-3, "unet train logits")
+    loss = make_loss("dice_loss", 3, ignore_index=255)(y, gt) + 0.5 * F.cross_entropy(y, gt, ignore_index=255)
+    close(loss, fx["loss"], rtol=1e-4, what="loss")
+    loss.backward()
+    named = dict(model.named_parameters())
+    for key in [k[5:] for k in fx if k.startswith("grad/")]:
+        rel_close(golden_io.probe(named[key].grad), fx["grad/" + key], 2e-2, "grad " + key)
+
+
+@pytest.mark.parametrize("name", cases.DEC_CASES)
+def test_decoder_matches_reference_golden(name):
+    from vq_seg_amd.models.networks.unet.decoder import UnetDecoder
+    fx = golden_io.load(name)
+    feats, sd, g = cases.decoder_inputs(fx.meta)
+    dec = UnetDecoder(list(fx.meta["enc"]), list(fx.meta["dec"]))
+    dec.load_state_dict(sd)
+    dec = dec.to(dev())
+    cl = lambda t: t.to(dev()).contiguous(memory_format=torch.channels_last)
+    dec.eval()
+    with torch.no_grad():
+        y = dec(*[cl(f) for f in feats])
+    rel_close(y, fx["y_eval"], 1e-3, "decoder eval")
+    dec.train()
+    fr = [cl(f).requires_grad_(True) for f in feats]
+    y = dec(*fr)
+    rel_close(y, fx["y_train"], 1e-3, "decoder train")
+    (y * g.to(dev())).sum().backward()
+    for i, f in enumerate(fr):
+        rel_close(f.grad, fx[f"grad_feat{i}"], 2e-3, f"grad feat {i}")
+    rel_close(dec.blocks[0][0][0].weight.grad, fx["grad_w_first"], 2e-3, "grad w first")
+    rel_close(dec.blocks[4][1][0].weight.grad, fx["grad_w_last"], 2e-3, "grad w last")
+    rel_close(dec.blocks[4][1][1].weight.grad, fx["grad_bn_w_last"], 2e-3, "grad bn w")
+    rel_close(dec.blocks[4][1][1].bias.grad, fx["grad_bn_b_last"], 2e-3, "grad bn b")
+    post = dec.state_dict()
+    close(post["blocks.0.0.1.running_mean"], fx["run_mean_first"], rtol=1e-4, atol=1e-6)
+    close(post["blocks.0.0.1.running_var"], fx["run_var_first"], rtol=1e-4, atol=1e-6)
+    close(post["blocks.4.1.1.running_var"], fx["run_var_last"], rtol=1e-4, atol=1e-6)
+
+
+def test_prototype_losses_match_reference_golden():
+    from vq_seg_amd.models.modules.prototype import ReliablePrototypeLoss, ReliablePrototypeLossv2
+    fx = golden_io.load("prototype")
+    feat, gt, scores, protos, entropy = [t.to(dev()) for t in cases.proto_inputs()]
+    for tag, margin, scale in (("m0", 0.0, 1.0), ("m05", 0.5, 30.0)):
+        m1 = ReliablePrototypeLoss(3, 32, scale=scale, margin=margin, init="normal").to(dev())
+        with torch.no_grad():
+            m1.embedding.weight.copy_(protos)
+        m1.train()
+        fr = feat.clone().requires_grad_(True)
+        l1 = m1(fr, gt, percent=fx.meta["percent"], entropy=entropy)
+        assert l1.dtype == torch.float64
+        close(l1, fx[f"v1_{tag}_loss"], rtol=1e-5, what="v1 loss")
+        l1.backward()
+        rel_close(fr.grad, fx[f"v1_{tag}_grad"], 1e-3, "v1 grad")
+        assert m1.embedding.weight.grad is None
+        for kind, target in (("gt", gt), ("score", scores)):
+            m2 = ReliablePrototypeLossv2(3, 32, scale=scale, margin=margin, init="normal").to(dev())
+            with torch.no_grad():
+                m2.embedding.weight.copy_(protos)
+            m2.train()
+            l2 = m2(feat, target, fx.meta["th"])
+            close(l2, fx[f"v2_{tag}_{kind}_loss"], rtol=1e-4, what="v2 loss")
+            close(m2.embedding.weight, fx[f"v2_{tag}_{kind}_proto_after"], rtol=1e-5, what="v2 protos")
+
+
+def test_kmeans_prototype_init_and_model_first_train_forward():
+    """First TRAINING forward of a kmeans_init model initialises the 3 codebooks and the prototypes (q5)."""
+    from vq_seg_amd.models.networks import make_model
+    torch.manual_seed(0)
+    model = make_model({"name": "vqreptunet1x1v2", "params": {
+        "encoder_name": "resnet50", "num_classes": 3, "depth": 5,
+        "vq_cfg": {"num_embeddings": [0, 0, 32, 32, 16], "distance": "euclidean", "kmeans_init": True},
+        "margin": 0.5, "scale": 30.0, "use_feature": False, "encoder_weights": None}}).to(dev())
+    x, gt, _ = cases.model_inputs(b=2, s=128)
+    model.eval()
+    with torch.no_grad():
+        model(x.to(dev()))
+    assert not any(model.codebook[i].codebook.initted for i in (2, 3, 4)) and not model.prototype_loss.initted
+    model.train()
+    out = model(x.to(dev()), gt.to(dev()), th=0.7)
+    assert all(model.codebook[i].codebook.initted for i in (2, 3, 4)) and model.prototype_loss.initted
+    (out[0].mean() + out[1].sum() + out[3]).backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    assert (out[2] < 100).all()                                   # k-means codes are in use

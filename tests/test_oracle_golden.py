@@ -145,6 +145,14 @@ def test_whole_model(version):
     assert len(sd) == fx.meta["n_keys"] == 383
     x, gt, scores = cases.model_inputs()
     ks = (0, 0, 512, 512, 512)
+    kw0 = dict(percent=80.0) if version == 1 else dict(th=0.7)
+    with torch.no_grad():                                           # the preparation recipe of make_golden.prepare_model
+        R.resnet_encoder(sd, x, True, momentum=1.0)
+        feats = R.resnet_encoder(sd, x, False)[1:]
+        for i in (2, 3, 4):
+            sd[f"codebook.{i}.codebook.embedding.weight"] = cases.codebook_from_rows(cases.rows_of(feats[i]), 512, 900 + i)
+        R.vq_unet_forward(sd, x, True, ks, gt=gt, version=version, margin=fx.meta["margin"], scale=fx.meta["scale"],
+                          momentum=1.0, **kw0)
     p = {k: v.clone() for k, v in sd.items()}
     with torch.no_grad():
         logits, closs, usage, proto, aux = R.vq_unet_forward(p, x, False, ks, version=version)
@@ -191,6 +199,8 @@ def test_plain_unet():
     fx = golden_io.load("model_unet")
     sd = synth.synth_state_dict(golden_io.layout("unet"), fx.meta["model_seed"])
     x, gt, _ = cases.model_inputs(b=2, s=64, seed=6500)
+    with torch.no_grad():
+        R.unet_forward(sd, x, True, momentum=1.0)                  # BN calibration, as in make_golden.gen_unet
     p = {k: v.clone() for k, v in sd.items()}
     with torch.no_grad():
         y = R.unet_forward(p, x, False)

@@ -1,0 +1,27 @@
+"""SegmentationHead used by the plain Unet (reference: models/modules/segmentation_head.py:78-83):
+Conv2d(k, padding k//2, with bias) -> UpsamplingBilinear2d(scale) (align_corners=True) -> activation."""
+from torch import nn
+
+from ... import nnf
+
+
+class _Up(nn.Module):
+    def __init__(self, scale):
+        super().__init__()
+        self.scale_factor = scale
+
+    def forward(self, x):
+        return nnf.upsample_bilinear(x, scale_factor=self.scale_factor, align_corners=True)
+
+
+class _Conv(nn.Conv2d):
+    def forward(self, x):
+        return nnf.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0])
+
+
+class SegmentationHead(nn.Sequential):
+    def __init__(self, in_channels, out_channels, kernel_size=3, upsampling=1, activation=nn.Identity):
+        conv = _Conv(in_channels, out_channels, kernel_size=kernel_size, padding=kernel_size // 2)
+        up = _Up(upsampling) if upsampling > 1 else nn.Identity()
+        act = activation() if activation in (nn.Softmax2d, nn.Identity) else activation(dim=1)
+        super().__init__(conv, up, act)

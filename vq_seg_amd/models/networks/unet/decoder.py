@@ -1,0 +1,50 @@
+"""UNet decoder (reference: models/networks/unet/decoder.py:7-39).
+
+Five blocks of two fused Conv3x3(pad 1, zeros, no bias)-BatchNorm-ReLU units; between blocks the
+output is resized bilinearly (align_corners=False) to the next skip's size and concatenated
+(upsampled first, skip second).  Parameter holders are real nn.Conv2d / nn.BatchNorm2d so that
+`models.init_weight` and the reference's checkpoint keys (`decoder.blocks.i.j.k.*`) keep working.
+"""
+from torch import nn
+
+from .... import nnf as _nnf
+
+
+class ConvBNReLU(nn.Sequential):
+    """Sequential(Conv2d, BatchNorm2d, ReLU) parameter layout, fused execution."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3):
+        super().__init__(nn.Conv2d(in_channels, out_channels, kernel_size, padding=int((kernel_size - 1) / 2), bias=False),
+                         nn.BatchNorm2d(out_channels), nn.ReLU())
+
+    def forward(self, x):
+        return _nnf.conv_bn_act(x, self[0], self[1], self.training, relu=True)
+
+
+def conv_bn_relu(in_channels: int, out_channels: int, kernel_size: int = 3):
+    return ConvBNReLU(in_channels, out_channels, kernel_size)
+
+
+def double_conv_block(in_channels: int, out_channels: int, kernel_size: int = 3):
+    return nn.Sequential(conv_bn_relu(in_channels, out_channels, kernel_size),
+                         conv_bn_relu(out_channels, out_channels, kernel_size))
+
+
+class UnetDecoder(nn.Module):
+    def __init__(self, encoder_channels, decoder_channels):
+        super().__init__()
+        enc = list(encoder_channels[1:])[::-1]                     # deep -> shallow, e.g. (2048, 1024, 512, 256, 64)
+        blocks, prev = [], 0
+        for i, out_ch in enumerate(decoder_channels):
+            blocks.append(double_conv_block(enc[i] + prev, out_ch))
+            prev = out_ch
+        self.blocks = nn.ModuleList(blocks)
+
+    def forward(self, *features):
+        feats = features[::-1]
+        cat = feats[0]
+        for i in range(len(self.blocks) - 1):
+            out = self.blocks[i](cat)
+            up = _nnf.upsample_bilinear(out, size=feats[i + 1].shape[-2:], align_corners=False)
+            cat = _nnf.concat_channels(up, feats[i + 1])
+        return self.blocks[-1](cat)

@@ -1,0 +1,271 @@
+"""Cross-pseudo-supervision (CPS) training of two VQ-UNets: the caller of the hot path.
+
+Mirrors the loop bodies of the reference's trainers
+  v2: train_vqreptunet1x1v2.py:137-211  (score-mask CPS, CE + Dice, confidence threshold)
+  v1: deprecated/train_with_test_pt_pseudo_entropy_reg.py:141-203 (entropy-percentile pseudo labels,
+      criterion from cfg, `percent` schedule)
+as one `CPSTrainer.step()`; data-parallel across the GPUs of a node with a bucketed gradient
+all-reduce over RCCL that overlaps the backward pass (no reference counterpart: SURVEY 2, 8e).
+wandb / image dumps of the reference trainer are out of scope.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+from . import dist as vdist
+from .loss import make_loss
+from .measurement import confusion_matrix_device, miou_device
+from .models import init_weight
+from .models.networks import make_model
+from .utils.lr_schedulers import CosineAnnealingLR
+
+
+# ----------------------------------------------------------------------------------------------
+# gradient all-reduce: flat fp32 buckets, launched from post-accumulate hooks while backward runs
+# ----------------------------------------------------------------------------------------------
+class GradBuckets:
+    """Owns the .grad storage of `params` as views into a few flat buffers ("buckets", filled in
+    reverse parameter order = the order backward produces them).  With world_size > 1 each bucket is
+    all-reduced (sum, then scaled by 1/world) as soon as all its gradients have been accumulated."""
+
+    def __init__(self, params: List[nn.Parameter], bucket_mb: float = 64.0):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = vdist.world_size()
+        cap = int(bucket_mb * (1 << 20) / 4)
+        self.buckets: List[torch.Tensor] = []
+        self.owner: Dict[int, int] = {}
+        groups, cur, cur_n = [], [], 0
+        for p in reversed(self.params):
+            if cur and cur_n + p.numel() > cap:
+                groups.append(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            groups.append(cur)
+        for bi, g in enumerate(groups):
+            flat = torch.zeros(sum(p.numel() for p in g), dtype=torch.float32, device=g[0].device)
+            off = 0
+            for p in g:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                self.owner[id(p)] = bi
+            self.buckets.append(flat)
+        self._sizes = [len(g) for g in groups]
+        self._pending = list(self._sizes)
+        self._launched = [False] * len(groups)
+        self._handles = []
+        if self.world > 1:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def zero(self):
+        for b in self.buckets:
+            b.zero_()
+        self._pending = list(self._sizes)
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+
+    def _launch(self, bi):
+        self._launched[bi] = True
+        self._handles.append(dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def _on_grad(self, p):
+        bi = self.owner[id(p)]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0 and not self._launched[bi]:
+            self._launch(bi)
+
+    def finish(self):
+        """Call after backward: reduce what is left (parameters without a gradient this step keep
+        their bucket from completing), wait, average."""
+        if self.world == 1:
+            return
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi]:
+                self._launch(bi)
+        for h in self._handles:
+            h.wait()
+        for b in self.buckets:
+            b.mul_(1.0 / self.world)
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic data (no dataset is available offline; shapes and value ranges of data/dataset.py:41-62)
+# ----------------------------------------------------------------------------------------------
+class SyntheticCropWeed:
+    """Images: learnable colour-coded blobs + noise in [0,1] (TF.to_tensor range, no mean/std
+    normalisation, q14); labels: class ids 0/1/2 (post `img_to_label`).  Deterministic per (seed, rank)."""
+
+    def __init__(self, size: int, batch: int, device, seed: int = 42, cell: int = 32, num_classes: int = 3):
+        self.size, self.batch, self.device, self.cell, self.nc = size, batch, device, cell, num_classes
+        self.gen = torch.Generator(device="cpu")
+        self.gen.manual_seed(seed * 1000 + vdist.rank())
+        self.palette = torch.tensor([[0.25, 0.20, 0.15], [0.20, 0.55, 0.25], [0.55, 0.60, 0.20]])
+
+    def _one(self):
+        low = max(self.size // self.cell, 1)
+        lab = torch.randint(0, self.nc, (self.batch, 1, low, low), generator=self.gen).float()
+        lab = F.interpolate(lab, size=(self.size, self.size), mode="nearest")[:, 0].long()
+        img = self.palette[lab].permute(0, 3, 1, 2) + 0.15 * torch.rand(self.batch, 3, self.size, self.size, generator=self.gen)
+        return img.clamp_(0, 1), lab
+
+    def labelled(self):
+        img, lab = self._one()
+        return img.to(self.device, non_blocking=True), lab.to(self.device, non_blocking=True)
+
+    def unlabelled(self):
+        return self._one()[0].to(self.device, non_blocking=True)
+
+
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class CPSConfig:
+    model: dict
+    recipe: str = "v1"                       # "v1": entropy-percentile CPS; "v2": score-mask CPS
+    num_classes: int = 3
+    learning_rate: float = 1e-4
+    min_lr: float = 1e-7
+    total_iters: int = 1000
+    warmup_steps: int = 0
+    cps_loss_weight: float = 1.0
+    total_commitment_loss_weight: float = 1.0
+    total_prototype_loss_weight: float = 0.01
+    unsup_loss_drop_percent: float = 20.0
+    confidence_threshold: float = 0.7
+    criterion: str = "dice_loss"
+    init_weights: bool = True
+    bn_eps: float = 1e-5
+    bn_momentum: float = 0.1
+    amp_dtype: Optional[torch.dtype] = None   # torch.bfloat16 = the ROCm-native counterpart of the reference's fp16 AMP
+    bucket_mb: float = 64.0
+    seed: int = 42
+    extra: dict = field(default_factory=dict)
+
+
+def regularized_pseudo_label(raw: torch.Tensor, percent: float) -> torch.Tensor:
+    """make_regularized_pseudo_label (deprecated/train_with_test_pt_pseudo_entropy_reg.py:30-39) with
+    the percentile taken on the device (torch.quantile == np.percentile, linear interpolation)."""
+    prob = torch.softmax(raw.float(), dim=1)
+    label = torch.argmax(prob, dim=1)
+    entropy = -torch.sum(prob * torch.log(prob + 1e-10), dim=1)
+    flat = entropy.detach().flatten()
+    if flat.numel() > (1 << 24):                      # torch.quantile's input limit: exact k-th value instead
+        k = percent / 100.0 * (flat.numel() - 1)
+        lo = torch.kthvalue(flat, int(k) + 1).values
+        hi = torch.kthvalue(flat, min(int(k) + 2, flat.numel())).values
+        thresh = lo + (hi - lo) * (k - int(k))
+    else:
+        thresh = torch.quantile(flat, percent / 100.0)
+    return torch.where(entropy >= thresh, torch.full_like(label, 255), label)
+
+
+def score_mask(pred: torch.Tensor, pseudo: torch.Tensor, th: float = 0.7) -> torch.Tensor:
+    """train_vqreptunet1x1v2.py:43-46."""
+    top = torch.softmax(pred.float(), dim=1).max(dim=1)[0]
+    return torch.where(top > th, pseudo, torch.full_like(pseudo, 255))
+
+
+class CPSTrainer:
+    def __init__(self, cfg: CPSConfig, device):
+        self.cfg, self.device = cfg, device
+        torch.manual_seed(cfg.seed)                      # same initial weights on every rank
+        self.models = [make_model(cfg.model).to(device), make_model(cfg.model).to(device)]
+        if cfg.init_weights:                             # train_vqreptunet1x1v2.py:73-80
+            for m in self.models:
+                init_weight([m.decoder, m.segmentation_head], nn.init.kaiming_normal_, nn.BatchNorm2d, cfg.bn_eps,
+                            cfg.bn_momentum, mode="fan_in", nonlinearity="relu")
+        if vdist.world_size() > 1:
+            for m in self.models:
+                for t in list(m.parameters()) + list(m.buffers()):
+                    dist.broadcast(t.data, src=0)
+        for m in self.models:
+            m.to(memory_format=torch.channels_last)
+        self.buckets = [GradBuckets(list(m.parameters()), cfg.bucket_mb) for m in self.models]
+        self.opts = [torch.optim.Adam(m.parameters(), lr=cfg.learning_rate, betas=(0.9, 0.999)) for m in self.models]
+        self.sched = CosineAnnealingLR(cfg.learning_rate, cfg.min_lr, cfg.total_iters, cfg.warmup_steps)
+        self.ce = nn.CrossEntropyLoss(ignore_index=255)
+        self.criterion = make_loss(cfg.criterion, cfg.num_classes, ignore_index=255)
+        self.iter = 0
+
+    # -- one model forward under the configured precision
+    def _fwd(self, model, *a, **kw):
+        if self.cfg.amp_dtype is None:
+            return model(*a, **kw)
+        with torch.autocast("cuda", dtype=self.cfg.amp_dtype):
+            return model(*a, **kw)
+
+    def step(self, l_input, l_target, ul_input, epoch_frac: float = 0.0) -> Dict[str, torch.Tensor]:
+        """One CPS iteration on B labelled + B unlabelled images (6 forwards, 4 backwards per pair of
+        models).  Returns device scalars (no host sync)."""
+        cfg = self.cfg
+        m1, m2 = self.models
+        for b in self.buckets:
+            b.zero()
+        with torch.no_grad():                                           # pseudo labels from eval passes
+            m1.eval(); m2.eval()
+            score_1 = self._fwd(m1, ul_input)[0].float()
+            score_2 = self._fwd(m2, ul_input)[0].float()
+            m1.train(); m2.train()
+        if cfg.recipe == "v1":
+            percent = 100 - cfg.unsup_loss_drop_percent * (1 - epoch_frac)
+            kw = dict(percent=percent)
+            gt_ul_1, gt_ul_2 = torch.argmax(score_2, dim=1), torch.argmax(score_1, dim=1)
+        else:
+            kw = dict(th=cfg.confidence_threshold)
+            gt_ul_1, gt_ul_2 = score_2, score_1
+        ps1, c_l1, _u, p_l1 = self._fwd(m1, l_input, l_target, **kw)
+        ps2, c_l2, _u, p_l2 = self._fwd(m2, l_input, l_target, **kw)
+        pu1, c_u1, _u, p_u1 = self._fwd(m1, ul_input, gt_ul_1, **kw)
+        pu2, c_u2, usage, p_u2 = self._fwd(m2, ul_input, gt_ul_2, **kw)
+        ps1, ps2, pu1, pu2 = ps1.float(), ps2.float(), pu1.float(), pu2.float()
+        pred_1, pred_2 = torch.cat([ps1, pu1], dim=0), torch.cat([ps2, pu2], dim=0)
+        if cfg.recipe == "v1":
+            pseudo_1 = regularized_pseudo_label(pred_1, percent)
+            pseudo_2 = regularized_pseudo_label(pred_2, percent)
+            cps = self.criterion(pred_1, pseudo_2) + self.criterion(pred_2, pseudo_1)
+            sup_1, sup_2 = self.criterion(ps1, l_target), self.criterion(ps2, l_target)
+        else:
+            pl1, pl2 = torch.argmax(pred_1, dim=1).long(), torch.argmax(pred_2, dim=1).long()
+            f1 = score_mask(pred_1, pl1, cfg.confidence_threshold)
+            f2 = score_mask(pred_2, pl2, cfg.confidence_threshold)
+            cps = 0.5 * self.ce(pred_1, f2) + 0.5 * self.ce(pred_2, f1) + self.criterion(pred_1, f2) + self.criterion(pred_2, f1)
+            sup_1 = 0.5 * self.ce(ps1, l_target) + self.criterion(ps1, l_target)
+            sup_2 = 0.5 * self.ce(ps2, l_target) + self.criterion(ps2, l_target)
+        commitment = (c_l1 + c_l2 + c_u1 + c_u2) * cfg.total_commitment_loss_weight
+        prototype = (p_l1 + p_l2 + p_u1 + p_u2) * cfg.total_prototype_loss_weight
+        lr = self.sched.get_lr(self.iter)
+        for o in self.opts:
+            o.param_groups[0]["lr"] = lr
+        loss = sup_1 + sup_2 + cfg.cps_loss_weight * cps + commitment.sum() + prototype.float()
+        loss.backward()
+        for b in self.buckets:
+            b.finish()
+        for o in self.opts:
+            o.step()
+        self.iter += 1
+        with torch.no_grad():
+            miou, _ = miou_device(confusion_matrix_device(ps1, l_target, cfg.num_classes))
+        return {"loss": loss.detach(), "sup_loss_1": sup_1.detach(), "sup_loss_2": sup_2.detach(), "cps_loss": cps.detach(),
+                "commitment_loss": commitment.detach().sum(), "prototype_loss": prototype.detach(), "miou": miou,
+                "lr": torch.tensor(lr)}
+
+    def supervised_step(self, l_input, l_target) -> torch.Tensor:
+        """Plain supervised step of model 1 (Dice + 0.5 CE), for the single-model throughput figure."""
+        m = self.models[0]
+        self.buckets[0].zero()
+        m.train()
+        kw = dict(percent=80.0) if self.cfg.recipe == "v1" else dict(th=self.cfg.confidence_threshold)
+        pred, closs, _u, ploss = self._fwd(m, l_input, l_target, **kw)
+        pred = pred.float()
+        loss = 0.5 * self.ce(pred, l_target) + self.criterion(pred, l_target) + closs.sum() + 0.01 * ploss.float()
+        loss.backward()
+        self.buckets[0].finish()
+        self.opts[0].step()
+        return loss.detach()
