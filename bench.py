@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""Headline benchmark: train images/sec @512x512 vqreptunet1x1 K=512 (BASELINE.json `metric`).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = ONE cross-pseudo-supervision training iteration of the two VQ-UNets on B labelled +
+B unlabelled synthetic 512x512 images per GPU (6 forwards, 4 backwards, 2 Adam steps):
+"images" = the 2*B input images a step consumes per GPU.  Inputs are resident in HBM before the
+timed region.  Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     -- the hand-written distance+argmin kernel (vq_assign_f32_kernel): algorithmic flops
+                  2*N*K*C of every launch inside the timed region / its HIP-event time, vs the fp32
+                  MFMA peak (157.3 TF/s, MI355X_MICROARCH.md)
+  cpu_baseline -- the CPU oracle's restatement of the same iteration (oracle/cps_ref.py) timed on this
+                  host's cores on a bounded sample (B=1+1); a reported baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+# Ops still on PyTorch-ROCm/MIOpen (DESIGN.md "status") must not run MIOpen's exhaustive per-shape search on a
+# fresh box (minutes of silence); the hand-written HIP kernels are unaffected by this.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+SIZE, K_CODES = 512, 512
+
+
+def model_cfg():
+    return {"name": "vqreptunet1x1", "params": {
+        "encoder_name": "resnet50", "num_classes": 3, "depth": 5,
+        "vq_cfg": {"num_embeddings": [0, 0, K_CODES, K_CODES, K_CODES], "distance": "euclidean", "kmeans_init": True},
+        "margin": 0.0, "scale": 1.0, "use_feature": False, "encoder_weights": None}}
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """Oracle CPS iteration on the host CPU (fp32, all cores), B = 1 labelled + 1 unlabelled 512x512."""
+    from oracle.cps_ref import CPSReference
+    from tests import golden_io, synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    shapes = golden_io.layout("vqreptunet1x1")
+    sds = [synth.synth_state_dict(shapes, 77 + i) for i in range(2)]
+    ref = CPSReference(sds)
+    l_in, l_tg, ul_in = synth.uniform(1, (1, 3, SIZE, SIZE)), synth.blob_labels(2, 1, SIZE, cell=32), synth.uniform(3, (1, 3, SIZE, SIZE))
+    t0 = time.time()
+    ref.step(l_in, l_tg, ul_in)                      # warm-up iteration (also allocator / thread-pool warm-up)
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while n < 1 or (time.time() - t0 + warm) < seconds_budget and n < 3:
+        ref.step(l_in, l_tg, ul_in)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} CPS iteration(s) of B=1 labelled + 1 unlabelled 512x512 images, fp32, torch CPU ops "
+                      f"(oracle/cps_ref.py), after 1 warm-up iteration; {dt:.2f} s/iteration"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="labelled images per GPU per step (+ as many unlabelled)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)          # "nccl" IS RCCL on ROCm
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from vq_seg_amd import _hip
+    from vq_seg_amd.trainer import CPSConfig, CPSTrainer, SyntheticCropWeed
+
+    t_start = time.perf_counter()
+    cfg = CPSConfig(model=model_cfg(), recipe="v1", total_iters=args.steps + args.warmup + 1,
+                    amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
+    trainer = CPSTrainer(cfg, device)
+    data = SyntheticCropWeed(SIZE, args.batch, device, seed=42)
+    batches = [(data.labelled(), data.unlabelled()) for _ in range(2)]      # resident in HBM before timing
+    torch.cuda.synchronize()
+
+    def one(i):
+        (l_in, l_tg), ul_in = batches[i % len(batches)]
+        return trainer.step(l_in, l_tg, ul_in, epoch_frac=0.0)
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    for i in range(args.warmup):
+        one(i)
+        torch.cuda.synchronize()
+        note(f"warm-up step {i + 1}/{args.warmup} done")
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        _hip.profile_begin(64 * args.steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    loss = float(out["loss"])
+    note(f"{args.steps} timed steps done in {elapsed:.2f}s")
+
+    if rank == 0:
+        recs = _hip.profile_collect(64 * args.steps)
+        flops = sum(2.0 * n * c * k for n, c, k, _ in recs)
+        ms = sum(r[3] for r in recs)
+        per_shape = {}
+        for n, c, k, m in recs:
+            e = per_shape.setdefault(f"N{n}xC{c}xK{k}", [0, 0.0, 2.0 * n * c * k])
+            e[0] += 1
+            e[1] += m
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        images = 2 * args.batch * world * args.steps
+        line = {
+            "metric": "train images/sec @512x512 vqreptunet1x1 K=512",
+            "value": round(images / elapsed, 3), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "CPS training iteration (2 x vqreptunet1x1, ResNet-50 encoder, K=[0,0,512,512,512], "
+                                   "v1 recipe: 6 forwards + 4 backwards + 2 Adam steps) on 512x512x3 images",
+                       "images_per_step_per_gpu": 2 * args.batch, "labelled_per_gpu": args.batch,
+                       "unlabelled_per_gpu": args.batch, "parallelism": f"dp{world}",
+                       "vq_dtype": "f32 (exact fp32 MFMA, bit-exact argmin)", "conv_dtype": args.dtype,
+                       "final_loss": round(loss, 5)},
+            "roofline": {"kernel": "vq_assign_f32_kernel", "bound": "mfma", "achieved": round(achieved, 2),
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches": len(recs), "avg_launch_us": round(ms / max(len(recs), 1) * 1e3, 2),
+                         "per_shape": {s: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2),
+                                           "tflops": round(v[2] / (v[1] / v[0] * 1e-3) / 1e12, 2)}
+                                       for s, v in per_shape.items()},
+                         "note": "algorithmic flops 2*N*K*C per launch / HIP-event time on the launch stream, "
+                                 "all launches inside the timed region; peak = fp32 MFMA (MI355X_MICROARCH.md)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

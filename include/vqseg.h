@@ -39,6 +39,14 @@ const char* vqseg_last_error(void);
 /* Name of the dominant kernel symbol of an entry point (for rocprof matching). */
 const char* vqseg_kernel_name(const char* entry_point);
 
+/* Measurement aid (bench.py roofline leg): while enabled, every launch of the distance+argmin
+ * kernel is bracketed by a hipEvent pair on its own stream.  vqseg_profile_collect waits for the
+ * recorded launches, writes per-launch (n_rows, channels, n_codes, milliseconds) to HOST arrays,
+ * disables recording and returns the number of records (>= 0).  Not thread safe. */
+int vqseg_profile_begin(int capacity);
+int vqseg_profile_collect(int max_records, int64_t* n_rows_host, int* channels_host,
+                          int* n_codes_host, float* ms_host);
+
 /* ---------------------------------------------------------------------------------- *
  * Vector quantiser forward.
  * Replaces EuclideanCodebook.forward (vector_quantizer/vq_img.py:160-177: cdist ->

@@ -21,6 +21,8 @@ SYMBOLS = {
     "vqseg_abi_version": (c_int, []),
     "vqseg_last_error": (c_char_p, []),
     "vqseg_kernel_name": (c_char_p, [c_char_p]),
+    "vqseg_profile_begin": (c_int, [c_int]),
+    "vqseg_profile_collect": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqseg_vq_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "vqseg_vq_forward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -199,3 +201,20 @@ def kmeans_finalize(sums: torch.Tensor, counts: torch.Tensor, means: torch.Tenso
                                          _dev(means, torch.float32, "means"), c, k, _stream())
     _check(rc, "vqseg_kmeans_finalize_f32")
     return means
+
+
+def profile_begin(capacity: int = 4096) -> None:
+    _check(lib().vqseg_profile_begin(int(capacity)), "vqseg_profile_begin")
+
+
+def profile_collect(capacity: int = 4096):
+    """-> list of (n_rows, channels, n_codes, milliseconds) for every assign launch since profile_begin."""
+    import numpy as np
+    n = np.zeros(capacity, dtype=np.int64)
+    c = np.zeros(capacity, dtype=np.int32)
+    k = np.zeros(capacity, dtype=np.int32)
+    ms = np.zeros(capacity, dtype=np.float32)
+    cnt = lib().vqseg_profile_collect(capacity, n.ctypes.data, c.ctypes.data, k.ctypes.data, ms.ctypes.data)
+    if cnt < 0:
+        _check(cnt, "vqseg_profile_collect")
+    return [(int(n[i]), int(c[i]), int(k[i]), float(ms[i])) for i in range(cnt)]

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace vqseg {
 
 struct VqPlan {
@@ -16,6 +18,20 @@ struct KmPlan {
     VqPlan vq;
     size_t off_idx, off_counts, off_offsets, off_members, off_sums, off_counts64, bytes;
 };
+
+struct ProfShape {
+    int64_t n;
+    int c, k;
+};
+struct Profile {
+    bool enabled = false;
+    int capacity = 0;
+    std::vector<hipEvent_t> ev;
+    std::vector<ProfShape> shape;
+};
+hipError_t profile_begin(int capacity);
+void profile_release();
+int profile_collect(int max_records, int64_t* n, int* c, int* k, float* ms);
 
 VqPlan vq_plan(int64_t N, int C, int K);
 KmPlan km_plan(int64_t N, int C, int K);

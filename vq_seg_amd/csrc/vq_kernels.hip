@@ -495,6 +495,48 @@ hipError_t launch_prepare(const float* W, int K, int C, void* prepared, hipStrea
     return hipGetLastError();
 }
 
+// ---- optional per-launch timing of the assign kernel (bench.py's roofline leg): event pairs on the launch stream
+static Profile g_prof;
+
+hipError_t profile_begin(int capacity) {
+    profile_release();
+    g_prof.ev.resize((size_t)capacity * 2);
+    for (auto& e : g_prof.ev) {
+        hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess) return rc;
+    }
+    g_prof.shape.clear();
+    g_prof.capacity = capacity;
+    g_prof.enabled = true;
+    return hipSuccess;
+}
+
+void profile_release() {
+    for (auto& e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear();
+    g_prof.shape.clear();
+    g_prof.enabled = false;
+    g_prof.capacity = 0;
+}
+
+int profile_collect(int max_records, int64_t* n, int* c, int* k, float* ms) {
+    g_prof.enabled = false;
+    const int cnt = (int)g_prof.shape.size();
+    int out = 0;
+    for (int i = 0; i < cnt && out < max_records; ++i) {
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) break;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) break;
+        n[out] = g_prof.shape[i].n;
+        c[out] = g_prof.shape[i].c;
+        k[out] = g_prof.shape[i].k;
+        ms[out] = t;
+        ++out;
+    }
+    profile_release();
+    return out;
+}
+
 template <int T>
 static void launch_assign_t(const float* x, const float* E4, const float* en, int64_t N, int C, int Kp,
                             unsigned long long* keys, hipStream_t st) {
@@ -510,12 +552,19 @@ hipError_t launch_assign(const float* x, int64_t N, int C, int K, const void* pr
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws + p.off_keys);
     hipError_t e = hipMemsetAsync(keys, 0xff, (size_t)N * sizeof(unsigned long long), st);
     if (e != hipSuccess) return e;
+    const bool rec = g_prof.enabled && (int)g_prof.shape.size() < g_prof.capacity;
+    const size_t slot = g_prof.shape.size();
+    if (rec) {
+        g_prof.shape.push_back({N, C, K});
+        (void)hipEventRecord(g_prof.ev[2 * slot], st);
+    }
     switch (p.T) {
         case 8: launch_assign_t<8>(x, E4, en, N, C, p.Kp, keys, st); break;
         case 4: launch_assign_t<4>(x, E4, en, N, C, p.Kp, keys, st); break;
         case 2: launch_assign_t<2>(x, E4, en, N, C, p.Kp, keys, st); break;
         default: launch_assign_t<1>(x, E4, en, N, C, p.Kp, keys, st); break;
     }
+    if (rec) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
     long blocks = (N + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(vq_unpack_keys, dim3((unsigned)blocks), dim3(256), 0, st, keys, (long)N,

@@ -47,6 +47,19 @@ const char* vqseg_kernel_name(const char* entry) {
     return "";
 }
 
+int vqseg_profile_begin(int capacity) {
+    if (capacity <= 0 || capacity > (1 << 20)) return fail(VQSEG_EINVAL, "capacity out of range");
+    hipError_t e = vqseg::profile_begin(capacity);
+    if (e != hipSuccess) return hip_fail(e, "profile_begin");
+    return 0;
+}
+
+int vqseg_profile_collect(int max_records, int64_t* n_rows_host, int* channels_host, int* n_codes_host, float* ms_host) {
+    if (max_records <= 0 || !n_rows_host || !channels_host || !n_codes_host || !ms_host)
+        return fail(VQSEG_EINVAL, "bad argument");
+    return vqseg::profile_collect(max_records, n_rows_host, channels_host, n_codes_host, ms_host);
+}
+
 size_t vqseg_vq_workspace_bytes(int64_t n, int c, int k) {
     if (n <= 0 || c <= 0 || k <= 0) return 0;
     return vqseg::vq_plan(n, c, k).bytes;
