@@ -116,6 +116,83 @@ int vqseg_kmeans_accumulate_f32(const float* samples, const float* means, int64_
 int vqseg_kmeans_finalize_f32(const float* sums, const int64_t* counts, float* means,
                               int channels, int n_codes, void* stream);
 
+
+/* ================================================================================== *
+ * Encoder / decoder blocks.  Tensors are NHWC rows; `precise` = 1: activations fp32, bf16x3
+ * split MFMA (parity mode); 0: activations bf16 (fast mode).  `bf16` flags name the
+ * element type of the activation tensors (0 = f32, 1 = bf16).
+ * ================================================================================== */
+
+/* nn.Conv2d weights [Cout][Cin][KH][KW] f32 -> MFMA-side image [Cout][KH][KW][Cin] bf16 (hi, and lo
+ * when `lo` != NULL).  transpose_flip = 1 builds the data-gradient image [Cin][KH][KW][Cout] with the
+ * taps flipped.  The contracted channel count is zero-padded to a multiple of 32; each array holds
+ * vqseg_conv_packed_elems() 16-bit elements. */
+size_t vqseg_conv_packed_elems(int cout, int cin, int kh, int kw, int transpose_flip);
+int vqseg_conv_pack_weights_f32(const float* w, int cout, int cin, int kh, int kw, int transpose_flip,
+                                void* hi, void* lo, void* stream);
+
+/* Implicit-GEMM convolution, no bias.  Replaces nn.Conv2d in conv_bn_relu
+ * (models/networks/unet/decoder.py:7-10) and in the ResNet blocks (models/encoders/resnet.py:117-190):
+ *   y[n,oh,ow,co] = sum_{kh,kw,ci} in[n, (oh*stride - pad + kh)/up, (ow*stride - pad + kw)/up, ci] * w[co,kh,kw,ci]
+ * with zero padding, or reflect padding (nn.Conv2d(padding_mode='reflect'), resnet.py:134-148) when
+ * `reflect`; `up` > 1 reads the input on an up-sampled grid (only exact multiples exist): the data
+ * gradient of a stride-`up` convolution.  Channels [0,c1) come from x, [c1,cin) from x2 -- the decoder's
+ * torch.cat((upsampled, skip), 1) (decoder.py:35-37) fused into the loader (c1 == cin: no concat).
+ * stat_partial (nullable): per-wave (mean, M2) BatchNorm partials, vqseg_conv_stat_slots() x 2 x cout floats. */
+int64_t vqseg_conv_stat_slots(int64_t m_rows, int cout);
+int vqseg_conv2d_f(const void* x, const void* x2, int c1, const void* w_hi, const void* w_lo, void* y,
+                   float* stat_partial, int n, int h, int w, int cin, int cout, int kh, int kw, int stride,
+                   int pad, int reflect, int up, int ho, int wo, int precise, void* stream);
+
+/* Weight gradient of the same convolution: gw[co][ci][kh][kw] (nn.Conv2d layout, f32) =
+ * sum_m gy[m][co] * in_tap[m][ci].  im2col = 1: x is a [M][cin] patch matrix of a kh x kw x cin_out
+ * convolution (the 7x7 stem) and gw gets [cout][cin_out][kh][kw]. */
+size_t vqseg_conv2d_wgrad_workspace_bytes(int n, int h, int w, int cin, int ho, int wo, int cout, int kh, int kw);
+int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, int n, int h, int w, int cin,
+                         int ho, int wo, int cout, int kh, int kw, int stride, int pad, int reflect, int precise,
+                         int cin_out, int im2col, void* workspace, size_t workspace_bytes, float* gw, void* stream);
+
+/* nn.BatchNorm2d (+ fused residual add and ReLU).  Training: batch statistics merged from the conv
+ * epilogue partials (Welford/Chan, double, fixed order), running stats updated like nn.BatchNorm2d
+ * (biased variance to normalise, unbiased into running_var).  Eval: running statistics.
+ *   finalize -> scale[c] = gamma*invstd, shift[c] = beta - mean*scale, save_mean, save_invstd
+ *   apply    -> out = relu?( y*scale + shift (+ res) )
+ *   backward -> gz = g_out * (out > 0); dgamma, dbeta; g_y (train: with the batch-statistics terms);
+ *               g_res = gz when a residual branch exists. */
+int vqseg_bn_finalize_f(const float* partial, int64_t m_rows, int c, const float* gamma, const float* beta,
+                        float* run_mean, float* run_var, float momentum, float eps, int training,
+                        float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+int vqseg_bn_apply_f(int bf16, const void* y, const void* res, const float* scale, const float* shift,
+                     int64_t m_rows, int c, int relu, void* out, void* stream);
+size_t vqseg_bn_backward_workspace_floats(int64_t m_rows, int c);
+int vqseg_bn_backward_f(int bf16, const void* g_out, const void* out, const void* y, const float* mean,
+                        const float* invstd, const float* gamma, int64_t m_rows, int c, int relu, int training,
+                        float* workspace, float* dgamma, float* dbeta, void* g_y, void* g_res, void* stream);
+
+/* nn.MaxPool2d(3, 2, 1) (resnet.py:167) forward / backward (first maximum in scan order). */
+int vqseg_maxpool3x3s2_f(int bf16, int backward, const void* x, const void* g, int n, int h, int w, int c,
+                         void* out, void* stream);
+
+/* Bilinear resize: F.interpolate(mode='bilinear') (decoder.py:35, align_corners = 0) and
+ * nn.UpsamplingBilinear2d (modified_vqunet/net.py:1172, align_corners = 1).
+ * forward: src [n,h,w,c] -> dst [n,ho,wo,c];  backward: src = grad [n,ho,wo,c] -> dst [n,h,w,c]. */
+int vqseg_bilinear_f(int bf16, int backward, const void* src, int n, int h, int w, int c, int ho, int wo,
+                     int align_corners, void* dst, void* stream);
+
+/* 1x1 segmentation head, nn.Conv2d(32, num_classes, 1, bias=False) (net.py:1169): logits f32. */
+int vqseg_head1x1_forward_f(int bf16, const void* x, const float* w, int64_t m_rows, int cin, int cout,
+                            float* y, void* stream);
+size_t vqseg_head1x1_backward_workspace_floats(int64_t m_rows, int cin, int cout);
+int vqseg_head1x1_backward_f(int bf16, const void* x, const float* w, const float* g, int64_t m_rows, int cin,
+                             int cout, void* gx, float* gw, float* workspace, void* stream);
+
+/* Stem support: patch matrix of the 7x7/2 convolution (resnet.py:122-125; zero or reflect padding),
+ * columns (kh, kw, ci) padded with zeros to kp; gradient fold of reflect padding 1; f32 <-> bf16 cast. */
+int vqseg_im2col_f(int out_bf16, const float* x, int n, int h, int w, int cin, int kh, int kw, int stride,
+                   int pad, int reflect, int ho, int wo, int kp, void* out, void* stream);
+int vqseg_reflect_fold_f(int bf16, const void* gp, int n, int h, int w, int c, void* gx, void* stream);
+int vqseg_cast_f(int to_bf16, const void* x, int64_t n, void* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

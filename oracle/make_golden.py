@@ -131,7 +131,7 @@ def gen_kmeans(ref):
 # ---------------------------------------------------------------- decoder
 DEC_CASES = [
     dict(name="decoder_small", enc=(3, 8, 16, 24, 32, 48), dec=(24, 16, 12, 8, 4), b=2, s=64),
-    dict(name="decoder_odd", enc=(3, 4, 8, 8, 16, 16), dec=(8, 8, 4, 4, 2), b=1, s=96),
+    dict(name="decoder_odd", enc=(3, 4, 8, 8, 16, 16), dec=(8, 8, 4, 4, 4), b=1, s=96),
 ]
 
 

@@ -1,0 +1,210 @@
+"""GPU parity of the encoder/decoder building blocks (HIP kernels through the C ABI) against plain PyTorch
+fp32 references of the same ops run on the CPU (this tier's oracle for floating-point kernels).
+precise mode (fp32 activations, bf16x3 split MFMA): 2e-4 of the tensor scale; fast mode (bf16): 3e-2."""
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def cl(t):
+    return t.to(dev()).contiguous(memory_format=torch.channels_last)
+
+
+CONV_CASES = [
+    # n, cin, cout, h, w, k, stride, pad, reflect, c2 (second input channels), residual
+    (2, 64, 64, 16, 16, 3, 1, 1, False, 0, False),
+    (2, 64, 128, 17, 13, 3, 1, 1, True, 0, False),          # reflect, ragged spatial size
+    (1, 128, 256, 16, 16, 3, 2, 1, True, 0, False),         # stride-2 reflect (bottleneck conv2 of a stage's first block)
+    (2, 256, 512, 8, 8, 1, 2, 0, False, 0, False),          # 1x1 stride-2 projection shortcut
+    (2, 64, 256, 12, 12, 1, 1, 0, False, 0, True),          # conv3 + residual + relu
+    (2, 128, 32, 24, 24, 3, 1, 1, False, 64, False),        # decoder concat 128 + 64 -> 32
+    (1, 32, 32, 40, 40, 3, 1, 1, False, 0, False),
+    (2, 24, 16, 9, 11, 3, 1, 1, False, 32, False),          # odd channel counts (fixture-style decoder)
+    (3, 48, 24, 5, 5, 3, 1, 1, False, 0, False),
+]
+
+
+@pytest.mark.parametrize("mode", ["precise", "fast"])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bn_act_forward_backward(case, training, mode):
+    from vq_seg_amd import nnf
+    n, cin, cout, h, w, k, s, p, reflect, c2, use_res = case
+    if mode == "fast" and (cin % 8 or c2 % 8 or cout % 8):
+        pytest.skip("bf16 mode needs channel counts that are multiples of 8")
+    seed = sum(case[:8]) + 7 * int(training)
+    conv = nn.Conv2d(cin + c2, cout, k, s, p, bias=False, padding_mode="reflect" if reflect else "zeros")
+    bn = nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        conv.weight.copy_(synth.uniform(seed, tuple(conv.weight.shape), -1, 1) * (2.0 / ((cin + c2) * k * k)) ** 0.5)
+        bn.weight.copy_(synth.uniform(seed + 1, (cout,), 0.5, 1.5))
+        bn.bias.copy_(synth.uniform(seed + 2, (cout,), -0.3, 0.3))
+        bn.running_mean.copy_(synth.uniform(seed + 3, (cout,), -0.2, 0.2))
+        bn.running_var.copy_(synth.uniform(seed + 4, (cout,), 0.5, 1.5))
+    conv.train(training), bn.train(training)
+    x = synth.uniform(seed + 5, (n, cin, h, w), -1, 1)
+    x2 = synth.uniform(seed + 6, (n, c2, h, w), -1, 1) if c2 else None
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    res = synth.uniform(seed + 7, (n, cout, ho, wo), -1, 1) if use_res else None
+    g = synth.uniform(seed + 8, (n, cout, ho, wo), -1, 1)
+    dt = torch.float32 if mode == "precise" else torch.bfloat16
+    x, g = x.to(dt).float(), g.to(dt).float()                   # the values the kernels actually receive
+    x2 = x2.to(dt).float() if c2 else None
+    res = res.to(dt).float() if use_res else None
+    # ReLU is discontinuous: where the pre-activation is within the kernels' rounding error of zero the mask may
+    # legitimately differ from the fp32 reference, so the cotangent is zeroed there (both sides).
+    with torch.no_grad():
+        pre = bn(conv(torch.cat((x, x2), 1) if c2 else x)) + (res if use_res else 0)
+        if training:                                            # undo the running-stat update of this probe forward
+            bn.running_mean.copy_(synth.uniform(seed + 3, (cout,), -0.2, 0.2))
+            bn.running_var.copy_(synth.uniform(seed + 4, (cout,), 0.5, 1.5))
+            bn.num_batches_tracked.zero_()
+    g = g * (pre.abs() > (1e-4 if mode == "precise" else 5e-2)).float()
+    # ---- CPU fp32 reference
+    xr = x.clone().requires_grad_(True)
+    x2r = x2.clone().requires_grad_(True) if c2 else None
+    rr = res.clone().requires_grad_(True) if use_res else None
+    inp = torch.cat((xr, x2r), 1) if c2 else xr
+    y = bn(conv(inp))
+    if use_res:
+        y = y + rr
+    y = F.relu(y)
+    y.backward(g)
+    ref = dict(y=y.detach(), gx=xr.grad, gx2=x2r.grad if c2 else None, gr=rr.grad if use_res else None,
+               gw=conv.weight.grad.clone(), gg=bn.weight.grad.clone(), gb=bn.bias.grad.clone(),
+               rm=bn.running_mean.clone(), rv=bn.running_var.clone())
+    # ---- HIP path
+    import copy
+    conv_g, bn_g = copy.deepcopy(conv).to(dev()), copy.deepcopy(bn).to(dev())
+    for m_ in (conv_g, bn_g):
+        for p_ in m_.parameters():
+            p_.grad = None
+    with torch.no_grad():
+        bn_g.running_mean.copy_(synth.uniform(seed + 3, (cout,), -0.2, 0.2))
+        bn_g.running_var.copy_(synth.uniform(seed + 4, (cout,), 0.5, 1.5))
+    xg = cl(x).to(dt).requires_grad_(True)
+    x2g = cl(x2).to(dt).requires_grad_(True) if c2 else None
+    rg = cl(res).to(dt).requires_grad_(True) if use_res else None
+    out = nnf.conv_bn_act(xg, conv_g, bn_g, relu=True, residual=rg, x2=x2g)
+    assert out.dtype == dt and out.shape == ref["y"].shape
+    out.backward(cl(g).to(dt))
+    tol = 2e-4 if mode == "precise" else 3e-2
+    assert rel(out.float(), ref["y"]) < tol, "forward"
+    assert rel(xg.grad.float(), ref["gx"]) < tol, "grad x"
+    if c2:
+        assert rel(x2g.grad.float(), ref["gx2"]) < tol, "grad x2"
+    if use_res:
+        assert rel(rg.grad.float(), ref["gr"]) < tol, "grad residual"
+    assert rel(conv_g.weight.grad, ref["gw"]) < tol, "grad weight"
+    assert rel(bn_g.weight.grad, ref["gg"]) < tol, "grad gamma"
+    assert rel(bn_g.bias.grad, ref["gb"]) < tol, "grad beta"
+    if training:
+        assert rel(bn_g.running_mean, ref["rm"]) < (1e-5 if mode == "precise" else 1e-2)
+        assert rel(bn_g.running_var, ref["rv"]) < (1e-5 if mode == "precise" else 1e-2)
+        assert int(bn_g.num_batches_tracked) == int(bn.num_batches_tracked) + 1   # (copied after the CPU forward)
+
+
+@pytest.mark.parametrize("mode", ["precise", "fast"])
+@pytest.mark.parametrize("reflect", [True, False])
+def test_stem(reflect, mode):
+    from vq_seg_amd import nnf
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False, padding_mode="reflect" if reflect else "zeros")
+    bn = nn.BatchNorm2d(64)
+    x = synth.uniform(5, (2, 3, 40, 36))
+    g = synth.uniform(6, (2, 64, 20, 18), -1, 1)
+    if mode == "fast":
+        g = g.bfloat16().float()
+    with torch.no_grad():                                          # see test_conv_bn_act: zero the cotangent near the ReLU kink
+        pre = bn(conv(x))
+        bn.running_mean.zero_(), bn.running_var.fill_(1.0), bn.num_batches_tracked.zero_()
+    g = g * (pre.abs() > (1e-4 if mode == "precise" else 5e-2)).float()
+    y = F.relu(bn(conv(x)))
+    y.backward(g)
+    import copy
+    cg, bg = copy.deepcopy(conv).to(dev()), copy.deepcopy(bn).to(dev())
+    cg.weight.grad = None
+    bg.weight.grad = bg.bias.grad = None
+    with torch.no_grad():
+        bg.running_mean.zero_(), bg.running_var.fill_(1.0)
+    if mode == "fast":
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = nnf.stem_conv_bn_act(cl(x), cg, bg)
+    else:
+        out = nnf.stem_conv_bn_act(cl(x), cg, bg)
+    out.backward(cl(g).to(out.dtype))
+    tol = 2e-4 if mode == "precise" else 3e-2
+    assert out.dtype == (torch.float32 if mode == "precise" else torch.bfloat16)
+    assert rel(out.float(), y) < tol
+    assert rel(cg.weight.grad, conv.weight.grad) < tol
+    assert rel(bg.weight.grad, bn.weight.grad) < tol and rel(bg.bias.grad, bn.bias.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool_bilinear_head(dtype):
+    from vq_seg_amd import nnf
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    x = synth.uniform(1, (2, 64, 18, 22), -1, 1)
+    xq = x.to(dtype).float()                                   # the values the kernel actually sees
+    g = synth.uniform(2, (2, 64, 9, 11), -1, 1)
+    xr = xq.clone().requires_grad_(True)
+    y = F.max_pool2d(xr, 3, 2, 1)
+    y.backward(g.to(dtype).float())
+    xg = cl(x).to(dtype).requires_grad_(True)
+    out = nnf.max_pool_3x3_s2(xg)
+    out.backward(cl(g).to(dtype))
+    assert rel(out.float(), y) < tol and rel(xg.grad.float(), xr.grad) < tol
+    for align, (ho, wo) in ((False, (36, 44)), (True, (36, 44)), (False, (35, 41))):
+        xr = xq.clone().requires_grad_(True)
+        y = F.interpolate(xr, size=(ho, wo), mode="bilinear", align_corners=align)
+        gg = synth.uniform(3, tuple(y.shape), -1, 1)
+        y.backward(gg.to(dtype).float())
+        xg = cl(x).to(dtype).requires_grad_(True)
+        out = nnf.upsample_bilinear(xg, size=(ho, wo), align_corners=align)
+        out.backward(cl(gg).to(dtype))
+        assert rel(out.float(), y) < max(tol, 1e-6), (align, ho, wo)
+        assert rel(xg.grad.float(), xr.grad) < max(tol, 2e-6), (align, ho, wo)
+    # 1x1 head: fp32 logits
+    w = synth.uniform(4, (3, 32, 1, 1), -1, 1)
+    x = synth.uniform(5, (2, 32, 20, 20), -1, 1)
+    xq = x.to(dtype).float()
+    xr, wr = xq.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr)
+    gg = synth.uniform(6, tuple(y.shape), -1, 1)
+    y.backward(gg)
+    xg, wg = cl(x).to(dtype).requires_grad_(True), w.to(dev()).requires_grad_(True)
+    out = nnf.head_conv1x1(xg, wg)
+    assert out.dtype == torch.float32
+    out.backward(cl(gg))
+    assert rel(out, y) < 1e-5 and rel(wg.grad, wr.grad) < 1e-5 and rel(xg.grad.float(), xr.grad) < max(tol, 1e-5)
+
+
+def test_kernels_are_deterministic():
+    from vq_seg_amd import nnf
+    conv = nn.Conv2d(64, 128, 3, 1, 1, bias=False).to(dev())
+    bn = nn.BatchNorm2d(128).to(dev())
+    x = cl(synth.uniform(1, (4, 64, 32, 32), -1, 1))
+    outs = []
+    for _ in range(3):
+        xg = x.clone().requires_grad_(True)
+        conv.weight.grad = None
+        o = nnf.conv_bn_act(xg, conv, bn)
+        o.sum().backward()
+        outs.append((o.detach().clone(), xg.grad.clone(), conv.weight.grad.clone()))
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0])), "run-to-run differences"

@@ -38,6 +38,27 @@ SYMBOLS = {
     "vqseg_kmeans_accumulate_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                             c_size_t, c_void_p]),
     "vqseg_kmeans_finalize_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "vqseg_conv_packed_elems": (c_size_t, [c_int] * 5),
+    "vqseg_conv_pack_weights_f32": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
+    "vqseg_conv_stat_slots": (c_int64, [c_int64, c_int]),
+    "vqseg_conv2d_f": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 14 + [c_void_p]),
+    "vqseg_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int] * 9),
+    "vqseg_conv2d_wgrad_f": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 16 + [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "vqseg_bn_finalize_f": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vqseg_bn_apply_f": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "vqseg_bn_backward_workspace_floats": (c_size_t, [c_int64, c_int]),
+    "vqseg_bn_backward_f": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vqseg_maxpool3x3s2_f": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vqseg_bilinear_f": (c_int, [c_int, c_int, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p]),
+    "vqseg_head1x1_forward_f": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "vqseg_head1x1_backward_workspace_floats": (c_size_t, [c_int64, c_int, c_int]),
+    "vqseg_head1x1_backward_f": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
+    "vqseg_im2col_f": (c_int, [c_int, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p]),
+    "vqseg_reflect_fold_f": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vqseg_cast_f": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -1,0 +1,38 @@
+// Internal declarations for the convolution / batch-norm / resampling kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace vqseg {
+
+struct ConvArgs {
+    const void* x;              // input rows [N, H, W, C1]      (f32 in precise mode, bf16 in fast mode)
+    const void* x2;             // optional second input [N, H, W, Cin - C1] (channel concat), else unused
+    int C1;                     // channels taken from x (== Cin without concat)
+    const unsigned short* w_hi; // packed weights [Cout][KH][KW][Cin padded to 32] bf16 (hi part)
+    const unsigned short* w_lo; // lo part (precise mode) or null
+    void* y;                    // output rows [N, Ho, Wo, Cout]
+    float* stat_partial;        // optional [ceil(M/128) * WM][2][Cout] per-wave (mean, M2), else null
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, reflect, up;
+};
+
+struct WgradArgs {
+    const void* gy;             // output gradient rows [N, Ho, Wo, Cout]
+    const void* x;              // forward input rows [N, H, W, C1]
+    const void* x2;             // optional second input (concat)
+    int C1;
+    float* partial;             // [slabs][Cout][KH*KW][Cin] fp32
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, reflect;
+};
+
+hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st);
+int wgrad_slabs(const WgradArgs& a);
+hipError_t launch_wgrad(const WgradArgs& a, int precise, int slabs, hipStream_t st);
+hipError_t launch_wgrad_reduce(const float* partial, int slabs, int Cout, int Cin, int Cin_out, int KH, int KW, int im2col,
+                               float* gw, hipStream_t st);
+size_t packed_elems(int Cout, int Cin, int KH, int KW, int transpose_flip);
+hipError_t launch_pack_weights(const float* w, int Cout, int Cin, int KH, int KW, int transpose_flip, unsigned short* hi,
+                               unsigned short* lo, hipStream_t st);
+
+}  // namespace vqseg

@@ -1,0 +1,620 @@
+// conv_kernels.hip -- implicit-GEMM convolution on the bf16 matrix cores of gfx950 (MI355X).
+//
+// Reference ops replaced: nn.Conv2d inside conv_bn_relu (models/networks/unet/decoder.py:7-10) and inside
+// the ResNet bottlenecks (models/encoders/resnet.py:117-190 on torchvision's Bottleneck): 3x3 / 1x1 / 7x7,
+// stride 1 / 2, zero or reflect padding, no bias.  One kernel covers the forward convolution, the data
+// gradient (same kernel on the output gradient with tap-flipped, channel-transposed weights and an
+// up-sampled ("dilated") input grid for stride-2 layers) and -- through `x2` -- the channel concatenation
+// of the decoder (decoder.py:35-37), so torch.cat never materialises.
+//
+// GEMM view:  Y[m, co] = sum_{tap, ci} A[m, (tap, ci)] * Wp[co, (tap, ci)],   m = (n, oh, ow) pixel rows, NHWC.
+//   workgroup = 4 waves = 128 pixel rows x BN output channels, wave = 64 x (BN/2) via v_mfma_f32_32x32x16_bf16
+//   K loop: taps outer, channel chunks of BK inner; A rows are gathered (zero / reflect / dilated), staged
+//   global -> registers -> LDS (rows padded by 16 B => conflict-free ds_read_b128), weights likewise.
+// Precision modes (template PRECISE):
+//   fast    : activations and weights bf16, fp32 accumulate                       (BK = 64)
+//   precise : activations fp32 in HBM, split on the fly into bf16 hi + lo; weights pre-split;
+//             acc += a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  (3 MFMAs)  ~ 2^-16 relative per product (BK = 32).
+//             This is the parity mode (logits within 1e-3 of the fp32 CPU reference) at 3/16 of the cost
+//             of the fp32 MFMA.
+// Optional epilogue: per-wave partial BatchNorm statistics (count, mean, M2 over the wave's 64 rows) for a
+// deterministic two-level Welford merge (no float atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "conv_kernels.h"
+
+namespace vqseg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 128;
+
+__device__ __forceinline__ unsigned int pack2(float a, float b) {
+    const __bf16 x = (__bf16)a, y = (__bf16)b;
+    return (unsigned int)__builtin_bit_cast(unsigned short, x) | ((unsigned int)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ float bf16_round(float a) { return (float)((__bf16)a); }
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+
+template <int BN, bool PRECISE, int BK>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+    constexpr int BKP = BK + 8;                          // bf16 elements per LDS row (16-byte pad)
+    constexpr int NT = BN / 64;                          // 32-wide N tiles per wave (BN=128 -> 2; 64 -> 1)
+    constexpr int WN = (BN >= 64) ? 2 : 1;               // waves along N
+    constexpr int WM = 4 / WN;                           // waves along M
+    constexpr int MT = BM / (WM * 32);                   // 32-tall M tiles per wave
+    constexpr int NTT = (BN >= 64) ? NT : 1;
+    constexpr int A_EPC = PRECISE ? 4 : 8;               // elements per 16-byte global chunk of A
+    constexpr int A_CPR = BK / A_EPC;                    // 16-byte chunks per A row and stage (8, or 4 for fast BK=32)
+    constexpr int A_RPP = 256 / A_CPR;                   // rows per pass
+    constexpr int A_PASSES = BM / A_RPP;
+    constexpr int B_CPR = BK / 8;                        // 16-byte chunks per weight row and stage
+    constexpr int B_CHUNKS = BN * B_CPR * (PRECISE ? 2 : 1);
+    constexpr int B_PER_THREAD = (B_CHUNKS + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* As_hi = reinterpret_cast<__bf16*>(smem);
+    __bf16* As_lo = As_hi + (PRECISE ? BM * BKP : 0);
+    __bf16* Bs_hi = As_lo + BM * BKP;
+    __bf16* Bs_lo = Bs_hi + (PRECISE ? BN * BKP : 0);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+
+    const long M = (long)p.N * p.Ho * p.Wo;
+    const long m0 = (long)blockIdx.x * BM;
+    const int co0 = blockIdx.y * BN;
+
+    // ---- per-thread A rows: A_PASSES passes of A_RPP rows, A_CPR chunks per row
+    const int a_chunk = tid % A_CPR;
+    const int a_row0 = tid / A_CPR;
+    int a_n[A_PASSES], a_oh[A_PASSES], a_ow[A_PASSES];
+    bool a_ok[A_PASSES];
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+        long m = m0 + a_row0 + A_RPP * i;
+        a_ok[i] = m < M;
+        if (!a_ok[i]) m = M - 1;
+        const int n = (int)(m / ((long)p.Ho * p.Wo));
+        const int rem = (int)(m - (long)n * p.Ho * p.Wo);
+        a_n[i] = n;
+        a_oh[i] = rem / p.Wo;
+        a_ow[i] = rem - a_oh[i] * p.Wo;
+    }
+
+    f32x16 acc[MT][NTT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NTT; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+    const int n_taps = p.KH * p.KW;
+    const int cin_p = (p.Cin + 31) / 32 * 32;            // packed weights pad Cin to a multiple of 32 with zeros
+    const int chunks_per_tap = (cin_p + BK - 1) / BK;
+    const int n_stage = n_taps * chunks_per_tap;
+    const long w_row = (long)n_taps * cin_p;              // packed weight row length (bf16 elements)
+
+    u32x4 a_reg[A_PASSES];
+    u32x4 b_reg[B_PER_THREAD];
+
+    auto load_stage = [&](int s) {
+        const int tap = s / chunks_per_tap;
+        const int ci0 = (s - tap * chunks_per_tap) * BK;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        // which source tensor holds this thread's 16-byte chunk (concat fusion): [0, C1) -> x, [C1, Cin) -> x2
+        const int cg = ci0 + a_chunk * A_EPC;              // global input channel of the chunk
+        const bool second = cg >= p.C1;
+        const char* src = reinterpret_cast<const char*>(second ? p.x2 : p.x);
+        const int csrc = second ? (p.Cin - p.C1) : p.C1;
+        const int cbase = second ? (cg - p.C1) : cg;
+        const bool c_ok = cg < p.Cin;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            int ih = a_oh[i] * p.stride - p.pad + kh;
+            int iw = a_ow[i] * p.stride - p.pad + kw;
+            bool ok = a_ok[i] && c_ok;
+            if (p.reflect) {
+                ih = reflect_idx(ih, p.H * p.up);
+                iw = reflect_idx(iw, p.W * p.up);
+            }
+            if (p.up > 1) {                                  // dilated input grid (stride-2 data gradient)
+                ok = ok && (ih % p.up == 0) && (iw % p.up == 0) && ih >= 0 && iw >= 0;
+                ih /= p.up;
+                iw /= p.up;
+            }
+            ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) {
+                const long off = (((long)a_n[i] * p.H + ih) * p.W + iw) * csrc + cbase;
+                v = *reinterpret_cast<const u32x4*>(src + off * (PRECISE ? 4 : 2));
+            }
+            a_reg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_THREAD; ++i) {
+            const int idx = tid + 256 * i;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (idx < B_CHUNKS) {
+                const int arr = PRECISE ? idx / (BN * B_CPR) : 0;
+                const int rem = PRECISE ? idx % (BN * B_CPR) : idx;
+                const int row = rem / B_CPR, ch = rem % B_CPR;
+                const unsigned short* wsrc = arr ? p.w_lo : p.w_hi;
+                const int co = co0 + row;
+                if (co < p.Cout && ci0 + ch * 8 < cin_p)
+                    v = *reinterpret_cast<const u32x4*>(wsrc + (long)co * w_row + (long)tap * cin_p + ci0 + ch * 8);
+            }
+            b_reg[i] = v;
+        }
+    };
+
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            const int row = a_row0 + A_RPP * i;
+            if (PRECISE) {
+                const f32x4 f = __builtin_bit_cast(f32x4, a_reg[i]);
+                u32x2 hi, lo;
+                hi[0] = pack2(f[0], f[1]);
+                hi[1] = pack2(f[2], f[3]);
+                lo[0] = pack2(f[0] - bf16_round(f[0]), f[1] - bf16_round(f[1]));
+                lo[1] = pack2(f[2] - bf16_round(f[2]), f[3] - bf16_round(f[3]));
+                *reinterpret_cast<u32x2*>(As_hi + row * BKP + a_chunk * 4) = hi;
+                *reinterpret_cast<u32x2*>(As_lo + row * BKP + a_chunk * 4) = lo;
+            } else {
+                *reinterpret_cast<u32x4*>(As_hi + row * BKP + a_chunk * 8) = a_reg[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_THREAD; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < B_CHUNKS) {
+                const int arr = PRECISE ? idx / (BN * B_CPR) : 0;
+                const int rem = PRECISE ? idx % (BN * B_CPR) : idx;
+                const int row = rem / B_CPR, ch = rem % B_CPR;
+                __bf16* dst = arr ? Bs_lo : Bs_hi;
+                *reinterpret_cast<u32x4*>(dst + row * BKP + ch * 8) = b_reg[i];
+            }
+        }
+    };
+
+    load_stage(0);
+    for (int s = 0; s < n_stage; ++s) {
+        store_stage();
+        __syncthreads();
+        if (s + 1 < n_stage) load_stage(s + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 a_hi[MT], a_lo[MT], b_hi[NTT], b_lo[NTT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int row = (wm * MT + a) * 32 + r;
+                a_hi[a] = *reinterpret_cast<const bf16x8*>(As_hi + row * BKP + kk * 16 + h * 8);
+                if (PRECISE) a_lo[a] = *reinterpret_cast<const bf16x8*>(As_lo + row * BKP + kk * 16 + h * 8);
+            }
+#pragma unroll
+            for (int b = 0; b < NTT; ++b) {
+                const int row = (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
+                b_hi[b] = *reinterpret_cast<const bf16x8*>(Bs_hi + row * BKP + kk * 16 + h * 8);
+                if (PRECISE) b_lo[b] = *reinterpret_cast<const bf16x8*>(Bs_lo + row * BKP + kk * 16 + h * 8);
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NTT; ++b) {
+                    if (PRECISE) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[a], b_hi[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[a], b_lo[b], acc[a][b], 0, 0, 0);
+                    }
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[a], b_hi[b], acc[a][b], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: store Y (row = pixel, lane column = output channel) and the per-wave BN partials
+    const long wrow0 = m0 + (long)wm * MT * 32;
+#pragma unroll
+    for (int b = 0; b < NTT; ++b) {
+        const int co = co0 + (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
+        const bool cok = co < p.Cout;
+        float sum = 0.0f;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float v = acc[a][b][i];
+                if (m < M && cok) {
+                    if (PRECISE) reinterpret_cast<float*>(p.y)[m * p.Cout + co] = v;
+                    else reinterpret_cast<__bf16*>(p.y)[m * p.Cout + co] = (__bf16)v;
+                    sum += v;
+                }
+            }
+        if (p.stat_partial) {
+            long cnt_l = M - wrow0;
+            const float cnt = (float)(cnt_l < 0 ? 0 : (cnt_l > MT * 32 ? MT * 32 : cnt_l));
+            sum += __shfl_xor(sum, 32);
+            const float mean = cnt > 0.f ? sum / cnt : 0.f;
+            float m2 = 0.0f;
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    const float d = acc[a][b][i] - mean;
+                    if (m < M) m2 = __builtin_fmaf(d, d, m2);
+                }
+            m2 += __shfl_xor(m2, 32);
+            if (h == 0 && cok) {
+                const long slot = (long)blockIdx.x * WM + wm;             // partial index along M
+                p.stat_partial[(slot * 2 + 0) * p.Cout + co] = mean;
+                p.stat_partial[(slot * 2 + 1) * p.Cout + co] = m2;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// weight packing: nn.Conv2d weight [Cout][Cin][KH][KW] f32 -> [Cout][KH][KW][Cin] bf16 hi (+ lo)
+//   transpose_flip: data-gradient form  [Cin][KH][KW][Cout] with taps flipped
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_pack_weights(const float* __restrict__ w, int Cout, int Cin, int KH, int KW,
+                                                         int transpose_flip, unsigned short* __restrict__ hi,
+                                                         unsigned short* __restrict__ lo) {
+    // destination [R][KH][KW][Cc_p]: R rows, Cc contraction channels padded to a multiple of 32 with zeros
+    const int R = transpose_flip ? Cin : Cout, Cc = transpose_flip ? Cout : Cin;
+    const int Cp = (Cc + 31) / 32 * 32;
+    const long total = (long)R * KH * KW * Cp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % Cp);
+        long t = i / Cp;
+        const int kw = (int)(t % KW);
+        t /= KW;
+        const int kh = (int)(t % KH);
+        const int rr = (int)(t / KH);
+        float v = 0.0f;
+        if (c < Cc) {
+            if (transpose_flip) v = w[(((long)c * Cin + rr) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+            else v = w[(((long)rr * Cin + c) * KH + kh) * KW + kw];
+        }
+        const __bf16 bh = (__bf16)v;
+        hi[i] = __builtin_bit_cast(unsigned short, bh);
+        if (lo) {
+            const __bf16 bl = (__bf16)(v - (float)bh);
+            lo[i] = __builtin_bit_cast(unsigned short, bl);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host-side launch
+// ------------------------------------------------------------------------------------
+template <int BN, bool PRECISE, int BK>
+static void launch_t(const ConvArgs& a, hipStream_t st) {
+    constexpr int BKP = BK + 8;
+    const size_t lds = (size_t)(BM + BN) * BKP * 2 * (PRECISE ? 2 : 1);
+    const long M = (long)a.N * a.Ho * a.Wo;
+    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN));
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, PRECISE, BK>), grid, dim3(256), lds, st, a);
+}
+
+hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
+    const int bn = a.Cout >= 128 ? 128 : (a.Cout >= 64 ? 64 : 32);
+    const bool k64 = !precise && a.Cin % 64 == 0 && (a.C1 == a.Cin || a.C1 % 64 == 0);
+    if (precise) {
+        if (bn == 128) launch_t<128, true, 32>(a, st);
+        else if (bn == 64) launch_t<64, true, 32>(a, st);
+        else launch_t<32, true, 32>(a, st);
+    } else if (k64) {
+        if (bn == 128) launch_t<128, false, 64>(a, st);
+        else if (bn == 64) launch_t<64, false, 64>(a, st);
+        else launch_t<32, false, 64>(a, st);
+    } else {
+        if (bn == 128) launch_t<128, false, 32>(a, st);
+        else if (bn == 64) launch_t<64, false, 32>(a, st);
+        else launch_t<32, false, 32>(a, st);
+    }
+    return hipGetLastError();
+}
+
+size_t packed_elems(int Cout, int Cin, int KH, int KW, int transpose_flip) {
+    const int R = transpose_flip ? Cin : Cout, Cc = transpose_flip ? Cout : Cin;
+    return (size_t)R * KH * KW * ((Cc + 31) / 32 * 32);
+}
+
+hipError_t launch_pack_weights(const float* w, int Cout, int Cin, int KH, int KW, int transpose_flip, unsigned short* hi,
+                               unsigned short* lo, hipStream_t st) {
+    const long total = (long)packed_elems(Cout, Cin, KH, KW, transpose_flip);
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_pack_weights, dim3((unsigned)blocks), dim3(256), 0, st, w, Cout, Cin, KH, KW, transpose_flip, hi,
+                       lo);
+    return hipGetLastError();
+}
+
+
+// =====================================================================================================
+// Weight gradient:  dW[co][tap][ci] = sum_m GY[m][co] * A_tap[m][ci]      (m = pixel rows, the GEMM K dim)
+//
+// Both operands are pixel-major in HBM (NHWC), i.e. K is their SLOW dimension.  They are staged as
+// [32 pixels][channels] bf16 tiles in LDS (rows padded to +64 B: conflict-free) and the MFMA fragments
+// (8 consecutive pixels of one channel per lane) are fetched with the gfx950 transposing LDS read
+// ds_read_b64_tr_b16 -- no explicit transpose pass.  The pixel range is split over gridDim.z slabs
+// (deterministic: each slab writes its own fp32 partial, reduced in fixed order by wgrad_reduce_kernel,
+// which also converts [Cout][taps][Cin] to nn.Conv2d's [Cout][Cin][KH][KW]).
+// =====================================================================================================
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int TM, int TN>
+struct WgradCfg {
+    static constexpr int WGM = (TM >= 4 && TN == 1) ? 4 : (TM >= 2 ? 2 : 1);
+    static constexpr int WGN = (TN >= 4 && TM == 1) ? 4 : ((TN >= 2 && WGM <= 2) ? 2 : 1);
+    static constexpr int PM = TM / WGM, PN = TN / WGN;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int row_stride, int pix0, int col0, int lane) {
+    // fragment for MFMA 32x32x16: lane (r = lane & 31, h = lane >> 5) gets column (col0 + r), rows pix0 + 8h .. +7
+    const int g = lane >> 4;                      // 16-lane group: (g & 1) -> column block, (g >> 1) -> h
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    const __bf16* a0 = tile + (pix0 + 8 * (g >> 1) + q) * row_stride + col0 + 16 * (g & 1) + 4 * pp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * row_stride));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TM, int TN, bool PRECISE>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+    using Cfg = WgradCfg<TM, TN>;
+    constexpr int BKM = 32;                               // pixels per stage
+    constexpr int GS = TM * 32 + 32;                      // LDS row stride (bf16) of the GY tile (+64 B pad)
+    constexpr int AS = TN * 32 + 32;
+    constexpr int EPC = PRECISE ? 4 : 8;                  // elements per 16-byte chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* G_hi = reinterpret_cast<__bf16*>(smem);
+    __bf16* G_lo = G_hi + (PRECISE ? BKM * GS : 0);
+    __bf16* A_hi = G_lo + BKM * GS;
+    __bf16* A_lo = A_hi + (PRECISE ? BKM * AS : 0);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
+    const bool active = wave < Cfg::WGM * Cfg::WGN;
+
+    const int ci_tiles = (p.Cin + TN * 32 - 1) / (TN * 32);
+    const int tap = blockIdx.x / ci_tiles;
+    const int ci0 = (blockIdx.x - tap * ci_tiles) * (TN * 32);
+    const int co0 = blockIdx.y * (TM * 32);
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const long M = (long)p.N * p.Ho * p.Wo;
+    long mz = (M + gridDim.z - 1) / gridDim.z;
+    mz = (mz + BKM - 1) / BKM * BKM;
+    const long m_begin = (long)blockIdx.z * mz;
+    long m_end = m_begin + mz;
+    if (m_end > M) m_end = M;
+
+    f32x16 acc[Cfg::PM][Cfg::PN];
+#pragma unroll
+    for (int a = 0; a < Cfg::PM; ++a)
+#pragma unroll
+        for (int b = 0; b < Cfg::PN; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+    constexpr int G_CPR = TM * 32 / EPC, A_CPR = TN * 32 / EPC;     // 16-byte chunks per tile row
+    constexpr int G_N = (BKM * G_CPR + 255) / 256, A_N = (BKM * A_CPR + 255) / 256;
+    u32x4 g_reg[G_N], a_reg[A_N];
+
+    auto load_stage = [&](long mb) {
+#pragma unroll
+        for (int i = 0; i < G_N; ++i) {
+            const int idx = tid + 256 * i;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (idx < BKM * G_CPR) {
+                const int row = idx / G_CPR, ch = idx % G_CPR;
+                const long m = mb + row;
+                const int co = co0 + ch * EPC;
+                if (m < m_end && co < p.Cout) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.gy) + (m * p.Cout + co) * (PRECISE ? 4 : 2));
+            }
+            g_reg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < A_N; ++i) {
+            const int idx = tid + 256 * i;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (idx < BKM * A_CPR) {
+                const int row = idx / A_CPR, ch = idx % A_CPR;
+                const long m = mb + row;
+                const int cg = ci0 + ch * EPC;                       // global input channel of this chunk
+                const bool second = cg >= p.C1;
+                const char* xsrc = reinterpret_cast<const char*>(second ? p.x2 : p.x);
+                const int csrc = second ? (p.Cin - p.C1) : p.C1;
+                const int cbase = second ? (cg - p.C1) : cg;
+                if (m < m_end && cg < p.Cin) {
+                    const int n = (int)(m / ((long)p.Ho * p.Wo));
+                    const int rem = (int)(m - (long)n * p.Ho * p.Wo);
+                    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                    int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+                    if (p.reflect) {
+                        ih = reflect_idx(ih, p.H);
+                        iw = reflect_idx(iw, p.W);
+                    }
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
+                        const long off = (((long)n * p.H + ih) * p.W + iw) * csrc + cbase;
+                        v = *reinterpret_cast<const u32x4*>(xsrc + off * (PRECISE ? 4 : 2));
+                    }
+                }
+            }
+            a_reg[i] = v;
+        }
+    };
+
+    auto store_tile = [&](const u32x4& v, __bf16* hi, __bf16* lo, int row, int ch, int stride_) {
+        if (PRECISE) {
+            const f32x4 f = __builtin_bit_cast(f32x4, v);
+            u32x2 h2, l2;
+            h2[0] = pack2(f[0], f[1]);
+            h2[1] = pack2(f[2], f[3]);
+            l2[0] = pack2(f[0] - bf16_round(f[0]), f[1] - bf16_round(f[1]));
+            l2[1] = pack2(f[2] - bf16_round(f[2]), f[3] - bf16_round(f[3]));
+            *reinterpret_cast<u32x2*>(hi + row * stride_ + ch * 4) = h2;
+            *reinterpret_cast<u32x2*>(lo + row * stride_ + ch * 4) = l2;
+        } else {
+            *reinterpret_cast<u32x4*>(hi + row * stride_ + ch * 8) = v;
+        }
+    };
+
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < G_N; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < BKM * G_CPR) store_tile(g_reg[i], G_hi, G_lo, idx / G_CPR, idx % G_CPR, GS);
+        }
+#pragma unroll
+        for (int i = 0; i < A_N; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < BKM * A_CPR) store_tile(a_reg[i], A_hi, A_lo, idx / A_CPR, idx % A_CPR, AS);
+        }
+    };
+
+    if (m_begin < m_end) load_stage(m_begin);
+    for (long mb = m_begin; mb < m_end; mb += BKM) {
+        store_stage();
+        __syncthreads();
+        if (mb + BKM < m_end) load_stage(mb + BKM);
+        if (active) {
+#pragma unroll
+            for (int kk = 0; kk < BKM / 16; ++kk) {
+                bf16x8 gh[Cfg::PM], gl[Cfg::PM], ah[Cfg::PN], al[Cfg::PN];
+#pragma unroll
+                for (int a = 0; a < Cfg::PM; ++a) {
+                    const int col = (wm * Cfg::PM + a) * 32;
+                    gh[a] = tr_frag(G_hi, GS, kk * 16, col, lane);
+                    if (PRECISE) gl[a] = tr_frag(G_lo, GS, kk * 16, col, lane);
+                }
+#pragma unroll
+                for (int b = 0; b < Cfg::PN; ++b) {
+                    const int col = (wn * Cfg::PN + b) * 32;
+                    ah[b] = tr_frag(A_hi, AS, kk * 16, col, lane);
+                    if (PRECISE) al[b] = tr_frag(A_lo, AS, kk * 16, col, lane);
+                }
+#pragma unroll
+                for (int a = 0; a < Cfg::PM; ++a)
+#pragma unroll
+                    for (int b = 0; b < Cfg::PN; ++b) {
+                        if (PRECISE) {
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl[a], ah[b], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[a], al[b], acc[a][b], 0, 0, 0);
+                        }
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[a], ah[b], acc[a][b], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: slab [z][Cout][taps][Cin] fp32 (row = co on registers, column = ci on lanes)
+    if (active) {
+        const int r = lane & 31, h = lane >> 5;
+        const long taps = (long)p.KH * p.KW;
+        float* slab = p.partial + (long)blockIdx.z * p.Cout * taps * p.Cin;
+#pragma unroll
+        for (int a = 0; a < Cfg::PM; ++a)
+#pragma unroll
+            for (int b = 0; b < Cfg::PN; ++b) {
+                const int ci = ci0 + (wn * Cfg::PN + b) * 32 + r;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int co = co0 + (wm * Cfg::PM + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (co < p.Cout && ci < p.Cin) slab[((long)co * taps + tap) * p.Cin + ci] = acc[a][b][i];
+                }
+            }
+    }
+}
+
+// sum the slabs in order; emit nn.Conv2d layout [Cout][Cin_out][KH][KW] (Cin_out <= Cin: the stem's padded
+// im2col columns are dropped)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int slabs, int Cout, int Cin,
+                                                           int Cin_out, int KH, int KW, int im2col, float* __restrict__ gw) {
+    const long total = (long)Cout * Cin_out * KH * KW;
+    const long slab = (long)Cout * (im2col ? 1 : KH * KW) * Cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int kw = (int)(i % KW);
+        long t = i / KW;
+        const int kh = (int)(t % KH);
+        t /= KH;
+        const int ci = (int)(t % Cin_out);
+        const int co = (int)(t / Cin_out);
+        // source index in the packed layout
+        long src;
+        if (im2col) src = (long)co * Cin + ((long)kh * KW + kw) * Cin_out + ci;     // 1x1 conv over (kh, kw, ci) columns
+        else src = ((long)co * KH * KW + (long)kh * KW + kw) * Cin + ci;
+        double s = 0.0;
+        for (int z = 0; z < slabs; ++z) s += (double)partial[(long)z * slab + src];
+        gw[i] = (float)s;
+    }
+}
+
+template <int TM, int TN, bool PRECISE>
+static void wgrad_launch_t(const WgradArgs& a, int slabs, hipStream_t st) {
+    constexpr int GS = TM * 32 + 32, AS = TN * 32 + 32;
+    const size_t lds = (size_t)32 * (GS + AS) * 2 * (PRECISE ? 2 : 1);
+    dim3 grid((unsigned)(a.KH * a.KW * ((a.Cin + TN * 32 - 1) / (TN * 32))), (unsigned)((a.Cout + TM * 32 - 1) / (TM * 32)),
+              (unsigned)slabs);
+    hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, PRECISE>), grid, dim3(256), lds, st, a);
+}
+
+int wgrad_slabs(const WgradArgs& a) {
+    const int tm = a.Cout >= 128 ? 4 : (a.Cout >= 64 ? 2 : 1);
+    const int tn = (a.Cin % 128 == 0) ? 4 : 1;
+    const long tiles = (long)a.KH * a.KW * ((a.Cin + tn * 32 - 1) / (tn * 32)) * ((a.Cout + tm * 32 - 1) / (tm * 32));
+    const long M = (long)a.N * a.Ho * a.Wo;
+    long s = (1024 + tiles - 1) / tiles;                   // aim at >= ~1024 workgroups
+    const long max_s = (M + 255) / 256;                     // at least 256 pixels per slab
+    if (s > max_s) s = max_s;
+    if (s > 256) s = 256;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+hipError_t launch_wgrad(const WgradArgs& a, int precise, int slabs, hipStream_t st) {
+    const int tm = a.Cout >= 128 ? 4 : (a.Cout >= 64 ? 2 : 1);
+    const int tn = (a.Cin % 128 == 0) ? 4 : 1;
+#define WG_CASE(TM_, TN_)                                               \
+    if (tm == TM_ && tn == TN_) {                                       \
+        if (precise) wgrad_launch_t<TM_, TN_, true>(a, slabs, st);      \
+        else wgrad_launch_t<TM_, TN_, false>(a, slabs, st);             \
+    }
+    WG_CASE(4, 4) WG_CASE(4, 1) WG_CASE(2, 4) WG_CASE(2, 1) WG_CASE(1, 4) WG_CASE(1, 1)
+#undef WG_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_wgrad_reduce(const float* partial, int slabs, int Cout, int Cin, int Cin_out, int KH, int KW, int im2col,
+                               float* gw, hipStream_t st) {
+    const long total = (long)Cout * Cin_out * KH * KW;
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, partial, slabs, Cout, Cin, Cin_out, KH, KW,
+                       im2col, gw);
+    return hipGetLastError();
+}
+
+}  // namespace vqseg

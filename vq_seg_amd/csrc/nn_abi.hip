@@ -1,0 +1,188 @@
+// nn_abi.hip -- extern "C" entry points for the convolution / batch-norm / resampling kernels
+// (declared in include/vqseg.h).  Validation + launch only: no allocation, no synchronisation.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vqseg.h"
+#include "conv_kernels.h"
+#include "nn_kernels.h"
+
+extern "C" int vqseg_set_error(int code, const char* msg);   // vqseg_abi.hip
+
+namespace {
+int bad(const char* msg) { return vqseg_set_error(VQSEG_EINVAL, msg); }
+int hipfail(hipError_t e, const char* where) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: %s", where, hipGetErrorString(e));
+    return vqseg_set_error((int)e, buf);
+}
+bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+int conv_wm(int cout) { return cout >= 64 ? 2 : 4; }
+int conv_rows_per_slot(int cout) { return cout >= 64 ? 64 : 32; }
+}  // namespace
+
+extern "C" {
+
+size_t vqseg_conv_packed_elems(int cout, int cin, int kh, int kw, int transpose_flip) {
+    if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return 0;
+    return vqseg::packed_elems(cout, cin, kh, kw, transpose_flip);
+}
+
+int vqseg_conv_pack_weights_f32(const float* w, int cout, int cin, int kh, int kw, int transpose_flip, void* hi, void* lo,
+                                void* stream) {
+    if (!w || !hi || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return bad("conv_pack_weights: bad argument");
+    hipError_t e = vqseg::launch_pack_weights(w, cout, cin, kh, kw, transpose_flip, static_cast<unsigned short*>(hi),
+                                              static_cast<unsigned short*>(lo), static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "conv_pack_weights");
+}
+
+int64_t vqseg_conv_stat_slots(int64_t m_rows, int cout) {
+    if (m_rows <= 0 || cout <= 0) return 0;
+    return (m_rows + 127) / 128 * conv_wm(cout);
+}
+
+int vqseg_conv2d_f(const void* x, const void* x2, int c1, const void* w_hi, const void* w_lo, void* y, float* stat_partial,
+                   int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int reflect, int up, int ho,
+                   int wo, int precise, void* stream) {
+    if (!x || !w_hi || !y || (precise && !w_lo)) return bad("conv2d: null pointer");
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || ho <= 0 || wo <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || up <= 0)
+        return bad("conv2d: non-positive dimension");
+    const int epc = precise ? 4 : 8;                       // channels per 16-byte activation chunk
+    if (cin % epc) return bad(precise ? "conv2d: Cin must be a multiple of 4" : "conv2d: Cin must be a multiple of 8 in bf16 mode");
+    if (c1 <= 0 || c1 > cin || (c1 < cin && (!x2 || c1 % epc || (cin - c1) % epc))) return bad("conv2d: bad channel split");
+    if (!a16(x) || !a16(x2) || !a16(w_hi) || !a16(w_lo) || !a16(y)) return bad("conv2d: pointers must be 16-byte aligned");
+    if (reflect && (pad >= h * up || pad >= w * up)) return bad("conv2d: reflect padding needs pad < size");
+    vqseg::ConvArgs a;
+    a.x = x; a.x2 = x2; a.C1 = c1;
+    a.w_hi = static_cast<const unsigned short*>(w_hi);
+    a.w_lo = static_cast<const unsigned short*>(w_lo);
+    a.y = y; a.stat_partial = stat_partial;
+    a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Ho = ho; a.Wo = wo; a.Cout = cout; a.KH = kh; a.KW = kw;
+    a.stride = stride; a.pad = pad; a.reflect = reflect; a.up = up;
+    hipError_t e = vqseg::launch_conv(a, precise, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "conv_igemm_kernel");
+}
+
+size_t vqseg_conv2d_wgrad_workspace_bytes(int n, int h, int w, int cin, int ho, int wo, int cout, int kh, int kw) {
+    if (n <= 0 || cin <= 0 || cout <= 0) return 0;
+    vqseg::WgradArgs a{};
+    a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Ho = ho; a.Wo = wo; a.Cout = cout; a.KH = kh; a.KW = kw;
+    return (size_t)vqseg::wgrad_slabs(a) * cout * kh * kw * cin * sizeof(float);
+}
+
+int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, int n, int h, int w, int cin, int ho, int wo,
+                         int cout, int kh, int kw, int stride, int pad, int reflect, int precise, int cin_out, int im2col,
+                         void* workspace, size_t workspace_bytes, float* gw, void* stream) {
+    if (!gy || !x || !workspace || !gw) return bad("conv2d_wgrad: null pointer");
+    const int epc = precise ? 4 : 8;
+    if (cin % epc || cout % epc) return bad("conv2d_wgrad: Cin and Cout must be multiples of 4 (f32) / 8 (bf16)");
+    if (c1 <= 0 || c1 > cin || (c1 < cin && (!x2 || c1 % epc || (cin - c1) % epc))) return bad("conv2d_wgrad: bad channel split");
+    vqseg::WgradArgs a;
+    const int kkh = im2col ? 1 : kh, kkw = im2col ? 1 : kw;     // a patch matrix is convolved 1x1
+    a.gy = gy; a.x = x; a.x2 = x2; a.C1 = c1; a.partial = static_cast<float*>(workspace);
+    a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Ho = ho; a.Wo = wo; a.Cout = cout; a.KH = kkh; a.KW = kkw;
+    a.stride = stride; a.pad = pad; a.reflect = reflect;
+    const int slabs = vqseg::wgrad_slabs(a);
+    if (workspace_bytes < (size_t)slabs * cout * kkh * kkw * cin * sizeof(float)) return vqseg_set_error(VQSEG_ENOSPC, "conv2d_wgrad: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = vqseg::launch_wgrad(a, precise, slabs, st);
+    if (e != hipSuccess) return hipfail(e, "conv_wgrad_kernel");
+    if (im2col) e = vqseg::launch_wgrad_reduce(a.partial, slabs, cout, cin, cin_out, kh, kw, 1, gw, st);   // kh,kw = ORIGINAL taps here
+    else e = vqseg::launch_wgrad_reduce(a.partial, slabs, cout, cin, cin_out, kh, kw, 0, gw, st);
+    return e == hipSuccess ? 0 : hipfail(e, "wgrad_reduce_kernel");
+}
+
+int vqseg_bn_finalize_f(const float* partial, int64_t m_rows, int c, const float* gamma, const float* beta, float* run_mean,
+                        float* run_var, float momentum, float eps, int training, float* scale, float* shift, float* save_mean,
+                        float* save_invstd, void* stream) {
+    if (!gamma || !beta || !scale || !shift || !save_mean || !save_invstd || c <= 0 || m_rows <= 0) return bad("bn_finalize: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (training) {
+        if (!partial) return bad("bn_finalize: training mode needs the conv epilogue partials");
+        e = vqseg::launch_bn_finalize(partial, vqseg_conv_stat_slots(m_rows, c), conv_rows_per_slot(c), m_rows, c, gamma, beta,
+                                      run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd, st);
+    } else {
+        if (!run_mean || !run_var) return bad("bn_finalize: eval mode needs running statistics");
+        e = vqseg::launch_bn_eval_coeffs(c, gamma, beta, run_mean, run_var, eps, scale, shift, save_mean, save_invstd, st);
+    }
+    return e == hipSuccess ? 0 : hipfail(e, "bn_finalize");
+}
+
+int vqseg_bn_apply_f(int bf16, const void* y, const void* res, const float* scale, const float* shift, int64_t m_rows, int c,
+                     int relu, void* out, void* stream) {
+    if (!y || !scale || !shift || !out || c % 4 || m_rows <= 0) return bad("bn_apply: bad argument");
+    hipError_t e = vqseg::launch_bn_apply(bf16, y, res, scale, shift, m_rows, c, relu, out, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "bn_apply_kernel");
+}
+
+size_t vqseg_bn_backward_workspace_floats(int64_t m_rows, int c) {
+    if (m_rows <= 0 || c <= 0) return 0;
+    return (size_t)vqseg::bn_bwd_blocks(m_rows) * 2 * c + 3 * (size_t)c;
+}
+
+int vqseg_bn_backward_f(int bf16, const void* g_out, const void* out, const void* y, const float* mean, const float* invstd,
+                        const float* gamma, int64_t m_rows, int c, int relu, int training, float* workspace, float* dgamma,
+                        float* dbeta, void* g_y, void* g_res, void* stream) {
+    if (!g_out || !y || !mean || !invstd || !gamma || !workspace || !dgamma || !dbeta || !g_y || (relu && !out)) return bad("bn_backward: null pointer");
+    if (c % 4 || (c > 256 && c % 256)) return bad("bn_backward: unsupported channel count");
+    float* partial = workspace;
+    float* coef = workspace + (size_t)vqseg::bn_bwd_blocks(m_rows) * 2 * c;
+    hipError_t e = vqseg::launch_bn_backward(bf16, g_out, out, y, mean, invstd, gamma, m_rows, c, relu, training, partial, coef,
+                                             dgamma, dbeta, g_y, g_res, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "bn_backward");
+}
+
+int vqseg_maxpool3x3s2_f(int bf16, int backward, const void* x, const void* g, int n, int h, int w, int c, void* out, void* stream) {
+    if (!x || !out || (backward && !g)) return bad("maxpool: null pointer");
+    hipError_t e = vqseg::launch_maxpool(bf16, backward, x, g, n, h, w, c, out, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "maxpool");
+}
+
+int vqseg_bilinear_f(int bf16, int backward, const void* src, int n, int h, int w, int c, int ho, int wo, int align_corners,
+                     void* dst, void* stream) {
+    if (!src || !dst || n <= 0 || h <= 0 || w <= 0 || c <= 0 || ho <= 0 || wo <= 0) return bad("bilinear: bad argument");
+    hipError_t e = vqseg::launch_bilinear(bf16, backward, src, n, h, w, c, ho, wo, align_corners, dst, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "bilinear");
+}
+
+int vqseg_head1x1_forward_f(int bf16, const void* x, const float* w, int64_t m_rows, int cin, int cout, float* y, void* stream) {
+    if (!x || !w || !y || cout > 4 || cout <= 0 || cin <= 0) return bad("head1x1: bad argument (Cout <= 4)");
+    hipError_t e = vqseg::launch_head_fwd(bf16, x, w, m_rows, cin, cout, y, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "head_fwd_kernel");
+}
+
+size_t vqseg_head1x1_backward_workspace_floats(int64_t m_rows, int cin, int cout) {
+    return (size_t)vqseg::head_bwd_blocks(m_rows) * cin * cout;
+}
+
+int vqseg_head1x1_backward_f(int bf16, const void* x, const float* w, const float* g, int64_t m_rows, int cin, int cout, void* gx,
+                             float* gw, float* workspace, void* stream) {
+    if (!x || !w || !g || !gx || !gw || !workspace || cout > 4 || cin * cout > 256) return bad("head1x1 backward: bad argument");
+    hipError_t e = vqseg::launch_head_bwd(bf16, x, w, g, m_rows, cin, cout, gx, gw, workspace, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "head_bwd");
+}
+
+int vqseg_im2col_f(int out_bf16, const float* x, int n, int h, int w, int cin, int kh, int kw, int stride, int pad, int reflect,
+                   int ho, int wo, int kp, void* out, void* stream) {
+    if (!x || !out || kp < kh * kw * cin) return bad("im2col: bad argument");
+    hipError_t e = vqseg::launch_im2col_stem(out_bf16, x, n, h, w, cin, kh, kw, stride, pad, reflect, ho, wo, kp, out,
+                                             static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "im2col_stem_kernel");
+}
+
+int vqseg_reflect_fold_f(int bf16, const void* gp, int n, int h, int w, int c, void* gx, void* stream) {
+    if (!gp || !gx || h < 2 || w < 2) return bad("reflect_fold: bad argument");
+    hipError_t e = vqseg::launch_reflect_fold(bf16, gp, n, h, w, c, gx, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "reflect_fold_kernel");
+}
+
+int vqseg_cast_f(int to_bf16, const void* x, int64_t n, void* y, void* stream) {
+    if (!x || !y || n <= 0) return bad("cast: bad argument");
+    hipError_t e = vqseg::launch_cast(to_bf16, x, n, y, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "cast_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// Internal declarations of the HBM-bound NN kernels (nn_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace vqseg {
+
+hipError_t launch_bn_finalize(const float* partial, long n_slots, int rows_per_slot, long M, int C, const float* gamma,
+                              const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
+                              float* shift, float* save_mean, float* save_invstd, hipStream_t st);
+hipError_t launch_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var,
+                                 float eps, float* scale, float* shift, float* save_mean, float* save_invstd, hipStream_t st);
+hipError_t launch_bn_apply(int bf16, const void* y, const void* res, const float* scale, const float* shift, long M, int C,
+                           int relu, void* out, hipStream_t st);
+long bn_bwd_blocks(long M);
+hipError_t launch_bn_backward(int bf16, const void* g_out, const void* out, const void* y, const float* mean,
+                              const float* invstd, const float* gamma, long M, int C, int relu, int training, float* partial,
+                              float* coef, float* dgamma, float* dbeta, void* g_y, void* g_res, hipStream_t st);
+hipError_t launch_maxpool(int bf16, int backward, const void* x, const void* g, int N, int H, int W, int C, void* out,
+                          hipStream_t st);
+hipError_t launch_bilinear(int bf16, int backward, const void* src, int N, int H, int W, int C, int Ho, int Wo, int align,
+                           void* dst, hipStream_t st);
+hipError_t launch_head_fwd(int bf16, const void* x, const float* w, long M, int Cin, int Cout, float* y, hipStream_t st);
+long head_bwd_blocks(long M);
+hipError_t launch_head_bwd(int bf16, const void* x, const float* w, const float* g, long M, int Cin, int Cout, void* gx,
+                           float* gw, float* partial, hipStream_t st);
+hipError_t launch_reduce_partials(const float* partial, long n_blocks, long n, float* out, hipStream_t st);
+hipError_t launch_im2col_stem(int out_bf16, const float* x, int N, int H, int W, int Cin, int KH, int KW, int stride, int pad,
+                              int reflect, int Ho, int Wo, int Kp, void* out, hipStream_t st);
+hipError_t launch_reflect_fold(int bf16, const void* gp, int N, int H, int W, int C, void* gx, hipStream_t st);
+hipError_t launch_cast(int to_bf16, const void* x, long n, void* y, hipStream_t st);
+
+}  // namespace vqseg

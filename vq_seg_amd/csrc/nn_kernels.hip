@@ -1,0 +1,646 @@
+// nn_kernels.hip -- HBM-bound companions of the convolution kernel (gfx950): batch-norm statistics /
+// apply / backward, ReLU + residual fusion, 3x3 stride-2 max-pool, bilinear resampling (both corner
+// conventions), the 1x1 segmentation head, stem im2col, reflect-padding gradient fold, dtype casts.
+//
+// Reference ops: nn.BatchNorm2d + nn.ReLU inside conv_bn_relu (models/networks/unet/decoder.py:7-10) and
+// the ResNet blocks; F.interpolate(mode='bilinear') (decoder.py:35, align_corners=False);
+// nn.UpsamplingBilinear2d (modified_vqunet/net.py:1172, align_corners=True); nn.MaxPool2d(3,2,1)
+// (models/encoders/resnet.py:167); the 1x1 head conv (net.py:1169).
+// All tensors are NHWC "rows" (pixel-major, channels contiguous).  T = float (precise mode) or __bf16.
+// Reductions are two-level with fixed order (no float atomics): results are run-to-run deterministic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nn_kernels.h"
+
+namespace vqseg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ float ld(const T* p, long i) { return (float)p[i]; }
+template <typename T>
+__device__ __forceinline__ void st(T* p, long i, float v) { p[i] = (T)v; }
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm forward statistics
+// ---------------------------------------------------------------------------------------------
+// Merge the per-wave partials (mean_s, M2_s over rows_per_slot rows) written by the conv epilogue:
+//   mean = sum n_s mean_s / M ;  M2 = sum (M2_s + n_s (mean_s - mean)^2)      (double, fixed tree order)
+// then scale = gamma * invstd, shift = beta - mean * scale, running-stat update (nn.BatchNorm2d: biased var
+// for normalisation, unbiased for running_var).  One block per channel.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, long n_slots, int rows_per_slot,
+                                                          long M, int C, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                          float* __restrict__ run_var, float momentum, float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    const int c = blockIdx.x;
+    __shared__ double red[256];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n_slots; i += 256) {
+        long n = M - i * rows_per_slot;
+        n = n < 0 ? 0 : (n > rows_per_slot ? rows_per_slot : n);
+        s += (double)n * (double)partial[(i * 2 + 0) * C + c];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    const double mean = red[0] / (double)M;
+    __syncthreads();
+    double q = 0.0;
+    for (long i = threadIdx.x; i < n_slots; i += 256) {
+        long n = M - i * rows_per_slot;
+        n = n < 0 ? 0 : (n > rows_per_slot ? rows_per_slot : n);
+        const double d = (double)partial[(i * 2 + 0) * C + c] - mean;
+        q += (double)partial[(i * 2 + 1) * C + c] + (double)n * d * d;
+    }
+    red[threadIdx.x] = q;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double var = red[0] / (double)M;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        save_mean[c] = (float)mean;
+        save_invstd[c] = invstd;
+        if (run_mean) {
+            const double unbiased = M > 1 ? red[0] / (double)(M - 1) : var;
+            run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
+            run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+// eval mode: scale/shift from the running statistics
+__global__ __launch_bounds__(256) void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                                             float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                             float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.0f / sqrtf(run_var[c] + eps);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - run_mean[c] * sc;
+    save_mean[c] = run_mean[c];
+    save_invstd[c] = invstd;
+}
+
+// out = [relu]( y * scale[c] + shift[c] [+ res] )
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       long M, int C, int relu, T* __restrict__ out) {
+    const long total = M * C;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 256 * 4) {
+        const int c = (int)(i % C);                       // C % 4 == 0: the 4 elements share a row
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = ld(y, i + e) * scale[c + e] + shift[c + e];
+            if (res) v += ld(res, i + e);
+            if (relu) v = v > 0.0f ? v : 0.0f;
+            st(out, i + e, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm backward (through the fused ReLU / residual):  gz = g_out * (out > 0)
+//   partial[blk][0][c] = sum gz,   partial[blk][1][c] = sum gz * xhat,   xhat = (y - mean) * invstd
+// ---------------------------------------------------------------------------------------------
+constexpr int BNB_ROWS = 128;      // rows per block of the reduce kernel
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ g_out, const T* __restrict__ out,
+                                                            const T* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, long M, int C, int relu,
+                                                            float* __restrict__ partial) {
+    // thread -> channel c = threadIdx.x % Cw (+ k * Cw), row lane = threadIdx.x / Cw, Cw = min(C, 256)
+    const int Cw = C < 256 ? C : 256;
+    const int lanes = 256 / Cw;                            // threads beyond lanes * Cw idle (C need not divide 256)
+    const int rl = threadIdx.x / Cw;
+    const bool live = rl < lanes;
+    const long row0 = (long)blockIdx.x * BNB_ROWS;
+    extern __shared__ float sh[];                          // [lanes][2][Cw]
+    for (int cb = 0; cb < C; cb += Cw) {
+        const int c = cb + threadIdx.x % Cw;
+        float s0 = 0.0f, s1 = 0.0f;
+        const float mu = mean[c], is = invstd[c];
+        for (int rr = rl; live && rr < BNB_ROWS; rr += lanes) {
+            const long m = row0 + rr;
+            if (m < M) {
+                float g = ld(g_out, m * C + c);
+                if (relu && !(ld(out, m * C + c) > 0.0f)) g = 0.0f;
+                s0 += g;
+                s1 += g * ((ld(y, m * C + c) - mu) * is);
+            }
+        }
+        if (live) {
+            sh[(rl * 2 + 0) * Cw + threadIdx.x % Cw] = s0;
+            sh[(rl * 2 + 1) * Cw + threadIdx.x % Cw] = s1;
+        }
+        __syncthreads();
+        if (rl == 0) {
+            float a = 0.0f, b = 0.0f;
+            for (int l = 0; l < lanes; ++l) {
+                a += sh[(l * 2 + 0) * Cw + threadIdx.x];
+                b += sh[(l * 2 + 1) * Cw + threadIdx.x];
+            }
+            partial[((long)blockIdx.x * 2 + 0) * C + c] = a;
+            partial[((long)blockIdx.x * 2 + 1) * C + c] = b;
+        }
+        __syncthreads();
+    }
+}
+
+// dgamma = sum gz*xhat, dbeta = sum gz; coefficients of the apply pass:
+//   train: g_y = k0[c] * (gz - k1[c] - xhat * k2[c]),  k0 = gamma*invstd, k1 = mean(gz), k2 = mean(gz*xhat)
+//   eval : g_y = k0[c] * gz
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, long n_blocks, long M, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                              int training, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef) {
+    const int c = blockIdx.x;
+    __shared__ double r0[256], r1[256];
+    double a = 0.0, b = 0.0;
+    for (long i = threadIdx.x; i < n_blocks; i += 256) {
+        a += (double)partial[(i * 2 + 0) * C + c];
+        b += (double)partial[(i * 2 + 1) * C + c];
+    }
+    r0[threadIdx.x] = a;
+    r1[threadIdx.x] = b;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) {
+            r0[threadIdx.x] += r0[threadIdx.x + m];
+            r1[threadIdx.x] += r1[threadIdx.x + m];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        dbeta[c] = (float)r0[0];
+        dgamma[c] = (float)r1[0];
+        coef[0 * C + c] = gamma[c] * invstd[c];
+        coef[1 * C + c] = training ? (float)(r0[0] / (double)M) : 0.0f;
+        coef[2 * C + c] = training ? (float)(r1[0] / (double)M) : 0.0f;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ g_out, const T* __restrict__ out,
+                                                           const T* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                           long M, int C, int relu, T* __restrict__ g_y, T* __restrict__ g_res) {
+    const long total = M * C;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 256 * 4) {
+        const int c = (int)(i % C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float g = ld(g_out, i + e);
+            if (relu && !(ld(out, i + e) > 0.0f)) g = 0.0f;
+            const float xh = (ld(y, i + e) - mean[c + e]) * invstd[c + e];
+            st(g_y, i + e, coef[c + e] * (g - coef[C + c + e] - xh * coef[2 * C + c + e]));
+            if (g_res) st(g_res, i + e, g);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// max-pool 3x3 stride 2 pad 1 (NHWC).  Backward recomputes the arg-max (first maximum in window scan
+// order kh, kw -- the order ATen's max_pool2d uses) and gathers: deterministic, no atomics.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C, int Ho, int Wo,
+                                                          T* __restrict__ y) {
+    const long total = (long)N * Ho * Wo * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int ow = (int)(t % Wo);
+        t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float best = -__builtin_inff();
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            if (ih < 0 || ih >= H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                if (iw < 0 || iw >= W) continue;
+                const float v = ld(x, (((long)n * H + ih) * W + iw) * C + c);
+                if (v > best || v != v) best = v;
+            }
+        }
+        st(y, i, best);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, int N, int H, int W,
+                                                          int C, int Ho, int Wo, T* __restrict__ gx) {
+    const long total = (long)N * H * W * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int iw = (int)(t % W);
+        t /= W;
+        const int ih = (int)(t % H);
+        const int n = (int)(t / H);
+        float acc = 0.0f;
+        // output windows that contain (ih, iw): oh in [(ih-1)/2 .. (ih+1)/2]
+        for (int oh = (ih - 1 + 1) / 2; oh <= (ih + 1) / 2 && oh < Ho; ++oh) {
+            if (oh < 0 || ih < oh * 2 - 1 || ih > oh * 2 + 1) continue;
+            for (int ow = (iw - 1 + 1) / 2; ow <= (iw + 1) / 2 && ow < Wo; ++ow) {
+                if (ow < 0 || iw < ow * 2 - 1 || iw > ow * 2 + 1) continue;
+                // arg-max of this window (first maximum in scan order)
+                float best = -__builtin_inff();
+                int bh = -1, bw = -1;
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int jh = oh * 2 - 1 + kh;
+                    if (jh < 0 || jh >= H) continue;
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int jw = ow * 2 - 1 + kw;
+                        if (jw < 0 || jw >= W) continue;
+                        const float v = ld(x, (((long)n * H + jh) * W + jw) * C + c);
+                        if (v > best || v != v) {
+                            best = v;
+                            bh = jh;
+                            bw = jw;
+                        }
+                    }
+                }
+                if (bh == ih && bw == iw) acc += ld(g, (((long)n * Ho + oh) * Wo + ow) * C + c);
+            }
+        }
+        st(gx, i, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bilinear resize (NHWC), both corner conventions (ATen upsample_bilinear2d semantics)
+//   align_corners: src = dst * (in-1)/(out-1);  else src = max((dst+0.5)*in/out - 0.5, 0)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bil_src(int d, int in, int out, int align, int& i0, int& i1, float& l1) {
+    float s;
+    if (align) s = out > 1 ? (float)d * ((float)(in - 1) / (float)(out - 1)) : 0.0f;
+    else {
+        s = ((float)d + 0.5f) * ((float)in / (float)out) - 0.5f;
+        if (s < 0.0f) s = 0.0f;
+    }
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C, int Ho, int Wo,
+                                                           int align, T* __restrict__ y) {
+    const long total = (long)N * Ho * Wo * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int ow = (int)(t % Wo);
+        t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        int h0, h1, w0, w1;
+        float lh, lw;
+        bil_src(oh, H, Ho, align, h0, h1, lh);
+        bil_src(ow, W, Wo, align, w0, w1, lw);
+        const long b = (long)n * H;
+        const float v00 = ld(x, ((b + h0) * W + w0) * C + c), v01 = ld(x, ((b + h0) * W + w1) * C + c);
+        const float v10 = ld(x, ((b + h1) * W + w0) * C + c), v11 = ld(x, ((b + h1) * W + w1) * C + c);
+        st(y, i, (1.0f - lh) * ((1.0f - lw) * v00 + lw * v01) + lh * ((1.0f - lw) * v10 + lw * v11));
+    }
+}
+
+// backward as a gather over the (few) output pixels whose footprint touches the input pixel
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ g, int N, int H, int W, int C, int Ho, int Wo,
+                                                           int align, T* __restrict__ gx) {
+    const long total = (long)N * H * W * C;
+    const int rh = (Ho + H - 1) / H + 1, rw = (Wo + W - 1) / W + 1;       // search radius in output pixels
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int iw = (int)(t % W);
+        t /= W;
+        const int ih = (int)(t % H);
+        const int n = (int)(t / H);
+        const int ohc = (int)(((long)ih * Ho) / H), owc = (int)(((long)iw * Wo) / W);
+        float acc = 0.0f;
+        for (int oh = ohc - rh; oh <= ohc + rh; ++oh) {
+            if (oh < 0 || oh >= Ho) continue;
+            int h0, h1;
+            float lh;
+            bil_src(oh, H, Ho, align, h0, h1, lh);
+            float wh = 0.0f;
+            if (h0 == ih) wh += 1.0f - lh;
+            if (h1 == ih) wh += lh;
+            if (wh == 0.0f) continue;
+            for (int ow = owc - rw; ow <= owc + rw; ++ow) {
+                if (ow < 0 || ow >= Wo) continue;
+                int w0, w1;
+                float lw;
+                bil_src(ow, W, Wo, align, w0, w1, lw);
+                float ww = 0.0f;
+                if (w0 == iw) ww += 1.0f - lw;
+                if (w1 == iw) ww += lw;
+                if (ww == 0.0f) continue;
+                acc += wh * ww * ld(g, (((long)n * Ho + oh) * Wo + ow) * C + c);
+            }
+        }
+        st(gx, i, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 segmentation head (Cin <= 64 -> Cout <= 4, no bias): forward, data gradient, weight gradient
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, long M, int Cin,
+                                                       int Cout, float* __restrict__ y) {
+    for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < Cin; ++c) {
+            const float v = ld(x, m * Cin + c);
+            for (int o = 0; o < Cout; ++o) acc[o] = __builtin_fmaf(v, w[o * Cin + c], acc[o]);
+        }
+        for (int o = 0; o < Cout; ++o) y[m * Cout + o] = acc[o];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restrict__ g, const float* __restrict__ w, long M,
+                                                            int Cin, int Cout, T* __restrict__ gx) {
+    const long total = M * Cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % Cin);
+        const long m = i / Cin;
+        float acc = 0.0f;
+        for (int o = 0; o < Cout; ++o) acc = __builtin_fmaf(g[m * Cout + o], w[o * Cin + c], acc);
+        st(gx, i, acc);
+    }
+}
+
+constexpr int HEAD_ROWS = 1024;
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_weight_kernel(const T* __restrict__ x, const float* __restrict__ g, long M, int Cin,
+                                                              int Cout, float* __restrict__ partial) {
+    // block -> HEAD_ROWS rows; thread -> (o, c) pairs over a row slice; partial[blk][Cout*Cin]
+    const int pairs = Cin * Cout;
+    const long row0 = (long)blockIdx.x * HEAD_ROWS;
+    __shared__ float sh[256];
+    const int slices = 256 / pairs > 0 ? 256 / pairs : 1;
+    const int pr = threadIdx.x % pairs, sl = threadIdx.x / pairs;
+    float acc = 0.0f;
+    if (sl < slices) {
+        const int o = pr / Cin, c = pr % Cin;
+        for (long m = row0 + sl; m < row0 + HEAD_ROWS && m < M; m += slices) acc = __builtin_fmaf(g[m * Cout + o], ld(x, m * Cin + c), acc);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < pairs) {
+        float s = 0.0f;
+        for (int l = 0; l < slices; ++l) s += sh[l * pairs + threadIdx.x];
+        partial[(long)blockIdx.x * pairs + threadIdx.x] = s;
+    }
+}
+
+// sum partial[blk][n] over blk in fixed order -> out[n] (double accumulate)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, long n_blocks, long n,
+                                                              float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (long b = 0; b < n_blocks; ++b) s += (double)partial[b * n + i];
+    out[i] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stem im2col: x [N,H,W,3] -> rows [N*Ho*Wo][Kp] with the 7x7x3 patch (kh, kw, ci order), stride 2, pad 3
+// (zero or reflect), columns >= 147 zero.  The stem then runs as a 1x1 convolution with Cin = Kp.
+// ---------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void im2col_stem_kernel(const TI* __restrict__ x, int N, int H, int W, int Cin, int KH, int KW,
+                                                          int stride, int pad, int reflect, int Ho, int Wo, int Kp,
+                                                          TO* __restrict__ out) {
+    const long total = (long)N * Ho * Wo * Kp;
+    const int K = KH * KW * Cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % Kp);
+        long t = i / Kp;
+        const int ow = (int)(t % Wo);
+        t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float v = 0.0f;
+        if (k < K) {
+            const int ci = k % Cin, kw = (k / Cin) % KW, kh = k / (Cin * KW);
+            int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+            if (reflect) {
+                if (ih < 0) ih = -ih;
+                if (ih >= H) ih = 2 * H - 2 - ih;
+                if (iw < 0) iw = -iw;
+                if (iw >= W) iw = 2 * W - 2 - iw;
+            }
+            if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = (float)x[(((long)n * H + ih) * W + iw) * Cin + ci];
+        }
+        out[i] = (TO)v;
+    }
+}
+
+// gradient of reflect padding (pad 1): gp [N, H+2, W+2, C] -> gx [N, H, W, C]
+template <typename T>
+__global__ __launch_bounds__(256) void reflect_fold_kernel(const T* __restrict__ gp, int N, int H, int W, int C, T* __restrict__ gx) {
+    const long total = (long)N * H * W * C;
+    const int Hp = H + 2, Wp = W + 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        // padded rows mapping to h: h+1 always; 0 if h == 1; Hp-1 if h == H-2
+        int hs[3], ws[3], nh = 0, nw = 0;
+        hs[nh++] = h + 1;
+        if (h == 1) hs[nh++] = 0;
+        if (h == H - 2) hs[nh++] = Hp - 1;
+        ws[nw++] = w + 1;
+        if (w == 1) ws[nw++] = 0;
+        if (w == W - 2) ws[nw++] = Wp - 1;
+        float acc = 0.0f;
+        for (int a = 0; a < nh; ++a)
+            for (int b = 0; b < nw; ++b) acc += ld(gp, (((long)n * Hp + hs[a]) * Wp + ws[b]) * C + c);
+        st(gx, i, acc);
+    }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, long n, TO* __restrict__ y) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = (TO)(float)x[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline unsigned grid_for(long work, int per_block = 256, long cap = 8192) {
+    long b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+hipError_t launch_bn_finalize(const float* partial, long n_slots, int rows_per_slot, long M, int C, const float* gamma,
+                              const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
+                              float* shift, float* save_mean, float* save_invstd, hipStream_t st_) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st_, partial, n_slots, rows_per_slot, M, C, gamma, beta,
+                       run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd);
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var,
+                                 float eps, float* scale, float* shift, float* save_mean, float* save_invstd, hipStream_t st_) {
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, st_, C, gamma, beta, run_mean, run_var, eps,
+                       scale, shift, save_mean, save_invstd);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t bn_apply_t(const void* y, const void* res, const float* scale, const float* shift, long M, int C, int relu,
+                             void* out, hipStream_t st_) {
+    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(M * C / 4)), dim3(256), 0, st_, (const T*)y, (const T*)res, scale, shift, M,
+                       C, relu, (T*)out);
+    return hipGetLastError();
+}
+hipError_t launch_bn_apply(int bf16, const void* y, const void* res, const float* scale, const float* shift, long M, int C,
+                           int relu, void* out, hipStream_t st_) {
+    return bf16 ? bn_apply_t<__bf16>(y, res, scale, shift, M, C, relu, out, st_)
+                : bn_apply_t<float>(y, res, scale, shift, M, C, relu, out, st_);
+}
+
+long bn_bwd_blocks(long M) { return (M + BNB_ROWS - 1) / BNB_ROWS; }
+
+template <typename T>
+static hipError_t bn_bwd_t(const void* g_out, const void* out, const void* y, const float* mean, const float* invstd,
+                           const float* gamma, long M, int C, int relu, int training, float* partial, float* coef,
+                           float* dgamma, float* dbeta, void* g_y, void* g_res, hipStream_t st_) {
+    const long nb = bn_bwd_blocks(M);
+    const int Cw = C < 256 ? C : 256;
+    const size_t lds = (size_t)(256 / Cw) * 2 * Cw * sizeof(float);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3((unsigned)nb), dim3(256), lds, st_, (const T*)g_out, (const T*)out,
+                       (const T*)y, mean, invstd, M, C, relu, partial);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st_, partial, nb, M, C, gamma, invstd, training, dgamma,
+                       dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(M * C / 4)), dim3(256), 0, st_, (const T*)g_out, (const T*)out,
+                       (const T*)y, mean, invstd, coef, M, C, relu, (T*)g_y, (T*)g_res);
+    return hipGetLastError();
+}
+hipError_t launch_bn_backward(int bf16, const void* g_out, const void* out, const void* y, const float* mean,
+                              const float* invstd, const float* gamma, long M, int C, int relu, int training, float* partial,
+                              float* coef, float* dgamma, float* dbeta, void* g_y, void* g_res, hipStream_t st_) {
+    return bf16 ? bn_bwd_t<__bf16>(g_out, out, y, mean, invstd, gamma, M, C, relu, training, partial, coef, dgamma, dbeta, g_y,
+                                   g_res, st_)
+                : bn_bwd_t<float>(g_out, out, y, mean, invstd, gamma, M, C, relu, training, partial, coef, dgamma, dbeta, g_y,
+                                  g_res, st_);
+}
+
+#define DISPATCH_T(bf16, CALL_F, CALL_B) \
+    do {                                 \
+        if (bf16) { CALL_B; } else { CALL_F; } \
+    } while (0)
+
+hipError_t launch_maxpool(int bf16, int backward, const void* x, const void* g, int N, int H, int W, int C, void* out,
+                          hipStream_t st_) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    if (!backward) {
+        const unsigned gr = grid_for((long)N * Ho * Wo * C);
+        DISPATCH_T(bf16, hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(gr), dim3(256), 0, st_, (const float*)x, N, H, W, C, Ho, Wo, (float*)out),
+                   hipLaunchKernelGGL(maxpool_fwd_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, (const __bf16*)x, N, H, W, C, Ho, Wo, (__bf16*)out));
+    } else {
+        const unsigned gr = grid_for((long)N * H * W * C);
+        DISPATCH_T(bf16, hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(gr), dim3(256), 0, st_, (const float*)x, (const float*)g, N, H, W, C, Ho, Wo, (float*)out),
+                   hipLaunchKernelGGL(maxpool_bwd_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, (const __bf16*)x, (const __bf16*)g, N, H, W, C, Ho, Wo, (__bf16*)out));
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_bilinear(int bf16, int backward, const void* src, int N, int H, int W, int C, int Ho, int Wo, int align,
+                           void* dst, hipStream_t st_) {
+    // forward: src [N,H,W,C] -> dst [N,Ho,Wo,C];  backward: src = grad [N,Ho,Wo,C] -> dst = grad_x [N,H,W,C]
+    if (!backward) {
+        const unsigned gr = grid_for((long)N * Ho * Wo * C);
+        DISPATCH_T(bf16, hipLaunchKernelGGL(bilinear_fwd_kernel<float>, dim3(gr), dim3(256), 0, st_, (const float*)src, N, H, W, C, Ho, Wo, align, (float*)dst),
+                   hipLaunchKernelGGL(bilinear_fwd_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, (const __bf16*)src, N, H, W, C, Ho, Wo, align, (__bf16*)dst));
+    } else {
+        const unsigned gr = grid_for((long)N * H * W * C);
+        DISPATCH_T(bf16, hipLaunchKernelGGL(bilinear_bwd_kernel<float>, dim3(gr), dim3(256), 0, st_, (const float*)src, N, H, W, C, Ho, Wo, align, (float*)dst),
+                   hipLaunchKernelGGL(bilinear_bwd_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, (const __bf16*)src, N, H, W, C, Ho, Wo, align, (__bf16*)dst));
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_head_fwd(int bf16, const void* x, const float* w, long M, int Cin, int Cout, float* y, hipStream_t st_) {
+    const unsigned gr = grid_for(M);
+    DISPATCH_T(bf16, hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(gr), dim3(256), 0, st_, (const float*)x, w, M, Cin, Cout, y),
+               hipLaunchKernelGGL(head_fwd_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, (const __bf16*)x, w, M, Cin, Cout, y));
+    return hipGetLastError();
+}
+
+long head_bwd_blocks(long M) { return (M + HEAD_ROWS - 1) / HEAD_ROWS; }
+
+hipError_t launch_head_bwd(int bf16, const void* x, const float* w, const float* g, long M, int Cin, int Cout, void* gx,
+                           float* gw, float* partial, hipStream_t st_) {
+    const unsigned gr = grid_for(M * Cin);
+    DISPATCH_T(bf16, hipLaunchKernelGGL(head_bwd_data_kernel<float>, dim3(gr), dim3(256), 0, st_, g, w, M, Cin, Cout, (float*)gx),
+               hipLaunchKernelGGL(head_bwd_data_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, g, w, M, Cin, Cout, (__bf16*)gx));
+    const long nb = head_bwd_blocks(M);
+    DISPATCH_T(bf16, hipLaunchKernelGGL(head_bwd_weight_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st_, (const float*)x, g, M, Cin, Cout, partial),
+               hipLaunchKernelGGL(head_bwd_weight_kernel<__bf16>, dim3((unsigned)nb), dim3(256), 0, st_, (const __bf16*)x, g, M, Cin, Cout, partial));
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, st_, partial, nb, (long)Cin * Cout, gw);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_partials(const float* partial, long n_blocks, long n, float* out, hipStream_t st_) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st_, partial, n_blocks, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_im2col_stem(int out_bf16, const float* x, int N, int H, int W, int Cin, int KH, int KW, int stride, int pad,
+                              int reflect, int Ho, int Wo, int Kp, void* out, hipStream_t st_) {
+    const unsigned gr = grid_for((long)N * Ho * Wo * Kp);
+    if (out_bf16)
+        hipLaunchKernelGGL((im2col_stem_kernel<float, __bf16>), dim3(gr), dim3(256), 0, st_, x, N, H, W, Cin, KH, KW, stride, pad,
+                           reflect, Ho, Wo, Kp, (__bf16*)out);
+    else
+        hipLaunchKernelGGL((im2col_stem_kernel<float, float>), dim3(gr), dim3(256), 0, st_, x, N, H, W, Cin, KH, KW, stride, pad,
+                           reflect, Ho, Wo, Kp, (float*)out);
+    return hipGetLastError();
+}
+
+hipError_t launch_reflect_fold(int bf16, const void* gp, int N, int H, int W, int C, void* gx, hipStream_t st_) {
+    const unsigned gr = grid_for((long)N * H * W * C);
+    DISPATCH_T(bf16, hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3(gr), dim3(256), 0, st_, (const float*)gp, N, H, W, C, (float*)gx),
+               hipLaunchKernelGGL(reflect_fold_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, (const __bf16*)gp, N, H, W, C, (__bf16*)gx));
+    return hipGetLastError();
+}
+
+hipError_t launch_cast(int to_bf16, const void* x, long n, void* y, hipStream_t st_) {
+    const unsigned gr = grid_for(n);
+    if (to_bf16) hipLaunchKernelGGL((cast_kernel<float, __bf16>), dim3(gr), dim3(256), 0, st_, (const float*)x, n, (__bf16*)y);
+    else hipLaunchKernelGGL((cast_kernel<__bf16, float>), dim3(gr), dim3(256), 0, st_, (const __bf16*)x, n, (float*)y);
+    return hipGetLastError();
+}
+
+}  // namespace vqseg

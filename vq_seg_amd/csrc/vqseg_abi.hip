@@ -34,6 +34,11 @@ int check_shape(int64_t n, int c, int k) {
 
 extern "C" {
 
+int vqseg_set_error(int code, const char* msg) {      // shared with nn_abi.hip (not part of the public header)
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
 int vqseg_abi_version(void) { return VQSEG_ABI_VERSION; }
 const char* vqseg_last_error(void) { return g_err; }
 

@@ -30,9 +30,9 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         idt = x
         if self.downsample is not None:
-            idt = nnf.conv_bn_act(x, self.downsample[0], self.downsample[1], self.training, relu=False)
-        y = nnf.conv_bn_act(x, self.conv1, self.bn1, self.training)
-        return nnf.conv_bn_act(y, self.conv2, self.bn2, self.training, relu=True, residual=idt)
+            idt = nnf.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+        y = nnf.conv_bn_act(x, self.conv1, self.bn1)
+        return nnf.conv_bn_act(y, self.conv2, self.bn2, relu=True, residual=idt)
 
 
 class Bottleneck(nn.Module):
@@ -54,10 +54,10 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         idt = x
         if self.downsample is not None:
-            idt = nnf.conv_bn_act(x, self.downsample[0], self.downsample[1], self.training, relu=False)
-        y = nnf.conv_bn_act(x, self.conv1, self.bn1, self.training)
-        y = nnf.conv_bn_act(y, self.conv2, self.bn2, self.training)
-        return nnf.conv_bn_act(y, self.conv3, self.bn3, self.training, relu=True, residual=idt)
+            idt = nnf.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+        y = nnf.conv_bn_act(x, self.conv1, self.bn1)
+        y = nnf.conv_bn_act(y, self.conv2, self.bn2)
+        return nnf.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=idt)
 
 
 resnet_encoders = {
@@ -111,7 +111,7 @@ class ResNetEncoder(nn.Module):
     def forward(self, x):
         """-> [x, stem (C64, /2), layer1 (/4), layer2 (/8), layer3 (/16), layer4 (/32)][: depth + 1]"""
         feats = [x]
-        y = nnf.conv_bn_act(x, self.conv1, self.bn1, self.training)
+        y = nnf.stem_conv_bn_act(x, self.conv1, self.bn1)
         feats.append(y)
         y = nnf.max_pool_3x3_s2(y)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):

@@ -15,8 +15,12 @@ class _Up(nn.Module):
 
 
 class _Conv(nn.Conv2d):
+    """3x3 conv WITH bias, 32 -> num_classes: only the plain `unet` plumbing model (BASELINE config #1, a CPU
+    wiring check in the reference) has this layer; it is not on the north-star path and stays an ATen call."""
+
     def forward(self, x):
-        return nnf.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0])
+        import torch.nn.functional as F
+        return F.conv2d(x.float(), self.weight, self.bias, self.stride, self.padding)
 
 
 class SegmentationHead(nn.Sequential):

@@ -34,7 +34,7 @@ class _Upsampling(nn.Module):
 
 class _Head1x1(nn.Conv2d):
     def forward(self, x):
-        return nnf.conv2d(x, self.weight, None, 1, 0)
+        return nnf.head_conv1x1(x, self.weight)
 
 
 class _VQRePTUnet1x1Base(nn.Module):

@@ -17,8 +17,8 @@ class ConvBNReLU(nn.Sequential):
         super().__init__(nn.Conv2d(in_channels, out_channels, kernel_size, padding=int((kernel_size - 1) / 2), bias=False),
                          nn.BatchNorm2d(out_channels), nn.ReLU())
 
-    def forward(self, x):
-        return _nnf.conv_bn_act(x, self[0], self[1], self.training, relu=True)
+    def forward(self, x, x2=None):
+        return _nnf.conv_bn_act(x, self[0], self[1], relu=True, x2=x2)
 
 
 def conv_bn_relu(in_channels: int, out_channels: int, kernel_size: int = 3):
@@ -41,10 +41,11 @@ class UnetDecoder(nn.Module):
         self.blocks = nn.ModuleList(blocks)
 
     def forward(self, *features):
-        feats = features[::-1]
-        cat = feats[0]
-        for i in range(len(self.blocks) - 1):
-            out = self.blocks[i](cat)
-            up = _nnf.upsample_bilinear(out, size=feats[i + 1].shape[-2:], align_corners=False)
-            cat = _nnf.concat_channels(up, feats[i + 1])
-        return self.blocks[-1](cat)
+        dt = features[0].dtype                                      # activation dtype of the un-quantised skips
+        feats = [_nnf.cast_act(f, dt) for f in features[::-1]]      # (the VQ layer always returns fp32, vq_img.py:229)
+        out = self.blocks[0][1](self.blocks[0][0](feats[0]))
+        for i in range(1, len(self.blocks)):
+            up = _nnf.upsample_bilinear(out, size=feats[i].shape[-2:], align_corners=False)
+            # torch.cat((up, skip), 1) of the reference (decoder.py:35-37) is fused into the conv loader
+            out = self.blocks[i][1](self.blocks[i][0](up, feats[i]))
+        return out

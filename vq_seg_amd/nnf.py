@@ -1,49 +1,379 @@
-"""Functional building blocks of the encoder/decoder (the calls the nn.Modules make).
+"""Functional building blocks of the encoder/decoder, executed by the gfx950 HIP kernels behind
+include/vqseg.h (conv_kernels.hip, nn_kernels.hip).  torch only owns memory and the autograd tape.
 
-Each function is the single implementation of its op for the accelerated path; tensors are
-channels_last (NHWC) on the device.  STATUS (round 1): the VQ layer runs on hand-written HIP
-kernels; the convolution / batch-norm / resampling ops below still enqueue PyTorch-ROCm
-(MIOpen / ATen) device kernels and are the next ops to move behind include/vqseg.h
-(DESIGN.md, section "Kernel inventory and status").  There is no CPU path here either way:
-the model refuses CPU tensors at its entry.
+Layout: activations are NHWC in memory ("channels_last" views of logically NCHW tensors).
+Precision follows the activation dtype: float32 -> "precise" kernels (bf16x3 split MFMA, fp32 storage;
+the parity mode), bfloat16 -> "fast" kernels (bf16 storage and operands, fp32 accumulate).
+
+Every function here has exactly one implementation; CPU tensors are refused (no fallback).
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
-import torch.nn.functional as F
+
+from . import _hip
+from ._hip import _check, _dev, _stream, lib
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, reflect=False):
-    """Conv2d with zero or reflect padding (nn.Conv2d(padding_mode=...) semantics)."""
-    if reflect and padding > 0:
-        x = F.pad(x, (padding, padding, padding, padding), mode="reflect")
-        padding = 0
-    return F.conv2d(x, weight, bias, stride=stride, padding=padding)
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
+def _rows(x: torch.Tensor) -> torch.Tensor:
+    """logical (N, C, H, W) -> contiguous (N, H, W, C) view (free for channels_last tensors)."""
+    v = x.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
 
 
-def batch_norm(x, bn, training):
-    return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
+def _nchw(rows: torch.Tensor) -> torch.Tensor:
+    return rows.permute(0, 3, 1, 2)
 
 
-def conv_bn_act(x, conv, bn, training, relu=True, residual=None):
-    """Conv (no bias) -> BatchNorm2d (batch statistics in training mode, running-stat update as
-    nn.BatchNorm2d) -> [+ residual] -> [ReLU]."""
-    y = conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0], conv.padding_mode == "reflect")
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    y = batch_norm(y, bn, training)
-    if residual is not None:
-        y = y + residual
-    return F.relu(y) if relu else y
+def _is_bf16(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return 1
+    if t.dtype == torch.float32:
+        return 0
+    raise _hip.HipLibraryError(f"activations must be float32 (precise mode) or bfloat16 (fast mode), got {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def act_dtype() -> torch.dtype:
+    """bf16 'fast' mode under torch.autocast (the reference trainer's `autocast(enabled=half)`,
+    train_vqreptunet1x1v2.py:151 -- fp16 there, bf16 here: the ROCm-native half type), else fp32."""
+    if torch.is_autocast_enabled():
+        return torch.bfloat16
+    return torch.float32
+
+
+def packed_weights(weight: torch.Tensor, precise: bool, transpose_flip: bool):
+    """MFMA-side image of an nn.Conv2d weight, rebuilt only when the parameter changes."""
+    cache = getattr(weight, "_vq_pack", None)
+    key = (weight._version, weight.data_ptr())
+    if cache is None or cache["key"] != key:
+        cache = {"key": key}
+        weight._vq_pack = cache
+    k = (precise, transpose_flip)
+    if k not in cache:
+        w = weight.detach()
+        w = w if w.is_contiguous() else w.contiguous()
+        cout, cin, kh, kw = w.shape
+        n = lib().vqseg_conv_packed_elems(cout, cin, kh, kw, int(transpose_flip))
+        hi = torch.empty(n, dtype=torch.int16, device=w.device)
+        lo = torch.empty(n, dtype=torch.int16, device=w.device) if precise else None
+        with torch.cuda.device(w.device):
+            _check(lib().vqseg_conv_pack_weights_f32(_dev(w, torch.float32, "weight"), cout, cin, kh, kw, int(transpose_flip),
+                                                     hi.data_ptr(), _p(lo), _stream()), "vqseg_conv_pack_weights_f32")
+        cache[k] = (hi, lo)
+    return cache[k]
+
+
+def _conv_raw(x_rows, x2_rows, c1, w_hi, w_lo, out_shape, stat, n, h, w, cin, cout, kh, kw, stride, pad, reflect, up,
+              ho, wo, w_offset_elems=0):
+    precise = x_rows.dtype == torch.float32
+    y = torch.empty(out_shape, dtype=x_rows.dtype, device=x_rows.device)
+    esz = 2
+    with torch.cuda.device(x_rows.device):
+        rc = lib().vqseg_conv2d_f(x_rows.data_ptr(), _p(x2_rows), c1, w_hi.data_ptr() + w_offset_elems * esz,
+                                  (w_lo.data_ptr() + w_offset_elems * esz) if w_lo is not None else None, y.data_ptr(),
+                                  _p(stat), n, h, w, cin, cout, kh, kw, stride, pad, int(reflect), up, ho, wo, int(precise),
+                                  _stream())
+    _check(rc, "vqseg_conv2d_f")
+    return y
+
+
+def _out_size(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+# ------------------------------------------------------------------------------------------------
+# Conv (no bias) -> BatchNorm -> [+ residual] -> [ReLU], optional channel concat of two inputs
+# ------------------------------------------------------------------------------------------------
+class _ConvBNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, x2, residual, weight, gamma, beta, bn, stride, pad, reflect, relu, patches_of):
+        """x (N,C1,H,W) [+ x2 (N,C2,H,W)] -> out (N,Cout,Ho,Wo).  `patches_of` = (kh, kw, cin, stride, pad, reflect,
+        H, W) when x is an im2col patch matrix of the stem (then the convolution itself is 1x1)."""
+        xr = _rows(x)
+        x2r = _rows(x2) if x2 is not None else None
+        bf = _is_bf16(xr)
+        precise = not bf
+        n, h, w, c1 = xr.shape
+        cin = c1 + (x2r.shape[3] if x2r is not None else 0)
+        cout = weight.shape[0]
+        kh, kw = (1, 1) if patches_of else (weight.shape[2], weight.shape[3])
+        ho, wo = _out_size(h, kh, stride, pad), _out_size(w, kw, stride, pad)
+        m = n * ho * wo
+        training = bool(bn.training)
+        L = lib()
+        dev = xr.device
+        if patches_of:
+            w_hi, w_lo = _stem_weights(weight, precise, cin)
+        else:
+            w_hi, w_lo = packed_weights(weight, precise, False)
+        stat = torch.empty(L.vqseg_conv_stat_slots(m, cout) * 2 * cout, dtype=torch.float32, device=dev) if training else None
+        y = _conv_raw(xr, x2r, c1, w_hi, w_lo, (n, ho, wo, cout), stat, n, h, w, cin, cout, kh, kw, stride, pad, reflect, 1,
+                      ho, wo)
+        coef = torch.empty(4, cout, dtype=torch.float32, device=dev)       # scale, shift, mean, invstd
+        if bn.momentum is None:
+            raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not used by the path")
+        with torch.cuda.device(dev):
+            _check(L.vqseg_bn_finalize_f(_p(stat), m, cout, _dev(gamma, torch.float32, "bn.weight"),
+                                         _dev(beta, torch.float32, "bn.bias"), _p(bn.running_mean), _p(bn.running_var),
+                                         float(bn.momentum), float(bn.eps), int(training), coef[0].data_ptr(),
+                                         coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), _stream()),
+                   "vqseg_bn_finalize_f")
+            if training and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            rr = _rows(residual) if residual is not None else None
+            if rr is not None and rr.dtype != y.dtype:
+                raise _hip.HipLibraryError("residual dtype differs from the activation dtype")
+            out = torch.empty_like(y)
+            _check(L.vqseg_bn_apply_f(bf, y.data_ptr(), _p(rr), coef[0].data_ptr(), coef[1].data_ptr(), m, cout, int(relu),
+                                      out.data_ptr(), _stream()), "vqseg_bn_apply_f")
+        ctx.save_for_backward(xr, x2r, y, out, coef, weight, gamma)
+        ctx.cfg = (stride, pad, bool(reflect), bool(relu), training, residual is not None, patches_of, (n, h, w, c1, cin, cout,
+                                                                                                         kh, kw, ho, wo))
+        return _nchw(out)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        xr, x2r, y, out, coef, weight, gamma = ctx.saved_tensors
+        stride, pad, reflect, relu, training, has_res, patches_of, (n, h, w, c1, cin, cout, kh, kw, ho, wo) = ctx.cfg
+        L = lib()
+        dev = y.device
+        bf = _is_bf16(y)
+        precise = not bf
+        m = n * ho * wo
+        g = _rows(g_out)
+        if g.dtype != y.dtype:
+            g = g.to(y.dtype)
+        g_y = torch.empty_like(y)
+        g_res = torch.empty_like(y) if has_res else None
+        ws = torch.empty(L.vqseg_bn_backward_workspace_floats(m, cout), dtype=torch.float32, device=dev)
+        dgb = torch.empty(2, cout, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _check(L.vqseg_bn_backward_f(bf, g.data_ptr(), out.data_ptr(), y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
+                                         _dev(gamma.detach(), torch.float32, "bn.weight"), m, cout, int(relu), int(training),
+                                         ws.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), g_y.data_ptr(), _p(g_res),
+                                         _stream()), "vqseg_bn_backward_f")
+        # ---- weight gradient
+        gw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+        if patches_of:
+            okh, okw, ocin = patches_of[0], patches_of[1], patches_of[2]
+            nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, 1, 1)
+            wsw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _check(L.vqseg_conv2d_wgrad_f(g_y.data_ptr(), xr.data_ptr(), None, cin, n, h, w, cin, ho, wo, cout, okh, okw, 1, 0,
+                                              0, int(precise), ocin, 1, wsw.data_ptr(), nbytes, gw.data_ptr(), _stream()),
+                       "vqseg_conv2d_wgrad_f")
+        else:
+            nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, kh, kw)
+            wsw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _check(L.vqseg_conv2d_wgrad_f(g_y.data_ptr(), xr.data_ptr(), _p(x2r), c1, n, h, w, cin, ho, wo, cout, kh, kw,
+                                              stride, pad, int(reflect), int(precise), cin, 0, wsw.data_ptr(), nbytes,
+                                              gw.data_ptr(), _stream()), "vqseg_conv2d_wgrad_f")
+        # ---- data gradient(s): the same implicit-GEMM kernel on g_y with tap-flipped, transposed weights
+        gx = gx2 = None
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if (need1 or need2) and not patches_of:
+            t_hi, t_lo = packed_weights(weight, precise, True)                 # [Cin][kh][kw][Cout]
+            taps = kh * kw
+            hp, wp = (h + 2 * pad, w + 2 * pad) if reflect else (h, w)         # reflect: gradient of the padded input first
+            dpad = (kh - 1) if reflect else (kh - 1 - pad)
+
+            def dgrad(c_lo, c_cnt):
+                gp = _conv_raw(g_y, None, cout, t_hi, t_lo, (n, hp, wp, c_cnt), None, n, ho, wo, cout, c_cnt, kh, kw, 1, dpad, False,
+                               stride, hp, wp, w_offset_elems=c_lo * taps * ((cout + 31) // 32 * 32))
+                if not reflect:
+                    return gp
+                if pad != 1:
+                    raise NotImplementedError("reflect-padding data gradient is implemented for pad == 1")
+                gxx = torch.empty((n, h, w, c_cnt), dtype=gp.dtype, device=dev)
+                with torch.cuda.device(dev):
+                    _check(L.vqseg_reflect_fold_f(bf, gp.data_ptr(), n, h, w, c_cnt, gxx.data_ptr(), _stream()),
+                           "vqseg_reflect_fold_f")
+                return gxx
+
+            if need1:
+                gx = _nchw(dgrad(0, c1))
+            if need2 and x2r is not None:
+                gx2 = _nchw(dgrad(c1, cin - c1))
+        return gx, gx2, (_nchw(g_res) if has_res else None), gw, dgb[0], dgb[1], None, None, None, None, None, None
+
+
+def _stem_weights(weight, precise, kp):
+    """[64][3][7][7] -> packed [64][kp] rows ((kh, kw, ci) columns, zero padded to kp)."""
+    cache = getattr(weight, "_vq_pack", None)
+    key = (weight._version, weight.data_ptr())
+    if cache is None or cache["key"] != key:
+        cache = {"key": key}
+        weight._vq_pack = cache
+    k = ("stem", precise, kp)
+    if k not in cache:
+        # view the [Cout][Cin][KH][KW] stem weight as a 1x1 convolution over kp = pad32(KH*KW*Cin) patch columns
+        cout, cin, kh, kw = weight.shape
+        w2 = torch.zeros(cout, kp, 1, 1, dtype=torch.float32, device=weight.device)
+        w2[:, :kh * kw * cin, 0, 0] = weight.detach().permute(0, 2, 3, 1).reshape(cout, kh * kw * cin)
+        cache[k] = packed_weights(w2, precise, False)
+        cache[("stem_keepalive", precise, kp)] = w2
+    return cache[k]
+
+
+def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None):
+    """Conv2d (no bias; zero or reflect padding) -> BatchNorm2d -> [+ residual] -> [ReLU] on the HIP kernels.
+    `x2`: second input whose channels follow x's (the decoder's concat).  `training` is ignored: the
+    BatchNorm module's own mode decides (nn.BatchNorm2d semantics)."""
+    if conv.bias is not None:
+        raise NotImplementedError("conv_bn_act: the reference's fused blocks have no conv bias")
+    if not x.is_cuda:
+        raise _hip.HipLibraryError(f"the HIP path needs 'cuda' (ROCm) tensors, got {x.device}; there is no CPU fallback")
+    pad = conv.padding[0]
+    return _ConvBNAct.apply(x, x2, residual, conv.weight, bn.weight, bn.bias, bn, conv.stride[0], pad,
+                            conv.padding_mode == "reflect" and pad > 0, relu, None)
+
+
+def stem_conv_bn_act(x, conv, bn):
+    """7x7 stride-2 stem on a 3-channel fp32 image: im2col patch matrix (zero / reflect padding) + 1x1 MFMA conv."""
+    if not x.is_cuda:
+        raise _hip.HipLibraryError(f"the HIP path needs 'cuda' (ROCm) tensors, got {x.device}; there is no CPU fallback")
+    xr = _rows(x.float())
+    n, h, w, cin = xr.shape
+    kh, kw = conv.kernel_size
+    s, p = conv.stride[0], conv.padding[0]
+    reflect = conv.padding_mode == "reflect"
+    ho, wo = _out_size(h, kh, s, p), _out_size(w, kw, s, p)
+    kp = (kh * kw * cin + 31) // 32 * 32
+    dt = act_dtype()
+    patches = torch.empty((n, ho, wo, kp), dtype=dt, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().vqseg_im2col_f(int(dt == torch.bfloat16), xr.data_ptr(), n, h, w, cin, kh, kw, s, p, int(reflect), ho, wo, kp,
+                                    patches.data_ptr(), _stream()), "vqseg_im2col_f")
+    return _ConvBNAct.apply(_nchw(patches), None, None, conv.weight, bn.weight, bn.bias, bn, 1, 0, False, True,
+                            (kh, kw, cin, s, p, reflect, h, w))
+
+
+# ------------------------------------------------------------------------------------------------
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xr = _rows(x)
+        n, h, w, c = xr.shape
+        ho, wo = _out_size(h, 3, 2, 1), _out_size(w, 3, 2, 1)
+        y = torch.empty((n, ho, wo, c), dtype=xr.dtype, device=xr.device)
+        with torch.cuda.device(xr.device):
+            _check(lib().vqseg_maxpool3x3s2_f(_is_bf16(xr), 0, xr.data_ptr(), None, n, h, w, c, y.data_ptr(), _stream()),
+                   "vqseg_maxpool3x3s2_f")
+        ctx.save_for_backward(xr)
+        return _nchw(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        (xr,) = ctx.saved_tensors
+        n, h, w, c = xr.shape
+        gr = _rows(g).to(xr.dtype)
+        gx = torch.empty_like(xr)
+        with torch.cuda.device(xr.device):
+            _check(lib().vqseg_maxpool3x3s2_f(_is_bf16(xr), 1, xr.data_ptr(), gr.data_ptr(), n, h, w, c, gx.data_ptr(), _stream()),
+                   "vqseg_maxpool3x3s2_f")
+        return _nchw(gx)
 
 
 def max_pool_3x3_s2(x):
-    return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    return _MaxPool.apply(x)
+
+
+class _Bilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ho, wo, align):
+        xr = _rows(x)
+        n, h, w, c = xr.shape
+        y = torch.empty((n, ho, wo, c), dtype=xr.dtype, device=xr.device)
+        with torch.cuda.device(xr.device):
+            _check(lib().vqseg_bilinear_f(_is_bf16(xr), 0, xr.data_ptr(), n, h, w, c, ho, wo, int(align), y.data_ptr(), _stream()),
+                   "vqseg_bilinear_f")
+        ctx.cfg = (n, h, w, c, ho, wo, int(align), xr.dtype)
+        return _nchw(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, c, ho, wo, align, dt = ctx.cfg
+        gr = _rows(g).to(dt)
+        gx = torch.empty((n, h, w, c), dtype=dt, device=gr.device)
+        with torch.cuda.device(gr.device):
+            _check(lib().vqseg_bilinear_f(int(dt == torch.bfloat16), 1, gr.data_ptr(), n, h, w, c, ho, wo, align, gx.data_ptr(),
+                                          _stream()), "vqseg_bilinear_f")
+        return _nchw(gx), None, None, None
 
 
 def upsample_bilinear(x, size=None, scale_factor=None, align_corners=False):
-    return F.interpolate(x, size=size, scale_factor=scale_factor, mode="bilinear", align_corners=align_corners)
+    if size is None:
+        size = (int(x.shape[-2] * scale_factor), int(x.shape[-1] * scale_factor))
+    return _Bilinear.apply(x, int(size[0]), int(size[1]), bool(align_corners))
 
 
-def concat_channels(a, b):
-    return torch.cat((a, b), dim=1)
+class _Head1x1(torch.autograd.Function):
+    """nn.Conv2d(Cin, num_classes <= 4, 1, bias=False): fp32 logits whatever the activation dtype."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        xr = _rows(x)
+        n, h, w, cin = xr.shape
+        cout = weight.shape[0]
+        wt = weight.detach().reshape(cout, cin).contiguous()
+        y = torch.empty((n, h, w, cout), dtype=torch.float32, device=xr.device)
+        with torch.cuda.device(xr.device):
+            _check(lib().vqseg_head1x1_forward_f(_is_bf16(xr), xr.data_ptr(), _dev(wt, torch.float32, "head weight"), n * h * w, cin,
+                                                 cout, y.data_ptr(), _stream()), "vqseg_head1x1_forward_f")
+        ctx.save_for_backward(xr, wt)
+        return _nchw(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        xr, wt = ctx.saved_tensors
+        n, h, w, cin = xr.shape
+        cout = wt.shape[0]
+        m = n * h * w
+        gr = _rows(g).float()
+        gx = torch.empty_like(xr)
+        gw = torch.empty((cout, cin), dtype=torch.float32, device=xr.device)
+        ws = torch.empty(lib().vqseg_head1x1_backward_workspace_floats(m, cin, cout), dtype=torch.float32, device=xr.device)
+        with torch.cuda.device(xr.device):
+            _check(lib().vqseg_head1x1_backward_f(_is_bf16(xr), xr.data_ptr(), wt.data_ptr(), gr.data_ptr(), m, cin, cout, gx.data_ptr(),
+                                                  gw.data_ptr(), ws.data_ptr(), _stream()), "vqseg_head1x1_backward_f")
+        return _nchw(gx), gw.reshape(cout, cin, 1, 1)
+
+
+def head_conv1x1(x, weight):
+    return _Head1x1.apply(x, weight)
+
+
+class _Cast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        if x.dtype == dtype:
+            return x
+        xr = _rows(x)
+        y = torch.empty(xr.shape, dtype=dtype, device=xr.device)
+        with torch.cuda.device(xr.device):
+            _check(lib().vqseg_cast_f(int(dtype == torch.bfloat16), xr.data_ptr(), xr.numel(), y.data_ptr(), _stream()), "vqseg_cast_f")
+        return _nchw(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Cast.apply(g, ctx.src), None
+
+
+def cast_act(x, dtype):
+    """f32 <-> bf16 activation cast (NHWC), differentiable."""
+    if x.dtype == dtype:
+        return x
+    if {x.dtype, dtype} != {torch.float32, torch.bfloat16}:
+        return x.to(dtype)
+    return _Cast.apply(x, dtype)

@@ -185,8 +185,6 @@ class CPSTrainer:
             for m in self.models:
                 for t in list(m.parameters()) + list(m.buffers()):
                     dist.broadcast(t.data, src=0)
-        for m in self.models:
-            m.to(memory_format=torch.channels_last)
         self.buckets = [GradBuckets(list(m.parameters()), cfg.bucket_mb) for m in self.models]
         self.opts = [torch.optim.Adam(m.parameters(), lr=cfg.learning_rate, betas=(0.9, 0.999)) for m in self.models]
         self.sched = CosineAnnealingLR(cfg.learning_rate, cfg.min_lr, cfg.total_iters, cfg.warmup_steps)

@@ -45,8 +45,10 @@ class _VQFunction(torch.autograd.Function):
 
 def _rows_of(x: torch.Tensor):
     """(B, C, H, W) any float -> contiguous fp32 (B*H*W, C) rows (free for channels_last input)."""
+    from .. import nnf
     b, c, h, w = x.shape
-    rows = x.to(torch.float32).permute(0, 2, 3, 1)          # vq_img.py:229,232
+    x = nnf.cast_act(x, torch.float32) if x.dtype == torch.bfloat16 else x.to(torch.float32)
+    rows = x.permute(0, 2, 3, 1)                            # vq_img.py:229,232
     if not rows.is_contiguous():
         rows = rows.contiguous()
     return rows.reshape(b * h * w, c)
