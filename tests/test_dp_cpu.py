@@ -1,0 +1,118 @@
+"""Data-parallel host logic on CPU with the gloo backend, world_size 2 (the GPU path uses the same code over RCCL).
+
+  * GradBuckets: bucketed, hook-driven gradient all-reduce == the average of the per-rank gradients,
+    including parameters that receive no gradient (the frozen codebooks / v1 prototypes).
+  * distributed k-means init: rank 0's initial means are broadcast and per-iteration sums/counts are
+    all-reduced, so two ranks holding half the rows each reproduce single-process Lloyd on all rows.
+    (The per-rank accumulate kernel is replaced by the CPU oracle here: no GPU in this test.)
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def spawn(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _grad_job(rank, world):
+    from vq_seg_amd.trainer import GradBuckets
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 4))
+    frozen = nn.Parameter(torch.ones(5))                     # never receives a gradient
+    params = list(net.parameters()) + [frozen]
+    buckets = GradBuckets(params, bucket_mb=0.0003)          # tiny buckets -> several all-reduces
+    assert len(buckets.buckets) >= 3
+    x = torch.arange(8.0).repeat(3, 1) * (rank + 1)
+    for _ in range(2):                                       # second iteration checks zero() / re-arming
+        buckets.zero()
+        net(x).pow(2).sum().backward()
+        buckets.finish()
+    return [p.grad.clone() for p in params]
+
+
+def test_grad_buckets_average_over_ranks():
+    out = spawn(_grad_job)
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 4))
+    ref = [torch.zeros_like(p) for p in net.parameters()]
+    for rank in range(2):
+        net.zero_grad()
+        x = torch.arange(8.0).repeat(3, 1) * (rank + 1)
+        net(x).pow(2).sum().backward()
+        ref = [r + p.grad / 2 for r, p in zip(ref, net.parameters())]
+    for rank in range(2):
+        for g, r in zip(out[rank][:-1], ref):
+            assert torch.allclose(g, r, rtol=1e-6, atol=1e-7)
+        assert torch.equal(out[rank][-1], torch.zeros(5))
+    assert all(torch.equal(a, b) for a, b in zip(out[0], out[1]))      # every rank holds the same averaged gradient
+
+
+def _kmeans_job(rank, world):
+    from oracle import torch_ref
+    from tests import synth
+    from vq_seg_amd import _hip
+    from vq_seg_amd.vector_quantizer import vq_img
+
+    def accumulate(samples, means):                          # CPU stand-in for vqseg_kmeans_accumulate_f32
+        idx = torch.argmin(torch.cdist(samples, means), dim=-1)
+        k, c = means.shape
+        sums = torch.zeros(k, c).index_add_(0, idx, samples)
+        return sums, torch.bincount(idx, minlength=k)
+
+    def finalize(sums, counts, means):                       # vqseg_kmeans_finalize_f32
+        nz = counts > 0
+        means[nz] = sums[nz] / counts[nz, None].float()
+        return means
+
+    _hip.kmeans_accumulate, _hip.kmeans_finalize = accumulate, finalize
+    rows = synth.relu_features(7, (512, 16))
+    mine = rows[rank::world].contiguous()
+    init = rows[:8].clone() if rank == 0 else torch.zeros(8, 16)      # only rank 0's draw counts
+    means, counts = vq_img.kmeans(mine, 8, 10, init_means=init)
+    return means, counts
+
+
+def test_distributed_kmeans_matches_single_process():
+    from oracle import torch_ref
+    from tests import synth
+    out = spawn(_kmeans_job)
+    rows = synth.relu_features(7, (512, 16))
+    ref_means, ref_bins = torch_ref.kmeans_lloyd(rows, rows[:8].clone(), 10)
+    for means, counts in out:
+        assert torch.equal(counts, ref_bins)
+        assert torch.allclose(means, ref_means, rtol=1e-5, atol=1e-6)
+    assert torch.equal(out[0][0], out[1][0])
+
+
+def test_synthetic_data_is_sharded_by_rank():
+    from vq_seg_amd.trainer import SyntheticCropWeed
+    a = SyntheticCropWeed(32, 2, "cpu", seed=1)
+    img, lab = a.labelled()
+    assert img.shape == (2, 3, 32, 32) and lab.shape == (2, 32, 32) and img.min() >= 0 and img.max() <= 1
+    assert set(lab.unique().tolist()) <= {0, 1, 2}

@@ -553,22 +553,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 // im2col columns are dropped)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int slabs, int Cout, int Cin,
                                                            int Cin_out, int KH, int KW, int im2col, float* __restrict__ gw) {
-    const long total = (long)Cout * Cin_out * KH * KW;
+    // threads walk the SOURCE (packed) layout so the slabs are read coalesced; the transposing write happens once
     const long slab = (long)Cout * (im2col ? 1 : KH * KW) * Cin;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int kw = (int)(i % KW);
-        long t = i / KW;
-        const int kh = (int)(t % KH);
-        t /= KH;
-        const int ci = (int)(t % Cin_out);
-        const int co = (int)(t / Cin_out);
-        // source index in the packed layout
-        long src;
-        if (im2col) src = (long)co * Cin + ((long)kh * KW + kw) * Cin_out + ci;     // 1x1 conv over (kh, kw, ci) columns
-        else src = ((long)co * KH * KW + (long)kh * KW + kw) * Cin + ci;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < slab; i += (long)gridDim.x * 256) {
+        int co, kh, kw, ci;
+        if (im2col) {                                       // source [Cout][Cin = padded (kh, kw, ci) columns]
+            co = (int)(i / Cin);
+            const int col = (int)(i % Cin);
+            if (col >= KH * KW * Cin_out) continue;
+            ci = col % Cin_out;
+            kw = (col / Cin_out) % KW;
+            kh = col / (Cin_out * KW);
+        } else {                                            // source [Cout][KH][KW][Cin]
+            ci = (int)(i % Cin);
+            long t = i / Cin;
+            kw = (int)(t % KW);
+            t /= KW;
+            kh = (int)(t % KH);
+            co = (int)(t / KH);
+            if (ci >= Cin_out) continue;
+        }
         double s = 0.0;
-        for (int z = 0; z < slabs; ++z) s += (double)partial[(long)z * slab + src];
-        gw[i] = (float)s;
+        for (int z = 0; z < slabs; ++z) s += (double)partial[(long)z * slab + i];
+        gw[(((long)co * Cin_out + ci) * KH + kh) * KW + kw] = (float)s;
     }
 }
 
@@ -609,7 +616,7 @@ hipError_t launch_wgrad(const WgradArgs& a, int precise, int slabs, hipStream_t 
 
 hipError_t launch_wgrad_reduce(const float* partial, int slabs, int Cout, int Cin, int Cin_out, int KH, int KW, int im2col,
                                float* gw, hipStream_t st) {
-    const long total = (long)Cout * Cin_out * KH * KW;
+    const long total = (long)Cout * (im2col ? 1 : KH * KW) * Cin;
     long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, partial, slabs, Cout, Cin, Cin_out, KH, KW,

@@ -113,7 +113,7 @@ int vqseg_bn_finalize_f(const float* partial, int64_t m_rows, int c, const float
 
 int vqseg_bn_apply_f(int bf16, const void* y, const void* res, const float* scale, const float* shift, int64_t m_rows, int c,
                      int relu, void* out, void* stream) {
-    if (!y || !scale || !shift || !out || c % 4 || m_rows <= 0) return bad("bn_apply: bad argument");
+    if (!y || !scale || !shift || !out || c <= 0 || m_rows <= 0) return bad("bn_apply: bad argument");
     hipError_t e = vqseg::launch_bn_apply(bf16, y, res, scale, shift, m_rows, c, relu, out, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hipfail(e, "bn_apply_kernel");
 }
@@ -127,7 +127,7 @@ int vqseg_bn_backward_f(int bf16, const void* g_out, const void* out, const void
                         const float* gamma, int64_t m_rows, int c, int relu, int training, float* workspace, float* dgamma,
                         float* dbeta, void* g_y, void* g_res, void* stream) {
     if (!g_out || !y || !mean || !invstd || !gamma || !workspace || !dgamma || !dbeta || !g_y || (relu && !out)) return bad("bn_backward: null pointer");
-    if (c % 4 || (c > 256 && c % 256)) return bad("bn_backward: unsupported channel count");
+    if (c <= 0) return bad("bn_backward: unsupported channel count");
     float* partial = workspace;
     float* coef = workspace + (size_t)vqseg::bn_bwd_blocks(m_rows) * 2 * c;
     hipError_t e = vqseg::launch_bn_backward(bf16, g_out, out, y, mean, invstd, gamma, m_rows, c, relu, training, partial, coef,

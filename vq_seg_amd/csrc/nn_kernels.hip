@@ -22,6 +22,41 @@ __device__ __forceinline__ float ld(const T* p, long i) { return (float)p[i]; }
 template <typename T>
 __device__ __forceinline__ void st(T* p, long i, float v) { p[i] = (T)v; }
 
+// 16-byte vector access: 4 floats or 8 bf16 per thread (index i = first element, 16-byte aligned)
+template <typename T>
+struct VecN { static constexpr int N = 16 / sizeof(T); };
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ void ldv(const T* p, long i, float (&v)[VecN<T>::N]) {
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(p + i);
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(raw[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = __uint_as_float(raw[e] << 16);
+            v[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u);
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void stv(T* p, long i, const float (&v)[VecN<T>::N]) {
+    u32x4 raw;
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) raw[e] = __float_as_uint(v[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const __bf16 a = (__bf16)v[2 * e], b = (__bf16)v[2 * e + 1];
+            raw[e] = (unsigned int)__builtin_bit_cast(unsigned short, a) | ((unsigned int)__builtin_bit_cast(unsigned short, b) << 16);
+        }
+    }
+    *reinterpret_cast<u32x4*>(p + i) = raw;
+}
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm forward statistics
 // ---------------------------------------------------------------------------------------------
@@ -95,20 +130,33 @@ __global__ __launch_bounds__(256) void bn_eval_coeffs_kernel(int C, const float*
     save_invstd[c] = invstd;
 }
 
-// out = [relu]( y * scale[c] + shift[c] [+ res] )
+// out = [relu]( y * scale[c] + shift[c] [+ res] )      (16 bytes per thread when C allows, else scalar)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        long M, int C, int relu, T* __restrict__ out) {
+    constexpr int V = VecN<T>::N;
     const long total = M * C;
-    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 256 * 4) {
-        const int c = (int)(i % C);                       // C % 4 == 0: the 4 elements share a row
+    if (C % V == 0) {
+        for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * V; i < total; i += (long)gridDim.x * 256 * V) {
+            const int c = (int)(i % C);
+            float v[V], r[V];
+            ldv(y, i, v);
+            if (res) ldv(res, i, r);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = ld(y, i + e) * scale[c + e] + shift[c + e];
-            if (res) v += ld(res, i + e);
-            if (relu) v = v > 0.0f ? v : 0.0f;
-            st(out, i + e, v);
+            for (int e = 0; e < V; ++e) {
+                float t = v[e] * scale[c + e] + shift[c + e];
+                if (res) t += r[e];
+                v[e] = (relu && !(t > 0.0f)) ? 0.0f : t;
+            }
+            stv(out, i, v);
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int c = (int)(i % C);
+            float t = ld(y, i) * scale[c] + shift[c];
+            if (res) t += ld(res, i);
+            st(out, i, (relu && !(t > 0.0f)) ? 0.0f : t);
         }
     }
 }
@@ -117,48 +165,85 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 // BatchNorm backward (through the fused ReLU / residual):  gz = g_out * (out > 0)
 //   partial[blk][0][c] = sum gz,   partial[blk][1][c] = sum gz * xhat,   xhat = (y - mean) * invstd
 // ---------------------------------------------------------------------------------------------
-constexpr int BNB_ROWS = 128;      // rows per block of the reduce kernel
+constexpr int BNB_ROWS = 256;      // rows per block of the reduce kernel
+constexpr int BNB_CG = 64;         // channels per block
 
+// grid (row chunks, channel groups).  Each thread owns V consecutive channels (one 16-byte load) of every
+// (256 / threads-per-row)-th row of the chunk; row lanes are folded through LDS in a fixed order.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ g_out, const T* __restrict__ out,
                                                             const T* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, long M, int C, int relu,
                                                             float* __restrict__ partial) {
-    // thread -> channel c = threadIdx.x % Cw (+ k * Cw), row lane = threadIdx.x / Cw, Cw = min(C, 256)
-    const int Cw = C < 256 ? C : 256;
-    const int lanes = 256 / Cw;                            // threads beyond lanes * Cw idle (C need not divide 256)
-    const int rl = threadIdx.x / Cw;
-    const bool live = rl < lanes;
+    constexpr int V = VecN<T>::N;
+    __shared__ float sh[2][256 * V];                       // [sum kind][row lane][channel in group]
+    const int cg = C < BNB_CG ? C : BNB_CG;                // channels handled by this block
+    const int c0 = blockIdx.y * BNB_CG;
     const long row0 = (long)blockIdx.x * BNB_ROWS;
-    extern __shared__ float sh[];                          // [lanes][2][Cw]
-    for (int cb = 0; cb < C; cb += Cw) {
-        const int c = cb + threadIdx.x % Cw;
-        float s0 = 0.0f, s1 = 0.0f;
-        const float mu = mean[c], is = invstd[c];
-        for (int rr = rl; live && rr < BNB_ROWS; rr += lanes) {
-            const long m = row0 + rr;
-            if (m < M) {
-                float g = ld(g_out, m * C + c);
-                if (relu && !(ld(out, m * C + c) > 0.0f)) g = 0.0f;
-                s0 += g;
-                s1 += g * ((ld(y, m * C + c) - mu) * is);
+    float s0[V], s1[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) s0[e] = s1[e] = 0.0f;
+    int tpr, lanes, rl = 0, cv = 0;
+    if (C % V == 0) {
+        tpr = cg / V;                                      // threads per row
+        lanes = 256 / tpr;
+        rl = threadIdx.x / tpr;
+        cv = (threadIdx.x % tpr) * V;
+        if (rl < lanes && c0 + cv < C) {
+            float mu[V], is[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                mu[e] = mean[c0 + cv + e];
+                is[e] = invstd[c0 + cv + e];
+            }
+            for (int rr = rl; rr < BNB_ROWS; rr += lanes) {
+                const long m = row0 + rr;
+                if (m >= M) break;
+                float g[V], o[V], yy[V];
+                ldv(g_out, m * C + c0 + cv, g);
+                ldv(y, m * C + c0 + cv, yy);
+                if (relu) ldv(out, m * C + c0 + cv, o);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float gz = (relu && !(o[e] > 0.0f)) ? 0.0f : g[e];
+                    s0[e] += gz;
+                    s1[e] = __builtin_fmaf(gz, (yy[e] - mu[e]) * is[e], s1[e]);
+                }
             }
         }
-        if (live) {
-            sh[(rl * 2 + 0) * Cw + threadIdx.x % Cw] = s0;
-            sh[(rl * 2 + 1) * Cw + threadIdx.x % Cw] = s1;
-        }
-        __syncthreads();
-        if (rl == 0) {
-            float a = 0.0f, b = 0.0f;
-            for (int l = 0; l < lanes; ++l) {
-                a += sh[(l * 2 + 0) * Cw + threadIdx.x];
-                b += sh[(l * 2 + 1) * Cw + threadIdx.x];
+    } else {                                               // scalar fallback (odd channel counts): one channel per thread
+        tpr = cg;
+        lanes = 256 / tpr;
+        rl = threadIdx.x / tpr;
+        cv = threadIdx.x % tpr;
+        if (rl < lanes && c0 + cv < C) {
+            const float mu = mean[c0 + cv], is = invstd[c0 + cv];
+            for (int rr = rl; rr < BNB_ROWS; rr += lanes) {
+                const long m = row0 + rr;
+                if (m >= M) break;
+                float gz = ld(g_out, m * C + c0 + cv);
+                if (relu && !(ld(out, m * C + c0 + cv) > 0.0f)) gz = 0.0f;
+                s0[0] += gz;
+                s1[0] = __builtin_fmaf(gz, (ld(y, m * C + c0 + cv) - mu) * is, s1[0]);
             }
-            partial[((long)blockIdx.x * 2 + 0) * C + c] = a;
-            partial[((long)blockIdx.x * 2 + 1) * C + c] = b;
         }
-        __syncthreads();
+    }
+    const int vv = (C % V == 0) ? V : 1;
+    if (rl < lanes) {
+        for (int e = 0; e < vv; ++e) {
+            sh[0][rl * cg + cv + e] = s0[e];
+            sh[1][rl * cg + cv + e] = s1[e];
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cg && c0 + (int)threadIdx.x < C) {
+        float a = 0.0f, b = 0.0f;
+        for (int l = 0; l < lanes; ++l) {
+            a += sh[0][l * cg + threadIdx.x];
+            b += sh[1][l * cg + threadIdx.x];
+        }
+        partial[((long)blockIdx.x * 2 + 0) * C + c0 + threadIdx.x] = a;
+        partial[((long)blockIdx.x * 2 + 1) * C + c0 + threadIdx.x] = b;
     }
 }
 
@@ -200,16 +285,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const T* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
                                                            long M, int C, int relu, T* __restrict__ g_y, T* __restrict__ g_res) {
+    constexpr int V = VecN<T>::N;
     const long total = M * C;
-    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 256 * 4) {
-        const int c = (int)(i % C);
+    if (C % V == 0) {
+        for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * V; i < total; i += (long)gridDim.x * 256 * V) {
+            const int c = (int)(i % C);
+            float g[V], o[V], yy[V], r[V];
+            ldv(g_out, i, g);
+            ldv(y, i, yy);
+            if (relu) ldv(out, i, o);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float g = ld(g_out, i + e);
-            if (relu && !(ld(out, i + e) > 0.0f)) g = 0.0f;
-            const float xh = (ld(y, i + e) - mean[c + e]) * invstd[c + e];
-            st(g_y, i + e, coef[c + e] * (g - coef[C + c + e] - xh * coef[2 * C + c + e]));
-            if (g_res) st(g_res, i + e, g);
+            for (int e = 0; e < V; ++e) {
+                const float gz = (relu && !(o[e] > 0.0f)) ? 0.0f : g[e];
+                const float xh = (yy[e] - mean[c + e]) * invstd[c + e];
+                r[e] = gz;
+                g[e] = coef[c + e] * (gz - coef[C + c + e] - xh * coef[2 * C + c + e]);
+            }
+            stv(g_y, i, g);
+            if (g_res) stv(g_res, i, r);
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int c = (int)(i % C);
+            float g = ld(g_out, i);
+            if (relu && !(ld(out, i) > 0.0f)) g = 0.0f;
+            const float xh = (ld(y, i) - mean[c]) * invstd[c];
+            st(g_y, i, coef[c] * (g - coef[C + c] - xh * coef[2 * C + c]));
+            if (g_res) st(g_res, i, g);
         }
     }
 }
@@ -218,70 +320,104 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // max-pool 3x3 stride 2 pad 1 (NHWC).  Backward recomputes the arg-max (first maximum in window scan
 // order kh, kw -- the order ATen's max_pool2d uses) and gathers: deterministic, no atomics.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+// Each thread handles VC consecutive channels of one pixel (VC = 16-byte vector when C allows, else 1).
+template <typename T, int VC>
+__device__ __forceinline__ void ldc(const T* p, long i, float (&v)[VecN<T>::N]) {
+    if constexpr (VC == 1) v[0] = ld(p, i);
+    else ldv(p, i, v);
+}
+template <typename T, int VC>
+__device__ __forceinline__ void stc(T* p, long i, const float (&v)[VecN<T>::N]) {
+    if constexpr (VC == 1) st(p, i, v[0]);
+    else stv(p, i, v);
+}
+
+template <typename T, int VC>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C, int Ho, int Wo,
                                                           T* __restrict__ y) {
-    const long total = (long)N * Ho * Wo * C;
+    constexpr int V = VecN<T>::N;
+    const int cv = C / VC;
+    const long total = (long)N * Ho * Wo * cv;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        long t = i / C;
+        const int c = (int)(i % cv) * VC;
+        long t = i / cv;
         const int ow = (int)(t % Wo);
         t /= Wo;
         const int oh = (int)(t % Ho);
         const int n = (int)(t / Ho);
-        float best = -__builtin_inff();
+        float best[V];
+#pragma unroll
+        for (int e = 0; e < VC; ++e) best[e] = -__builtin_inff();
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = oh * 2 - 1 + kh;
             if (ih < 0 || ih >= H) continue;
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = ow * 2 - 1 + kw;
                 if (iw < 0 || iw >= W) continue;
-                const float v = ld(x, (((long)n * H + ih) * W + iw) * C + c);
-                if (v > best || v != v) best = v;
+                float v[V];
+                ldc<T, VC>(x, (((long)n * H + ih) * W + iw) * C + c, v);
+#pragma unroll
+                for (int e = 0; e < VC; ++e)
+                    if (v[e] > best[e] || v[e] != v[e]) best[e] = v[e];
             }
         }
-        st(y, i, best);
+        stc<T, VC>(y, (((long)n * Ho + oh) * Wo + ow) * C + c, best);
     }
 }
 
-template <typename T>
+template <typename T, int VC>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, int N, int H, int W,
                                                           int C, int Ho, int Wo, T* __restrict__ gx) {
-    const long total = (long)N * H * W * C;
+    constexpr int V = VecN<T>::N;
+    const int cv = C / VC;
+    const long total = (long)N * H * W * cv;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        long t = i / C;
+        const int c = (int)(i % cv) * VC;
+        long t = i / cv;
         const int iw = (int)(t % W);
         t /= W;
         const int ih = (int)(t % H);
         const int n = (int)(t / H);
-        float acc = 0.0f;
-        // output windows that contain (ih, iw): oh in [(ih-1)/2 .. (ih+1)/2]
-        for (int oh = (ih - 1 + 1) / 2; oh <= (ih + 1) / 2 && oh < Ho; ++oh) {
-            if (oh < 0 || ih < oh * 2 - 1 || ih > oh * 2 + 1) continue;
-            for (int ow = (iw - 1 + 1) / 2; ow <= (iw + 1) / 2 && ow < Wo; ++ow) {
-                if (ow < 0 || iw < ow * 2 - 1 || iw > ow * 2 + 1) continue;
-                // arg-max of this window (first maximum in scan order)
-                float best = -__builtin_inff();
-                int bh = -1, bw = -1;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < VC; ++e) acc[e] = 0.0f;
+        // output windows that contain (ih, iw): oh in [ih/2 .. (ih+1)/2]
+        for (int oh = ih / 2; oh <= (ih + 1) / 2 && oh < Ho; ++oh) {
+            if (ih < oh * 2 - 1 || ih > oh * 2 + 1) continue;
+            for (int ow = iw / 2; ow <= (iw + 1) / 2 && ow < Wo; ++ow) {
+                if (iw < ow * 2 - 1 || iw > ow * 2 + 1) continue;
+                // arg-max of this window (first maximum in scan order), per channel
+                float best[V];
+                int bpos[V];
+#pragma unroll
+                for (int e = 0; e < VC; ++e) {
+                    best[e] = -__builtin_inff();
+                    bpos[e] = -1;
+                }
                 for (int kh = 0; kh < 3; ++kh) {
                     const int jh = oh * 2 - 1 + kh;
                     if (jh < 0 || jh >= H) continue;
                     for (int kw = 0; kw < 3; ++kw) {
                         const int jw = ow * 2 - 1 + kw;
                         if (jw < 0 || jw >= W) continue;
-                        const float v = ld(x, (((long)n * H + jh) * W + jw) * C + c);
-                        if (v > best || v != v) {
-                            best = v;
-                            bh = jh;
-                            bw = jw;
-                        }
+                        float v[V];
+                        ldc<T, VC>(x, (((long)n * H + jh) * W + jw) * C + c, v);
+#pragma unroll
+                        for (int e = 0; e < VC; ++e)
+                            if (v[e] > best[e] || v[e] != v[e]) {
+                                best[e] = v[e];
+                                bpos[e] = jh * W + jw;
+                            }
                     }
                 }
-                if (bh == ih && bw == iw) acc += ld(g, (((long)n * Ho + oh) * Wo + ow) * C + c);
+                float gv[V];
+                ldc<T, VC>(g, (((long)n * Ho + oh) * Wo + ow) * C + c, gv);
+#pragma unroll
+                for (int e = 0; e < VC; ++e)
+                    if (bpos[e] == ih * W + iw) acc[e] += gv[e];
             }
         }
-        st(gx, i, acc);
+        stc<T, VC>(gx, (((long)n * H + ih) * W + iw) * C + c, acc);
     }
 }
 
@@ -302,13 +438,15 @@ __device__ __forceinline__ void bil_src(int d, int in, int out, int align, int& 
     l1 = s - (float)i0;
 }
 
-template <typename T>
+template <typename T, int VC>
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C, int Ho, int Wo,
                                                            int align, T* __restrict__ y) {
-    const long total = (long)N * Ho * Wo * C;
+    constexpr int V = VecN<T>::N;
+    const int cv = C / VC;
+    const long total = (long)N * Ho * Wo * cv;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        long t = i / C;
+        const int c = (int)(i % cv) * VC;
+        long t = i / cv;
         const int ow = (int)(t % Wo);
         t /= Wo;
         const int oh = (int)(t % Ho);
@@ -318,27 +456,37 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__
         bil_src(oh, H, Ho, align, h0, h1, lh);
         bil_src(ow, W, Wo, align, w0, w1, lw);
         const long b = (long)n * H;
-        const float v00 = ld(x, ((b + h0) * W + w0) * C + c), v01 = ld(x, ((b + h0) * W + w1) * C + c);
-        const float v10 = ld(x, ((b + h1) * W + w0) * C + c), v11 = ld(x, ((b + h1) * W + w1) * C + c);
-        st(y, i, (1.0f - lh) * ((1.0f - lw) * v00 + lw * v01) + lh * ((1.0f - lw) * v10 + lw * v11));
+        float v00[V], v01[V], v10[V], v11[V], o[V];
+        ldc<T, VC>(x, ((b + h0) * W + w0) * C + c, v00);
+        ldc<T, VC>(x, ((b + h0) * W + w1) * C + c, v01);
+        ldc<T, VC>(x, ((b + h1) * W + w0) * C + c, v10);
+        ldc<T, VC>(x, ((b + h1) * W + w1) * C + c, v11);
+#pragma unroll
+        for (int e = 0; e < VC; ++e)
+            o[e] = (1.0f - lh) * ((1.0f - lw) * v00[e] + lw * v01[e]) + lh * ((1.0f - lw) * v10[e] + lw * v11[e]);
+        stc<T, VC>(y, (((long)n * Ho + oh) * Wo + ow) * C + c, o);
     }
 }
 
 // backward as a gather over the (few) output pixels whose footprint touches the input pixel
-template <typename T>
+template <typename T, int VC>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ g, int N, int H, int W, int C, int Ho, int Wo,
                                                            int align, T* __restrict__ gx) {
-    const long total = (long)N * H * W * C;
+    constexpr int V = VecN<T>::N;
+    const int cv = C / VC;
+    const long total = (long)N * H * W * cv;
     const int rh = (Ho + H - 1) / H + 1, rw = (Wo + W - 1) / W + 1;       // search radius in output pixels
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        long t = i / C;
+        const int c = (int)(i % cv) * VC;
+        long t = i / cv;
         const int iw = (int)(t % W);
         t /= W;
         const int ih = (int)(t % H);
         const int n = (int)(t / H);
         const int ohc = (int)(((long)ih * Ho) / H), owc = (int)(((long)iw * Wo) / W);
-        float acc = 0.0f;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < VC; ++e) acc[e] = 0.0f;
         for (int oh = ohc - rh; oh <= ohc + rh; ++oh) {
             if (oh < 0 || oh >= Ho) continue;
             int h0, h1;
@@ -357,10 +505,13 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
                 if (w0 == iw) ww += 1.0f - lw;
                 if (w1 == iw) ww += lw;
                 if (ww == 0.0f) continue;
-                acc += wh * ww * ld(g, (((long)n * Ho + oh) * Wo + ow) * C + c);
+                float gv[V];
+                ldc<T, VC>(g, (((long)n * Ho + oh) * Wo + ow) * C + c, gv);
+#pragma unroll
+                for (int e = 0; e < VC; ++e) acc[e] += wh * ww * gv[e];
             }
         }
-        st(gx, i, acc);
+        stc<T, VC>(gx, (((long)n * H + ih) * W + iw) * C + c, acc);
     }
 }
 
@@ -520,8 +671,8 @@ hipError_t launch_bn_eval_coeffs(int C, const float* gamma, const float* beta, c
 template <typename T>
 static hipError_t bn_apply_t(const void* y, const void* res, const float* scale, const float* shift, long M, int C, int relu,
                              void* out, hipStream_t st_) {
-    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(M * C / 4)), dim3(256), 0, st_, (const T*)y, (const T*)res, scale, shift, M,
-                       C, relu, (T*)out);
+    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_, (const T*)y,
+                       (const T*)res, scale, shift, M, C, relu, (T*)out);
     return hipGetLastError();
 }
 hipError_t launch_bn_apply(int bf16, const void* y, const void* res, const float* scale, const float* shift, long M, int C,
@@ -537,13 +688,11 @@ static hipError_t bn_bwd_t(const void* g_out, const void* out, const void* y, co
                            const float* gamma, long M, int C, int relu, int training, float* partial, float* coef,
                            float* dgamma, float* dbeta, void* g_y, void* g_res, hipStream_t st_) {
     const long nb = bn_bwd_blocks(M);
-    const int Cw = C < 256 ? C : 256;
-    const size_t lds = (size_t)(256 / Cw) * 2 * Cw * sizeof(float);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3((unsigned)nb), dim3(256), lds, st_, (const T*)g_out, (const T*)out,
-                       (const T*)y, mean, invstd, M, C, relu, partial);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3((unsigned)nb, (unsigned)((C + BNB_CG - 1) / BNB_CG)), dim3(256), 0, st_,
+                       (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, M, C, relu, partial);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st_, partial, nb, M, C, gamma, invstd, training, dgamma,
                        dbeta, coef);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(M * C / 4)), dim3(256), 0, st_, (const T*)g_out, (const T*)out,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_, (const T*)g_out, (const T*)out,
                        (const T*)y, mean, invstd, coef, M, C, relu, (T*)g_y, (T*)g_res);
     return hipGetLastError();
 }
@@ -561,32 +710,50 @@ hipError_t launch_bn_backward(int bf16, const void* g_out, const void* out, cons
         if (bf16) { CALL_B; } else { CALL_F; } \
     } while (0)
 
+template <typename T, int VC>
+static void maxpool_t(int backward, const void* x, const void* g, int N, int H, int W, int C, int Ho, int Wo, void* out,
+                      hipStream_t st_) {
+    if (!backward)
+        hipLaunchKernelGGL((maxpool_fwd_kernel<T, VC>), dim3(grid_for((long)N * Ho * Wo * (C / VC))), dim3(256), 0, st_, (const T*)x, N, H,
+                           W, C, Ho, Wo, (T*)out);
+    else
+        hipLaunchKernelGGL((maxpool_bwd_kernel<T, VC>), dim3(grid_for((long)N * H * W * (C / VC))), dim3(256), 0, st_, (const T*)x,
+                           (const T*)g, N, H, W, C, Ho, Wo, (T*)out);
+}
+
 hipError_t launch_maxpool(int bf16, int backward, const void* x, const void* g, int N, int H, int W, int C, void* out,
                           hipStream_t st_) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    if (!backward) {
-        const unsigned gr = grid_for((long)N * Ho * Wo * C);
-        DISPATCH_T(bf16, hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(gr), dim3(256), 0, st_, (const float*)x, N, H, W, C, Ho, Wo, (float*)out),
-                   hipLaunchKernelGGL(maxpool_fwd_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, (const __bf16*)x, N, H, W, C, Ho, Wo, (__bf16*)out));
+    if (bf16) {
+        if (C % 8 == 0) maxpool_t<__bf16, 8>(backward, x, g, N, H, W, C, Ho, Wo, out, st_);
+        else maxpool_t<__bf16, 1>(backward, x, g, N, H, W, C, Ho, Wo, out, st_);
     } else {
-        const unsigned gr = grid_for((long)N * H * W * C);
-        DISPATCH_T(bf16, hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(gr), dim3(256), 0, st_, (const float*)x, (const float*)g, N, H, W, C, Ho, Wo, (float*)out),
-                   hipLaunchKernelGGL(maxpool_bwd_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, (const __bf16*)x, (const __bf16*)g, N, H, W, C, Ho, Wo, (__bf16*)out));
+        if (C % 4 == 0) maxpool_t<float, 4>(backward, x, g, N, H, W, C, Ho, Wo, out, st_);
+        else maxpool_t<float, 1>(backward, x, g, N, H, W, C, Ho, Wo, out, st_);
     }
     return hipGetLastError();
+}
+
+template <typename T, int VC>
+static void bilinear_t(int backward, const void* src, int N, int H, int W, int C, int Ho, int Wo, int align, void* dst,
+                       hipStream_t st_) {
+    if (!backward)
+        hipLaunchKernelGGL((bilinear_fwd_kernel<T, VC>), dim3(grid_for((long)N * Ho * Wo * (C / VC))), dim3(256), 0, st_, (const T*)src, N,
+                           H, W, C, Ho, Wo, align, (T*)dst);
+    else
+        hipLaunchKernelGGL((bilinear_bwd_kernel<T, VC>), dim3(grid_for((long)N * H * W * (C / VC))), dim3(256), 0, st_, (const T*)src, N, H,
+                           W, C, Ho, Wo, align, (T*)dst);
 }
 
 hipError_t launch_bilinear(int bf16, int backward, const void* src, int N, int H, int W, int C, int Ho, int Wo, int align,
                            void* dst, hipStream_t st_) {
     // forward: src [N,H,W,C] -> dst [N,Ho,Wo,C];  backward: src = grad [N,Ho,Wo,C] -> dst = grad_x [N,H,W,C]
-    if (!backward) {
-        const unsigned gr = grid_for((long)N * Ho * Wo * C);
-        DISPATCH_T(bf16, hipLaunchKernelGGL(bilinear_fwd_kernel<float>, dim3(gr), dim3(256), 0, st_, (const float*)src, N, H, W, C, Ho, Wo, align, (float*)dst),
-                   hipLaunchKernelGGL(bilinear_fwd_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, (const __bf16*)src, N, H, W, C, Ho, Wo, align, (__bf16*)dst));
+    if (bf16) {
+        if (C % 8 == 0) bilinear_t<__bf16, 8>(backward, src, N, H, W, C, Ho, Wo, align, dst, st_);
+        else bilinear_t<__bf16, 1>(backward, src, N, H, W, C, Ho, Wo, align, dst, st_);
     } else {
-        const unsigned gr = grid_for((long)N * H * W * C);
-        DISPATCH_T(bf16, hipLaunchKernelGGL(bilinear_bwd_kernel<float>, dim3(gr), dim3(256), 0, st_, (const float*)src, N, H, W, C, Ho, Wo, align, (float*)dst),
-                   hipLaunchKernelGGL(bilinear_bwd_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, (const __bf16*)src, N, H, W, C, Ho, Wo, align, (__bf16*)dst));
+        if (C % 4 == 0) bilinear_t<float, 4>(backward, src, N, H, W, C, Ho, Wo, align, dst, st_);
+        else bilinear_t<float, 1>(backward, src, N, H, W, C, Ho, Wo, align, dst, st_);
     }
     return hipGetLastError();
 }
