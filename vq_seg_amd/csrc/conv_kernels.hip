@@ -63,8 +63,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int B_CHUNKS = BN * B_CPR * (PRECISE ? 2 : 1);
     constexpr int B_PER_THREAD = (B_CHUNKS + 255) / 256;
 
+    constexpr int STAGE_ELEMS = (BM + BN) * BKP * (PRECISE ? 2 : 1);    // bf16 elements of one LDS stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __bf16* As_hi = reinterpret_cast<__bf16*>(smem);
+    __bf16* As_hi = reinterpret_cast<__bf16*>(smem);                   // stage 0; stage 1 at + STAGE_ELEMS
     __bf16* As_lo = As_hi + (PRECISE ? BM * BKP : 0);
     __bf16* Bs_hi = As_lo + BM * BKP;
     __bf16* Bs_lo = Bs_hi + (PRECISE ? BN * BKP : 0);
@@ -110,10 +111,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int n_stage = n_taps * chunks_per_tap;
     const long w_row = (long)n_taps * cin_p;              // packed weight row length (bf16 elements)
 
-    u32x4 a_reg[A_PASSES];
-    u32x4 b_reg[B_PER_THREAD];
+    // ---- software pipeline: global loads run TWO stages ahead (two register sets), LDS is double buffered,
+    //      one barrier per stage:   iteration s:  issue loads(s+2) | MFMAs on LDS[s&1] | regs(s+1) -> LDS[(s+1)&1] | barrier
+    u32x4 a_r0[A_PASSES], a_r1[A_PASSES];
+    u32x4 b_r0[B_PER_THREAD], b_r1[B_PER_THREAD];
 
-    auto load_stage = [&](int s) {
+    auto load_stage = [&](int s, u32x4 (&a_reg)[A_PASSES], u32x4 (&b_reg)[B_PER_THREAD]) {
         const int tap = s / chunks_per_tap;
         const int ci0 = (s - tap * chunks_per_tap) * BK;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
@@ -163,7 +166,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         }
     };
 
-    auto store_stage = [&]() {
+    auto store_stage = [&](int buf, const u32x4 (&a_reg)[A_PASSES], const u32x4 (&b_reg)[B_PER_THREAD]) {
+        __bf16* Ah = As_hi + buf * STAGE_ELEMS;
+        __bf16* Al = As_lo + buf * STAGE_ELEMS;
+        __bf16* Bh = Bs_hi + buf * STAGE_ELEMS;
+        __bf16* Bl = Bs_lo + buf * STAGE_ELEMS;
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             const int row = a_row0 + A_RPP * i;
@@ -174,10 +181,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                 hi[1] = pack2(f[2], f[3]);
                 lo[0] = pack2(f[0] - bf16_round(f[0]), f[1] - bf16_round(f[1]));
                 lo[1] = pack2(f[2] - bf16_round(f[2]), f[3] - bf16_round(f[3]));
-                *reinterpret_cast<u32x2*>(As_hi + row * BKP + a_chunk * 4) = hi;
-                *reinterpret_cast<u32x2*>(As_lo + row * BKP + a_chunk * 4) = lo;
+                *reinterpret_cast<u32x2*>(Ah + row * BKP + a_chunk * 4) = hi;
+                *reinterpret_cast<u32x2*>(Al + row * BKP + a_chunk * 4) = lo;
             } else {
-                *reinterpret_cast<u32x4*>(As_hi + row * BKP + a_chunk * 8) = a_reg[i];
+                *reinterpret_cast<u32x4*>(Ah + row * BKP + a_chunk * 8) = a_reg[i];
             }
         }
 #pragma unroll
@@ -187,31 +194,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                 const int arr = PRECISE ? idx / (BN * B_CPR) : 0;
                 const int rem = PRECISE ? idx % (BN * B_CPR) : idx;
                 const int row = rem / B_CPR, ch = rem % B_CPR;
-                __bf16* dst = arr ? Bs_lo : Bs_hi;
+                __bf16* dst = arr ? Bl : Bh;
                 *reinterpret_cast<u32x4*>(dst + row * BKP + ch * 8) = b_reg[i];
             }
         }
     };
 
-    load_stage(0);
-    for (int s = 0; s < n_stage; ++s) {
-        store_stage();
-        __syncthreads();
-        if (s + 1 < n_stage) load_stage(s + 1);
+    auto compute = [&](int buf) {
+        const __bf16* Ah = As_hi + buf * STAGE_ELEMS;
+        const __bf16* Al = As_lo + buf * STAGE_ELEMS;
+        const __bf16* Bh = Bs_hi + buf * STAGE_ELEMS;
+        const __bf16* Bl = Bs_lo + buf * STAGE_ELEMS;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             bf16x8 a_hi[MT], a_lo[MT], b_hi[NTT], b_lo[NTT];
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int row = (wm * MT + a) * 32 + r;
-                a_hi[a] = *reinterpret_cast<const bf16x8*>(As_hi + row * BKP + kk * 16 + h * 8);
-                if (PRECISE) a_lo[a] = *reinterpret_cast<const bf16x8*>(As_lo + row * BKP + kk * 16 + h * 8);
+                a_hi[a] = *reinterpret_cast<const bf16x8*>(Ah + row * BKP + kk * 16 + h * 8);
+                if (PRECISE) a_lo[a] = *reinterpret_cast<const bf16x8*>(Al + row * BKP + kk * 16 + h * 8);
             }
 #pragma unroll
             for (int b = 0; b < NTT; ++b) {
                 const int row = (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
-                b_hi[b] = *reinterpret_cast<const bf16x8*>(Bs_hi + row * BKP + kk * 16 + h * 8);
-                if (PRECISE) b_lo[b] = *reinterpret_cast<const bf16x8*>(Bs_lo + row * BKP + kk * 16 + h * 8);
+                b_hi[b] = *reinterpret_cast<const bf16x8*>(Bh + row * BKP + kk * 16 + h * 8);
+                if (PRECISE) b_lo[b] = *reinterpret_cast<const bf16x8*>(Bl + row * BKP + kk * 16 + h * 8);
             }
 #pragma unroll
             for (int a = 0; a < MT; ++a)
@@ -224,29 +231,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[a], b_hi[b], acc[a][b], 0, 0, 0);
                 }
         }
+    };
+
+    load_stage(0, a_r0, b_r0);
+    if (n_stage > 1) load_stage(1, a_r1, b_r1);
+    store_stage(0, a_r0, b_r0);
+    __syncthreads();
+    for (int s = 0; s < n_stage; s += 2) {
+        // even stage s: registers set 0 is free (stored last iteration / prologue), set 1 holds stage s+1
+        if (s + 2 < n_stage) load_stage(s + 2, a_r0, b_r0);
+        compute(0);
+        if (s + 1 < n_stage) store_stage(1, a_r1, b_r1);
+        __syncthreads();
+        if (s + 1 >= n_stage) break;
+        // odd stage s+1
+        if (s + 3 < n_stage) load_stage(s + 3, a_r1, b_r1);
+        compute(1);
+        if (s + 2 < n_stage) store_stage(0, a_r0, b_r0);
         __syncthreads();
     }
 
-    // ---- epilogue: store Y (row = pixel, lane column = output channel) and the per-wave BN partials
+    // ---- epilogue: per-wave BN partials from the accumulators, then Y through LDS as 16-byte row segments
     const long wrow0 = m0 + (long)wm * MT * 32;
+    if (p.stat_partial) {
 #pragma unroll
-    for (int b = 0; b < NTT; ++b) {
-        const int co = co0 + (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
-        const bool cok = co < p.Cout;
-        float sum = 0.0f;
+        for (int b = 0; b < NTT; ++b) {
+            const int co = co0 + (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
+            const bool cok = co < p.Cout;
+            float sum = 0.0f;
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+            for (int a = 0; a < MT; ++a)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const float v = acc[a][b][i];
-                if (m < M && cok) {
-                    if (PRECISE) reinterpret_cast<float*>(p.y)[m * p.Cout + co] = v;
-                    else reinterpret_cast<__bf16*>(p.y)[m * p.Cout + co] = (__bf16)v;
-                    sum += v;
+                for (int i = 0; i < 16; ++i) {
+                    const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (m < M) sum += acc[a][b][i];
                 }
-            }
-        if (p.stat_partial) {
             long cnt_l = M - wrow0;
             const float cnt = (float)(cnt_l < 0 ? 0 : (cnt_l > MT * 32 ? MT * 32 : cnt_l));
             sum += __shfl_xor(sum, 32);
@@ -266,6 +285,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                 p.stat_partial[(slot * 2 + 0) * p.Cout + co] = mean;
                 p.stat_partial[(slot * 2 + 1) * p.Cout + co] = m2;
             }
+        }
+    }
+    constexpr int O_EPC = PRECISE ? 4 : 8;                  // output elements per 16-byte store
+    if (p.Cout % O_EPC == 0) {
+        // the main loop's last barrier has passed: LDS is free.  Tile [BM][BN] of the output element type.
+        constexpr int OS = BN + O_EPC;                      // row stride (elements) -- padded against bank conflicts
+        char* ot = smem;
+#pragma unroll
+        for (int b = 0; b < NTT; ++b) {
+            const int col = (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (wm * MT + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (PRECISE) reinterpret_cast<float*>(ot)[row * OS + col] = acc[a][b][i];
+                    else reinterpret_cast<__bf16*>(ot)[row * OS + col] = (__bf16)acc[a][b][i];
+                }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / O_EPC;                     // 16-byte chunks per tile row
+        for (int idx = tid; idx < BM * CPR; idx += 256) {
+            const int row = idx / CPR, ch = idx % CPR;
+            const long m = m0 + row;
+            const int co = co0 + ch * O_EPC;
+            if (m < M && co < p.Cout) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(ot + ((size_t)row * OS + ch * O_EPC) * (PRECISE ? 4 : 2));
+                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.y) + (m * p.Cout + co) * (PRECISE ? 4 : 2)) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < NTT; ++b) {
+            const int co = co0 + (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (m < M && co < p.Cout) {
+                        if (PRECISE) reinterpret_cast<float*>(p.y)[m * p.Cout + co] = acc[a][b][i];
+                        else reinterpret_cast<__bf16*>(p.y)[m * p.Cout + co] = (__bf16)acc[a][b][i];
+                    }
+                }
         }
     }
 }
@@ -308,7 +371,9 @@ __global__ __launch_bounds__(256) void conv_pack_weights(const float* __restrict
 template <int BN, bool PRECISE, int BK>
 static void launch_t(const ConvArgs& a, hipStream_t st) {
     constexpr int BKP = BK + 8;
-    const size_t lds = (size_t)(BM + BN) * BKP * 2 * (PRECISE ? 2 : 1);
+    size_t lds = (size_t)(BM + BN) * BKP * 2 * (PRECISE ? 2 : 1) * 2;                 // two stages
+    const size_t out_tile = (size_t)BM * (BN + (PRECISE ? 4 : 8)) * (PRECISE ? 4 : 2);  // epilogue staging tile
+    if (out_tile > lds) lds = out_tile;
     const long M = (long)a.N * a.Ho * a.Wo;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN));
     hipLaunchKernelGGL((conv_igemm_kernel<BN, PRECISE, BK>), grid, dim3(256), lds, st, a);

@@ -137,7 +137,29 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
                                                        long M, int C, int relu, T* __restrict__ out) {
     constexpr int V = VecN<T>::N;
     const long total = M * C;
-    if (C % V == 0) {
+    if (C % V == 0 && (256 * V) % C == 0) {
+        // the per-thread channel offset is invariant under the grid stride: keep scale/shift in registers
+        const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * V;
+        const int c = (int)(i0 % C);
+        float sc[V], sh[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            sc[e] = scale[c + e];
+            sh[e] = shift[c + e];
+        }
+        for (long i = i0; i < total; i += (long)gridDim.x * 256 * V) {
+            float v[V], r[V];
+            ldv(y, i, v);
+            if (res) ldv(res, i, r);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float t = __builtin_fmaf(v[e], sc[e], sh[e]);
+                if (res) t += r[e];
+                v[e] = (relu && !(t > 0.0f)) ? 0.0f : t;
+            }
+            stv(out, i, v);
+        }
+    } else if (C % V == 0) {
         for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * V; i < total; i += (long)gridDim.x * 256 * V) {
             const int c = (int)(i % C);
             float v[V], r[V];
@@ -145,7 +167,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
             if (res) ldv(res, i, r);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                float t = v[e] * scale[c + e] + shift[c + e];
+                float t = __builtin_fmaf(v[e], scale[c + e], shift[c + e]);
                 if (res) t += r[e];
                 v[e] = (relu && !(t > 0.0f)) ? 0.0f : t;
             }
@@ -287,7 +309,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            long M, int C, int relu, T* __restrict__ g_y, T* __restrict__ g_res) {
     constexpr int V = VecN<T>::N;
     const long total = M * C;
-    if (C % V == 0) {
+    if (C % V == 0 && (256 * V) % C == 0) {
+        const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * V;
+        const int c = (int)(i0 % C);
+        float mu[V], is[V], k0[V], k1[V], k2[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            mu[e] = mean[c + e];
+            is[e] = invstd[c + e];
+            k0[e] = coef[c + e];
+            k1[e] = coef[C + c + e];
+            k2[e] = coef[2 * C + c + e];
+        }
+        for (long i = i0; i < total; i += (long)gridDim.x * 256 * V) {
+            float g[V], o[V], yy[V], r[V];
+            ldv(g_out, i, g);
+            ldv(y, i, yy);
+            if (relu) ldv(out, i, o);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float gz = (relu && !(o[e] > 0.0f)) ? 0.0f : g[e];
+                const float xh = (yy[e] - mu[e]) * is[e];
+                r[e] = gz;
+                g[e] = k0[e] * (gz - k1[e] - xh * k2[e]);
+            }
+            stv(g_y, i, g);
+            if (g_res) stv(g_res, i, r);
+        }
+    } else if (C % V == 0) {
         for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * V; i < total; i += (long)gridDim.x * 256 * V) {
             const int c = (int)(i % C);
             float g[V], o[V], yy[V], r[V];

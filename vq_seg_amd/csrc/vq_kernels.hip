@@ -419,13 +419,19 @@ __global__ __launch_bounds__(64) void km_lists_kernel(const long long* __restric
 __global__ __launch_bounds__(256) void km_sums_kernel(const float* __restrict__ samples, int C,
                                                       const int* __restrict__ offsets, const int* __restrict__ members,
                                                       float* __restrict__ sums) {
+    // block = (cluster k, 64-channel group); 4 waves stride the member list (wave w takes members w, w+4, ...);
+    // each lane owns one channel; the 4 partial sums are combined in wave order: deterministic.
     const int k = blockIdx.x;
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= C) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
     const int b = offsets[k], e = offsets[k + 1];
     float s = 0.0f;
-    for (int m = b; m < e; ++m) s += samples[(size_t)members[m] * C + c];   // row order
-    sums[(size_t)k * C + c] = s;
+    if (c < C)
+        for (int m = b + wave; m < e; m += 4) s += samples[(size_t)members[m] * C + c];
+    __shared__ float sh[4][64];
+    sh[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < C) sums[(size_t)k * C + c] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
 }
 
 __global__ __launch_bounds__(256) void km_counts64_kernel(const int* __restrict__ counts, int K, long long* __restrict__ out) {
@@ -636,7 +642,7 @@ hipError_t launch_km_accumulate(const float* samples, const float* means, int64_
     hipLaunchKernelGGL(km_scan_kernel, dim3(1), dim3(1024), 0, st, counts, K, offsets);
     hipLaunchKernelGGL(km_lists_kernel, dim3(K), dim3(64), 0, st, reinterpret_cast<const long long*>(idx), (long)N,
                        offsets, members);
-    hipLaunchKernelGGL(km_sums_kernel, dim3(K, (C + 255) / 256), dim3(256), 0, st, samples, C, offsets, members, sums);
+    hipLaunchKernelGGL(km_sums_kernel, dim3(K, (C + 63) / 64), dim3(256), 0, st, samples, C, offsets, members, sums);
     hipLaunchKernelGGL(km_counts64_kernel, dim3((K + 255) / 256), dim3(256), 0, st, counts, K,
                        reinterpret_cast<long long*>(counts64));
     return hipGetLastError();
