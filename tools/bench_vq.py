@@ -31,8 +31,9 @@ def main():
                           ("L2 1024^2 K=1024", B * 16384 // 4, 512, 1024)]:
         x = torch.relu(torch.randn(n, c, device=dev))
         W = torch.relu(torch.randn(k, c, device=dev))
-        t_as = timeit(lambda: _hip.vq_assign(x, W))
-        t_fw = timeit(lambda: _hip.vq_forward(x, W, True, 1.0))
+        prep = _hip.vq_prepare(W)
+        t_as = timeit(lambda: _hip.vq_assign(x, W, prepared=prep))
+        t_fw = timeit(lambda: _hip.vq_forward(x, W, True, 1.0, prepared=prep))
         flops = 2.0 * n * k * c
         byts = n * (c * 4 * 2 + 8)
         print(f"{name:18s} N={n:7d} C={c:4d} K={k:4d}  assign {t_as*1e3:8.1f} us  {flops/t_as/1e9:7.1f} TF/s "

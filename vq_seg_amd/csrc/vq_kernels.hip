@@ -26,6 +26,7 @@
 //   idx        = lowest k attaining min d
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "vq_kernels.h"
 
@@ -115,18 +116,18 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const float* __re
     constexpr int JB = BK / 8;                   // 8-channel blocks per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Bs = reinterpret_cast<float*>(smem);                 // [2][BK/4][CODES][4]
-    float* xn_s = Bs + 2 * STAGE_FLOATS;                        // [WAVES][32]
+    float* xn_s = Bs + 2 * STAGE_FLOATS + 256;                  // [WAVES][32]  (after the key scratch, which aliases Bs)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    const int n_stage = (Cp + BK - 1) / BK;
+    const int code0 = blockIdx.y * CODES;
     const long row0 = (long)blockIdx.x * ROWS_PER_WG + wave * ROWS_PER_WAVE;
     long row = row0 + r;
     if (row > N - 1) row = N - 1;                               // clamp: loads stay in bounds
     const float* xrow = x + row * (long)C + 4 * h;
-    const int code0 = blockIdx.y * CODES;
-    const int n_stage = (Cp + BK - 1) / BK;
 
     f32x16 acc[T];
 #pragma unroll
@@ -159,8 +160,14 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const float* __re
         }
     };
 
+    // Software pipeline (one barrier per stage, no exposed LDS latency):
+    //   stage s lives in LDS buffer s&1.  B fragments are fetched into registers one 8-channel block AHEAD of the
+    //   MFMAs that consume them, so by the time the stage's last block starts every fragment of the stage is in
+    //   registers: the barrier sits right there, the freed buffer is refilled for stage s+2, and the first block of
+    //   stage s+1 is fetched under the last block's MFMAs.
     f32x4 a_cur[JB], a_nxt[JB];
     fill(0, 0);
+    if (n_stage > 1) fill(1, 1);
     load_a(0, a_cur);
 #pragma unroll
     for (int j = 0; j < JB; ++j) a_nxt[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -168,40 +175,50 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const float* __re
 
     // B fragment of lane (r, h) for block j, tile t: Bs[buf][2j + h][32 t + r][0..3]
     const float* bs_lane = Bs + (h * CODES + r) * 4;
-    int cur = 0;
+    f32x4 b_cur[T], b_nxt[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) b_cur[t] = *reinterpret_cast<const f32x4*>(bs_lane + t * 128);
+
+    auto mfma_block = [&](int j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = a_cur[j][e];
+            xn_part = __builtin_fmaf(a, a, xn_part);
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b_cur[t][e], acc[t], 0, 0, 0);
+        }
+        // issue order: one LDS read per four MFMAs (the reads belong to the NEXT block and are never waited on here)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    };
+
     for (int s = 0; s < n_stage; ++s) {
+        const float* bsrc = bs_lane + (s & 1) * STAGE_FLOATS;
+        if (s + 1 < n_stage) load_a(s + 1, a_nxt);
+#pragma unroll
+        for (int j = 0; j < JB - 1; ++j) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                b_nxt[t] = *reinterpret_cast<const f32x4*>(bsrc + (2 * (j + 1)) * CODES * 4 + t * 128);
+            mfma_block(j);
+#pragma unroll
+            for (int t = 0; t < T; ++t) b_cur[t] = b_nxt[t];
+        }
+        __syncthreads();                                       // stage s+1 landed; nobody reads buffer s&1 any more
+        if (s + 2 < n_stage) fill(s + 2, s & 1);
         if (s + 1 < n_stage) {
-            fill(s + 1, cur ^ 1);
-            load_a(s + 1, a_nxt);
+            const float* bnext = bs_lane + ((s + 1) & 1) * STAGE_FLOATS;
+#pragma unroll
+            for (int t = 0; t < T; ++t) b_nxt[t] = *reinterpret_cast<const f32x4*>(bnext + t * 128);
         }
-        const float* bsrc = bs_lane + cur * STAGE_FLOATS;
-        f32x4 b_cur[T], b_nxt[T];
+        mfma_block(JB - 1);
 #pragma unroll
-        for (int t = 0; t < T; ++t) b_cur[t] = *reinterpret_cast<const f32x4*>(bsrc + t * 128);
-#pragma unroll
-        for (int j = 0; j < JB; ++j) {
-            if (j + 1 < JB) {
-#pragma unroll
-                for (int t = 0; t < T; ++t)
-                    b_nxt[t] = *reinterpret_cast<const f32x4*>(bsrc + (2 * (j + 1)) * CODES * 4 + t * 128);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a = a_cur[j][e];
-                xn_part = __builtin_fmaf(a, a, xn_part);
-#pragma unroll
-                for (int t = 0; t < T; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b_cur[t][e], acc[t], 0, 0, 0);
-            }
-            if (j + 1 < JB) {
-#pragma unroll
-                for (int t = 0; t < T; ++t) b_cur[t] = b_nxt[t];
-            }
-        }
+        for (int t = 0; t < T; ++t) b_cur[t] = b_nxt[t];
 #pragma unroll
         for (int j = 0; j < JB; ++j) a_cur[j] = a_nxt[j];
-        __syncthreads();                                       // next buffer landed; this one is free
-        cur ^= 1;
     }
 
     // ---- epilogue: distances -> (min, code) per row over this workgroup's codes
@@ -218,11 +235,16 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const float* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e) xnr[4 * g + e] = v[e];
     }
-    float best_d[16];
+    // Running per-lane minimum in SQUARED-distance space; the reference argmins over sqrt(d2), whose rounding can
+    // collapse nearly equal d2 into one float (then the LOWER index wins).  A candidate within 2^-20 relative of the
+    // holder therefore takes the exact path (compare correctly-rounded square roots); everything else is decided
+    // on d2 alone.  Codes arrive in increasing index order per lane, so "keep the holder on a tie" is the tie rule.
+    float best2[16], bthr[16];
     int best_i[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        best_d[i] = __builtin_inff();
+        best2[i] = __builtin_inff();
+        bthr[i] = __builtin_inff();
         best_i[i] = 0x7fffffff;
     }
 #pragma unroll
@@ -231,43 +253,48 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const float* __re
         const float en = enorm[code];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            float d = __builtin_fmaf(-2.0f, acc[t][i], xnr[i]);
-            d = d + en;
-            d = __builtin_fmaxf(d, 0.0f);
-            d = __builtin_sqrtf(d);
-            if (d < best_d[i]) {
-                best_d[i] = d;
-                best_i[i] = code;
+            float d2 = __builtin_fmaf(-2.0f, acc[t][i], xnr[i]);
+            d2 = d2 + en;
+            d2 = __builtin_fmaxf(d2, 0.0f);
+            const bool clear = d2 < bthr[i];                                   // better by more than the collapse band
+            const bool near = !clear && d2 < best2[i];                         // inside the band: rare
+            if (__builtin_expect(__any(near), 0)) {
+                if (near) {
+                    const bool better = __builtin_sqrtf(d2) < __builtin_sqrtf(best2[i]);
+                    best_i[i] = better ? code : best_i[i];
+                    best2[i] = d2;                                             // same sqrt class or better: safe to lower
+                    bthr[i] = d2 * 0.99999905f;
+                }
             }
+            best_i[i] = clear ? code : best_i[i];
+            best2[i] = clear ? d2 : best2[i];
+            bthr[i] = clear ? d2 * 0.99999905f : bthr[i];
         }
     }
-    // reduce over the 32 lanes of each half (codes live on lanes); lowest code wins ties
+    // ---- merge the 32 code lanes of each half: keys (float_bits(sqrt d2) << 32 | code) through LDS, 2 lanes per row
+    // (the B stage buffers are free: after the last stage barrier every fragment lives in registers)
+    unsigned long long* ks = reinterpret_cast<unsigned long long*>(Bs) + wave * (32 * 33);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        float d = best_d[i];
-        int k = best_i[i];
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) {
-            const float od = __shfl_xor(d, m);
-            const int ok = __shfl_xor(k, m);
-            const bool take = (od < d) || (od == d && ok < k);
-            d = take ? od : d;
-            k = take ? ok : k;
-        }
-        best_d[i] = d;
-        best_i[i] = k;
+        const unsigned long long key =
+            ((unsigned long long)__float_as_uint(__builtin_sqrtf(best2[i])) << 32) | (unsigned int)best_i[i];
+        ks[(h * 16 + i) * 33 + r] = key;                                       // row (h, i), candidate lane r
     }
-    // every lane now holds the result of its half's 16 rows; lane r == i publishes row i
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                        // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int rw = lane >> 1, part = lane & 1;                             // rw = h' * 16 + i'
+        unsigned long long m = ~0ull;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        if (r == i) {
-            const long orow = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (orow < N) {
-                const unsigned long long key =
-                    ((unsigned long long)__float_as_uint(best_d[i]) << 32) | (unsigned int)best_i[i];
-                atomicMin(keys + orow, key);
-            }
+        for (int j = 0; j < 16; ++j) {
+            const unsigned long long v = ks[rw * 33 + part * 16 + j];
+            m = v < m ? v : m;
         }
+        const unsigned long long o = __shfl_xor(m, 1);
+        m = o < m ? o : m;
+        const int hh = rw >> 4, ii = rw & 15;
+        const long orow = row0 + (ii & 3) + 8 * (ii >> 2) + 4 * hh;
+        if (part == 0 && orow < N) atomicMin(keys + orow, m);
     }
 }
 
@@ -546,7 +573,8 @@ int profile_collect(int max_records, int64_t* n, int* c, int* k, float* ms) {
 template <int T>
 static void launch_assign_t(const float* x, const float* E4, const float* en, int64_t N, int C, int Kp,
                             unsigned long long* keys, hipStream_t st) {
-    const size_t lds = (size_t)(2 * STAGE_FLOATS + WAVES * 32) * sizeof(float);
+    static_assert((size_t)WAVES * 32 * 33 * sizeof(unsigned long long) <= (2 * STAGE_FLOATS + 256) * sizeof(float), "key scratch aliases the B stages");
+    const size_t lds = (size_t)(2 * STAGE_FLOATS + 256 + WAVES * 32) * sizeof(float);
     const dim3 grid((unsigned)((N + ROWS_PER_WG - 1) / ROWS_PER_WG), (unsigned)(Kp / (32 * T)));
     hipLaunchKernelGGL(vq_assign_f32_kernel<T>, grid, dim3(256), lds, st, x, E4, en, (long)N, C, C, Kp, keys);
 }
