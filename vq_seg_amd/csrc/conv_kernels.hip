@@ -47,6 +47,97 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i;
 }
 
+// ---- shared epilogue: per-wave BN partials from the accumulators, then Y through LDS as 16-byte row segments
+template <int TBM, int BN, bool PRECISE, int MT, int NTT, int NT, int NTHR>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const ConvArgs& p, char* smem, long M, long m0, int co0,
+                                              int wm, int wn, int r, int h, int tid) {
+    const long wrow0 = m0 + (long)wm * MT * 32;
+    if (p.stat_partial) {
+        // one (mean, M2) partial per SLOT of RPS consecutive rows: 64 rows (two 32-row tiles) or 32 when the wave has one
+        constexpr int TPS = MT >= 2 ? 2 : 1, RPS = TPS * 32;
+#pragma unroll
+        for (int b = 0; b < NTT; ++b) {
+            const int co = co0 + (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
+            const bool cok = co < p.Cout;
+#pragma unroll
+            for (int g = 0; g < MT / TPS; ++g) {
+                const long srow0 = wrow0 + g * RPS;
+                float sum = 0.0f;
+#pragma unroll
+                for (int a = g * TPS; a < (g + 1) * TPS; ++a)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (m < M) sum += acc[a][b][i];
+                    }
+                long cnt_l = M - srow0;
+                const float cnt = (float)(cnt_l < 0 ? 0 : (cnt_l > RPS ? RPS : cnt_l));
+                sum += __shfl_xor(sum, 32);
+                const float mean = cnt > 0.f ? sum / cnt : 0.f;
+                float m2 = 0.0f;
+#pragma unroll
+                for (int a = g * TPS; a < (g + 1) * TPS; ++a)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        const float d = acc[a][b][i] - mean;
+                        if (m < M) m2 = __builtin_fmaf(d, d, m2);
+                    }
+                m2 += __shfl_xor(m2, 32);
+                if (h == 0 && cok) {
+                    const long slot = srow0 / RPS;                        // global slot index along M
+                    p.stat_partial[(slot * 2 + 0) * p.Cout + co] = mean;
+                    p.stat_partial[(slot * 2 + 1) * p.Cout + co] = m2;
+                }
+            }
+        }
+    }
+    constexpr int O_EPC = PRECISE ? 4 : 8;                  // output elements per 16-byte store
+    if (p.Cout % O_EPC == 0) {
+        // the main loop's last barrier has passed: LDS is free.  Tile [BM][BN] of the output element type.
+        constexpr int OS = BN + O_EPC;                      // row stride (elements) -- padded against bank conflicts
+        char* ot = smem;
+#pragma unroll
+        for (int b = 0; b < NTT; ++b) {
+            const int col = (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (wm * MT + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (PRECISE) reinterpret_cast<float*>(ot)[row * OS + col] = acc[a][b][i];
+                    else reinterpret_cast<__bf16*>(ot)[row * OS + col] = (__bf16)acc[a][b][i];
+                }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / O_EPC;                     // 16-byte chunks per tile row
+        for (int idx = tid; idx < TBM * CPR; idx += NTHR) {
+            const int row = idx / CPR, ch = idx % CPR;
+            const long m = m0 + row;
+            const int co = co0 + ch * O_EPC;
+            if (m < M && co < p.Cout) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(ot + ((size_t)row * OS + ch * O_EPC) * (PRECISE ? 4 : 2));
+                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.y) + (m * p.Cout + co) * (PRECISE ? 4 : 2)) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < NTT; ++b) {
+            const int co = co0 + (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (m < M && co < p.Cout) {
+                        if (PRECISE) reinterpret_cast<float*>(p.y)[m * p.Cout + co] = acc[a][b][i];
+                        else reinterpret_cast<__bf16*>(p.y)[m * p.Cout + co] = (__bf16)acc[a][b][i];
+                    }
+                }
+        }
+    }
+}
+
 template <int BN, bool PRECISE, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int BKP = BK + 8;                          // bf16 elements per LDS row (16-byte pad)
@@ -116,10 +207,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     u32x4 a_r0[A_PASSES], a_r1[A_PASSES];
     u32x4 b_r0[B_PER_THREAD], b_r1[B_PER_THREAD];
 
+    // pixel offset (in pixels, -1 = padding / out of range) of each of this thread's rows for the CURRENT tap;
+    // recomputed only when the tap changes (every chunks_per_tap stages)
+    long a_pix[A_PASSES];
+    int cur_tap = -1;
+    auto set_tap = [&](int tap) {
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            int ih = a_oh[i] * p.stride - p.pad + kh;
+            int iw = a_ow[i] * p.stride - p.pad + kw;
+            bool ok = a_ok[i];
+            if (p.reflect) {
+                ih = reflect_idx(ih, p.H * p.up);
+                iw = reflect_idx(iw, p.W * p.up);
+            }
+            if (p.up == 2) {                                 // dilated input grid (stride-2 data gradient)
+                ok = ok && ih >= 0 && iw >= 0 && !((ih | iw) & 1);
+                ih >>= 1;
+                iw >>= 1;
+            }
+            ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            a_pix[i] = ok ? ((long)a_n[i] * p.H + ih) * p.W + iw : -1;
+        }
+        cur_tap = tap;
+    };
+
     auto load_stage = [&](int s, u32x4 (&a_reg)[A_PASSES], u32x4 (&b_reg)[B_PER_THREAD]) {
         const int tap = s / chunks_per_tap;
         const int ci0 = (s - tap * chunks_per_tap) * BK;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        if (tap != cur_tap) set_tap(tap);
         // which source tensor holds this thread's 16-byte chunk (concat fusion): [0, C1) -> x, [C1, Cin) -> x2
         const int cg = ci0 + a_chunk * A_EPC;              // global input channel of the chunk
         const bool second = cg >= p.C1;
@@ -129,24 +246,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         const bool c_ok = cg < p.Cin;
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
-            int ih = a_oh[i] * p.stride - p.pad + kh;
-            int iw = a_ow[i] * p.stride - p.pad + kw;
-            bool ok = a_ok[i] && c_ok;
-            if (p.reflect) {
-                ih = reflect_idx(ih, p.H * p.up);
-                iw = reflect_idx(iw, p.W * p.up);
-            }
-            if (p.up > 1) {                                  // dilated input grid (stride-2 data gradient)
-                ok = ok && (ih % p.up == 0) && (iw % p.up == 0) && ih >= 0 && iw >= 0;
-                ih /= p.up;
-                iw /= p.up;
-            }
-            ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) {
-                const long off = (((long)a_n[i] * p.H + ih) * p.W + iw) * csrc + cbase;
-                v = *reinterpret_cast<const u32x4*>(src + off * (PRECISE ? 4 : 2));
-            }
+            if (c_ok && a_pix[i] >= 0) v = *reinterpret_cast<const u32x4*>(src + (a_pix[i] * csrc + cbase) * (PRECISE ? 4 : 2));
             a_reg[i] = v;
         }
 #pragma unroll
@@ -251,86 +352,204 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: per-wave BN partials from the accumulators, then Y through LDS as 16-byte row segments
-    const long wrow0 = m0 + (long)wm * MT * 32;
-    if (p.stat_partial) {
+    conv_epilogue<BM, BN, PRECISE, MT, NTT, NT, 256>(acc, p, smem, M, m0, co0, wm, wn, r, h, tid);
+}
+
+// =====================================================================================================
+// Fast-mode (bf16) convolution with LDS-DMA staging.
+//
+// The register-staged kernel above is LDS-bound in bf16 mode: every stage pushes 32 KiB through the ds_write
+// path (~79 B/clk/CU) on top of 64 KiB of fragment reads.  Here both operand tiles go global -> LDS directly
+// (global_load_lds_dwordx4: no VGPR staging, no ds_write), which leaves only the fragment reads on the LDS.
+//   * LDS image: [row][64 bf16] = 128-byte rows, UNPADDED (a wave-instruction writes 1 KiB = 8 whole rows,
+//     lane l -> row l>>3, 16-byte slot l&7), XOR-swizzled through the SOURCE address: slot p of row R holds
+//     channel chunk c = p ^ ((R >> 1) & 7); readers apply the same XOR.  With two rows per 256-byte bank row this
+//     makes every 16-lane ds_read_b128 group hit 16 distinct slots (conflict-free).
+//   * zero padding / out-of-range rows / channels read a 256-byte zero page in the code object.
+//   * double-buffered stages, one barrier per stage, the next stage's DMA issued before the current MFMAs.
+// Requires every tap's channel range to be whole 64-channel chunks (Cin % 64 == 0, concat split % 64 == 0).
+// =====================================================================================================
+__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
+
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int TBM, int BN, int NW, int NBUF>
+__global__ __launch_bounds__(NW * 64) void conv_igemm_glds_kernel(const ConvArgs p) {
+    constexpr int BK = 64;
+    // wave grid WM x WN over the TBM x BN tile; wave tile (MT*32) x (NT*32)
+    constexpr int WN = (BN >= 256) ? 4 : (BN >= 64 ? 2 : 1);
+    constexpr int WM = NW / WN;
+    constexpr int MT = TBM / (WM * 32);
+    constexpr int NT = (BN >= 64) ? BN / (WN * 32) : 1;
+    constexpr int NTT = NT;
+    constexpr int STAGE_BYTES = (TBM + BN) * BK * 2;
+    constexpr int A_INSTR = TBM / 8 / NW;                // wave-instructions per wave for the A tile (8 rows each)
+    constexpr int B_ROWS_PER_WAVE = BN / NW;
+    constexpr int B_INSTR = (B_ROWS_PER_WAVE + 7) / 8;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+
+    const long M = (long)p.N * p.Ho * p.Wo;
+    const long m0 = (long)blockIdx.x * TBM;
+    const int co0 = blockIdx.y * BN;
+
+    // ---- this lane's A rows: instruction i of this wave covers tile rows 8*(A_INSTR*wave + i) .. +7; lane -> row l>>3
+    const int slot = lane & 7;
+    int a_n[A_INSTR], a_oh[A_INSTR], a_ow[A_INSTR], a_chunk[A_INSTR];
+    bool a_ok[A_INSTR];
 #pragma unroll
-        for (int b = 0; b < NTT; ++b) {
-            const int co = co0 + (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
-            const bool cok = co < p.Cout;
-            float sum = 0.0f;
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (m < M) sum += acc[a][b][i];
-                }
-            long cnt_l = M - wrow0;
-            const float cnt = (float)(cnt_l < 0 ? 0 : (cnt_l > MT * 32 ? MT * 32 : cnt_l));
-            sum += __shfl_xor(sum, 32);
-            const float mean = cnt > 0.f ? sum / cnt : 0.f;
-            float m2 = 0.0f;
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    const float d = acc[a][b][i] - mean;
-                    if (m < M) m2 = __builtin_fmaf(d, d, m2);
-                }
-            m2 += __shfl_xor(m2, 32);
-            if (h == 0 && cok) {
-                const long slot = (long)blockIdx.x * WM + wm;             // partial index along M
-                p.stat_partial[(slot * 2 + 0) * p.Cout + co] = mean;
-                p.stat_partial[(slot * 2 + 1) * p.Cout + co] = m2;
-            }
-        }
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int trow = 8 * (A_INSTR * wave + i) + (lane >> 3);
+        long m = m0 + trow;
+        a_ok[i] = m < M;
+        if (!a_ok[i]) m = M - 1;
+        const int n = (int)(m / ((long)p.Ho * p.Wo));
+        const int rem = (int)(m - (long)n * p.Ho * p.Wo);
+        a_n[i] = n;
+        a_oh[i] = rem / p.Wo;
+        a_ow[i] = rem - a_oh[i] * p.Wo;
+        a_chunk[i] = slot ^ ((trow >> 1) & 7);           // channel chunk (8 bf16) this lane fetches for its slot
     }
-    constexpr int O_EPC = PRECISE ? 4 : 8;                  // output elements per 16-byte store
-    if (p.Cout % O_EPC == 0) {
-        // the main loop's last barrier has passed: LDS is free.  Tile [BM][BN] of the output element type.
-        constexpr int OS = BN + O_EPC;                      // row stride (elements) -- padded against bank conflicts
-        char* ot = smem;
+    // ---- this lane's B rows (weights): wave w covers tile rows [w * BN/NW, (w+1) * BN/NW)
+    int b_row[B_INSTR], b_chunk[B_INSTR];
 #pragma unroll
-        for (int b = 0; b < NTT; ++b) {
-            const int col = (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = (wm * MT + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (PRECISE) reinterpret_cast<float*>(ot)[row * OS + col] = acc[a][b][i];
-                    else reinterpret_cast<__bf16*>(ot)[row * OS + col] = (__bf16)acc[a][b][i];
-                }
-        }
-        __syncthreads();
-        constexpr int CPR = BN / O_EPC;                     // 16-byte chunks per tile row
-        for (int idx = tid; idx < BM * CPR; idx += 256) {
-            const int row = idx / CPR, ch = idx % CPR;
-            const long m = m0 + row;
-            const int co = co0 + ch * O_EPC;
-            if (m < M && co < p.Cout) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(ot + ((size_t)row * OS + ch * O_EPC) * (PRECISE ? 4 : 2));
-                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.y) + (m * p.Cout + co) * (PRECISE ? 4 : 2)) = v;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int b = 0; b < NTT; ++b) {
-            const int co = co0 + (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (m < M && co < p.Cout) {
-                        if (PRECISE) reinterpret_cast<float*>(p.y)[m * p.Cout + co] = acc[a][b][i];
-                        else reinterpret_cast<__bf16*>(p.y)[m * p.Cout + co] = (__bf16)acc[a][b][i];
-                    }
-                }
-        }
+    for (int i = 0; i < B_INSTR; ++i) {
+        b_row[i] = B_ROWS_PER_WAVE * wave + 8 * i + (lane >> 3);
+        b_chunk[i] = slot ^ ((b_row[i] >> 1) & 7);
     }
+
+    f32x16 acc[MT][NTT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NTT; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+    const int n_taps = p.KH * p.KW;
+    const int cin_p = (p.Cin + 31) / 32 * 32;
+    const int chunks_per_tap = p.Cin / BK;
+    const int n_stage = n_taps * chunks_per_tap;
+    const long w_row = (long)n_taps * cin_p;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    long a_pix[A_INSTR];                                   // pixel offset of this lane's rows for the current tap, -1 = zero
+    int cur_tap = -1;
+    auto set_tap = [&](int tap) {
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            int ih = a_oh[i] * p.stride - p.pad + kh;
+            int iw = a_ow[i] * p.stride - p.pad + kw;
+            bool ok = a_ok[i];
+            if (p.reflect) {
+                ih = reflect_idx(ih, p.H * p.up);
+                iw = reflect_idx(iw, p.W * p.up);
+            }
+            if (p.up == 2) {
+                ok = ok && ih >= 0 && iw >= 0 && !((ih | iw) & 1);
+                ih >>= 1;
+                iw >>= 1;
+            }
+            ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            a_pix[i] = ok ? ((long)a_n[i] * p.H + ih) * p.W + iw : -1;
+        }
+        cur_tap = tap;
+    };
+
+    auto stage = [&](int s, int buf) {
+        char* As = smem + buf * STAGE_BYTES;
+        char* Bs = As + TBM * BK * 2;
+        const int tap = s / chunks_per_tap;
+        const int ci0 = (s - tap * chunks_per_tap) * BK;
+        if (tap != cur_tap) set_tap(tap);
+        const bool second = ci0 >= p.C1;                   // whole stage comes from one source (split % 64 == 0)
+        const char* src = reinterpret_cast<const char*>(second ? p.x2 : p.x);
+        const int csrc = second ? (p.Cin - p.C1) : p.C1;
+        const int cbase = second ? (ci0 - p.C1) : ci0;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const long off = a_pix[i] * csrc + cbase + a_chunk[i] * 8;
+            glds16(a_pix[i] >= 0 ? src + off * 2 : zero, As + (A_INSTR * wave + i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const int co = co0 + b_row[i];
+            const bool ok = co < p.Cout && b_row[i] < B_ROWS_PER_WAVE * (wave + 1);
+            const unsigned short* wp = p.w_hi + (long)co * w_row + (long)tap * cin_p + ci0 + b_chunk[i] * 8;
+            glds16(ok ? reinterpret_cast<const char*>(wp) : zero, Bs + (B_ROWS_PER_WAVE * wave + 8 * i) * 128);
+        }
+    };
+
+    auto compute = [&](int buf) {
+        const char* As = smem + buf * STAGE_BYTES;
+        const char* Bs = As + TBM * BK * 2;
+#pragma unroll(MT * NTT >= 8 ? 1 : 4)
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 af[MT], bfr[NTT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int row = (wm * MT + a) * 32 + r;
+                const int sl = (kk * 2 + h) ^ ((row >> 1) & 7);
+                af[a] = *reinterpret_cast<const bf16x8*>(As + row * 128 + sl * 16);
+            }
+#pragma unroll
+            for (int b = 0; b < NTT; ++b) {
+                const int row = (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
+                const int sl = (kk * 2 + h) ^ ((row >> 1) & 7);
+                bfr[b] = *reinterpret_cast<const bf16x8*>(Bs + row * 128 + sl * 16);
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NTT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    // NBUF-deep ring, DMA NBUF-1 stages ahead, ONE raw barrier per stage and COUNTED vmcnt (never drained in the loop):
+    //   iteration s:  wait until this wave's pieces of stage s have landed (later stages may still fly)  ->  s_barrier
+    //   (everyone's pieces landed, everyone finished the MFMAs of stage s-1, so the slot of stage s-1 is free)  ->  issue
+    //   the DMA of stage s+NBUF-1 into it  ->  MFMAs of stage s.  A slot is read only AFTER wait + barrier.
+    constexpr int G = A_INSTR + B_INSTR;                   // DMA wave-instructions per wave and stage
+    auto wait_in_flight = [&](int stages) {                // s_waitcnt vmcnt(stages * G), expcnt/lgkmcnt untouched
+        if (stages >= 2 && NBUF >= 4) __builtin_amdgcn_s_waitcnt(((2 * G) & 0xF) | (((2 * G) >> 4) << 14) | 0x0F70);
+        else if (stages >= 1 && NBUF >= 3) __builtin_amdgcn_s_waitcnt((G & 0xF) | ((G >> 4) << 14) | 0x0F70);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+    };
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+        if (i < n_stage) stage(i, i);
+    int slot_c = 0, slot_i = NBUF - 1;                     // ring slots of stage s (compute) and s+NBUF-1 (issue)
+    for (int s = 0; s < n_stage; ++s) {
+        const int behind = n_stage - 1 - s;                // stages issued after stage s that may still be in flight
+        wait_in_flight(behind < NBUF - 2 ? behind : NBUF - 2);
+        __builtin_amdgcn_s_barrier();
+        if (s + NBUF - 1 < n_stage) stage(s + NBUF - 1, slot_i);
+        compute(slot_c);
+        slot_c = slot_c == NBUF - 1 ? 0 : slot_c + 1;
+        slot_i = slot_i == NBUF - 1 ? 0 : slot_i + 1;
+    }
+    __syncthreads();                                       // all MFMAs done: LDS is free for the output tile
+    conv_epilogue<TBM, BN, false, MT, NTT, NT, NW * 64>(acc, p, smem, M, m0, co0, wm, wn, r, h, tid);
+}
+
+template <int TBM, int BN, int NW, int NBUF>
+static void launch_glds_t(const ConvArgs& a, hipStream_t st) {
+    size_t lds = (size_t)(TBM + BN) * 64 * 2 * NBUF;                       // the ring slots
+    const size_t out_tile = (size_t)TBM * (BN + 8) * 2;
+    if (out_tile > lds) lds = out_tile;
+    const long M = (long)a.N * a.Ho * a.Wo;
+    dim3 grid((unsigned)((M + TBM - 1) / TBM), (unsigned)((a.Cout + BN - 1) / BN));
+    hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF>), grid, dim3(NW * 64), lds, st, a);
 }
 
 // ------------------------------------------------------------------------------------
@@ -387,9 +606,15 @@ hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
         else if (bn == 64) launch_t<64, true, 32>(a, st);
         else launch_t<32, true, 32>(a, st);
     } else if (k64) {
-        if (bn == 128) launch_t<128, false, 64>(a, st);
-        else if (bn == 64) launch_t<64, false, 64>(a, st);
-        else launch_t<32, false, 64>(a, st);
+        // L2 -> LDS operand traffic bounds this kernel (~35 B/clk/CU): prefer the largest tile that still yields
+        // at least ~2 waves of workgroups over the 256 CUs
+        const long M = (long)a.N * a.Ho * a.Wo;
+        const long t256 = ((M + 255) / 256) * ((a.Cout + 255) / 256), t256x128 = ((M + 255) / 256) * ((a.Cout + 127) / 128);
+        (void)t256;
+        if (a.Cout % 128 == 0 && t256x128 >= 512) launch_glds_t<256, 128, 8, 3>(a, st);
+        else if (bn == 128) launch_glds_t<128, 128, 4, 2>(a, st);
+        else if (bn == 64) launch_glds_t<128, 64, 4, 3>(a, st);
+        else launch_glds_t<128, 32, 4, 3>(a, st);
     } else {
         if (bn == 128) launch_t<128, false, 32>(a, st);
         else if (bn == 64) launch_t<64, false, 32>(a, st);
@@ -487,6 +712,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     constexpr int G_N = (BKM * G_CPR + 255) / 256, A_N = (BKM * A_CPR + 255) / 256;
     u32x4 g_reg[G_N], a_reg[A_N];
 
+    // (n, oh, ow) of each A chunk's pixel row, advanced by BKM rows per stage without divisions
+    int pn[A_N], poh[A_N], pow_[A_N];
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) {
+        const int idx = tid + 256 * i;
+        long m = m_begin + (idx < BKM * A_CPR ? idx / A_CPR : 0);
+        if (m >= M) m = M - 1;
+        pn[i] = (int)(m / ((long)p.Ho * p.Wo));
+        const int rem = (int)(m - (long)pn[i] * p.Ho * p.Wo);
+        poh[i] = rem / p.Wo;
+        pow_[i] = rem - poh[i] * p.Wo;
+    }
+    auto advance_rows = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_N; ++i) {
+            pow_[i] += BKM;
+            while (pow_[i] >= p.Wo) {
+                pow_[i] -= p.Wo;
+                if (++poh[i] >= p.Ho) {
+                    poh[i] = 0;
+                    ++pn[i];
+                }
+            }
+        }
+    };
+
     auto load_stage = [&](long mb) {
 #pragma unroll
         for (int i = 0; i < G_N; ++i) {
@@ -513,9 +764,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
                 const int csrc = second ? (p.Cin - p.C1) : p.C1;
                 const int cbase = second ? (cg - p.C1) : cg;
                 if (m < m_end && cg < p.Cin) {
-                    const int n = (int)(m / ((long)p.Ho * p.Wo));
-                    const int rem = (int)(m - (long)n * p.Ho * p.Wo);
-                    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                    const int n = pn[i], oh = poh[i], ow = pow_[i];    // tracked incrementally (advance_rows)
                     int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
                     if (p.reflect) {
                         ih = reflect_idx(ih, p.H);
@@ -559,11 +808,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         }
     };
 
-    if (m_begin < m_end) load_stage(m_begin);
+    if (m_begin < m_end) {
+        load_stage(m_begin);
+        advance_rows();
+    }
     for (long mb = m_begin; mb < m_end; mb += BKM) {
         store_stage();
         __syncthreads();
-        if (mb + BKM < m_end) load_stage(mb + BKM);
+        if (mb + BKM < m_end) {
+            load_stage(mb + BKM);
+            advance_rows();
+        }
         if (active) {
 #pragma unroll
             for (int kk = 0; kk < BKM / 16; ++kk) {

@@ -40,7 +40,7 @@ int vqseg_conv_pack_weights_f32(const float* w, int cout, int cin, int kh, int k
 
 int64_t vqseg_conv_stat_slots(int64_t m_rows, int cout) {
     if (m_rows <= 0 || cout <= 0) return 0;
-    return (m_rows + 127) / 128 * conv_wm(cout);
+    return (m_rows + 255) / 256 * (256 / conv_rows_per_slot(cout));       // whole 256-row tiles, 64- or 32-row slots
 }
 
 int vqseg_conv2d_f(const void* x, const void* x2, int c1, const void* w_hi, const void* w_lo, void* y, float* stat_partial,
@@ -54,6 +54,7 @@ int vqseg_conv2d_f(const void* x, const void* x2, int c1, const void* w_hi, cons
     if (c1 <= 0 || c1 > cin || (c1 < cin && (!x2 || c1 % epc || (cin - c1) % epc))) return bad("conv2d: bad channel split");
     if (!a16(x) || !a16(x2) || !a16(w_hi) || !a16(w_lo) || !a16(y)) return bad("conv2d: pointers must be 16-byte aligned");
     if (reflect && (pad >= h * up || pad >= w * up)) return bad("conv2d: reflect padding needs pad < size");
+    if (up != 1 && up != 2) return bad("conv2d: up (input dilation) must be 1 or 2");
     vqseg::ConvArgs a;
     a.x = x; a.x2 = x2; a.C1 = c1;
     a.w_hi = static_cast<const unsigned short*>(w_hi);
@@ -102,7 +103,7 @@ int vqseg_bn_finalize_f(const float* partial, int64_t m_rows, int c, const float
     hipError_t e;
     if (training) {
         if (!partial) return bad("bn_finalize: training mode needs the conv epilogue partials");
-        e = vqseg::launch_bn_finalize(partial, vqseg_conv_stat_slots(m_rows, c), conv_rows_per_slot(c), m_rows, c, gamma, beta,
+        e = vqseg::launch_bn_finalize(partial, (m_rows + conv_rows_per_slot(c) - 1) / conv_rows_per_slot(c), conv_rows_per_slot(c), m_rows, c, gamma, beta,
                                       run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd, st);
     } else {
         if (!run_mean || !run_var) return bad("bn_finalize: eval mode needs running statistics");
