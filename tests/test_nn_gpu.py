@@ -37,6 +37,14 @@ CONV_CASES = [
     (1, 32, 32, 40, 40, 3, 1, 1, False, 0, False),
     (2, 24, 16, 9, 11, 3, 1, 1, False, 32, False),          # odd channel counts (fixture-style decoder)
     (3, 48, 24, 5, 5, 3, 1, 1, False, 0, False),
+    # shapes that take the fused nine-tap weight-gradient kernel (Ho % 4 == 0, Wo % 16 == 0): every (co, ci) tile config
+    (2, 64, 128, 8, 32, 3, 1, 1, True, 0, False),           # 128-wide co tile, 64-wide ci tile, reflect
+    (1, 128, 64, 12, 16, 3, 1, 1, False, 64, False),        # concat 128 + 64, 64-wide co tile
+    (2, 32, 32, 16, 48, 3, 1, 1, False, 0, False),          # 32 x 32
+    (1, 96, 32, 8, 16, 3, 1, 1, False, 32, False),          # split at 96 forces the 32-wide ci tile
+    (2, 64, 32, 20, 16, 3, 1, 1, True, 0, False),
+    (3, 32, 128, 4, 16, 3, 1, 1, False, 0, False),
+    (2, 32, 64, 8, 16, 3, 1, 1, True, 0, False),
 ]
 
 
@@ -118,6 +126,41 @@ def test_conv_bn_act_forward_backward(case, training, mode):
         assert rel(bn_g.running_mean, ref["rm"]) < (1e-5 if mode == "precise" else 1e-2)
         assert rel(bn_g.running_var, ref["rv"]) < (1e-5 if mode == "precise" else 1e-2)
         assert int(bn_g.num_batches_tracked) == int(bn.num_batches_tracked) + 1   # (copied after the CPU forward)
+
+
+WGRAD_CASES = [
+    # n, c1, c2, cout, h, w, reflect
+    (2, 64, 0, 128, 8, 32, True), (3, 128, 64, 64, 12, 16, False), (2, 32, 0, 32, 16, 48, False), (1, 96, 32, 32, 8, 16, False),
+    (2, 64, 0, 32, 20, 16, True), (3, 32, 0, 128, 4, 16, False), (2, 32, 0, 64, 8, 16, True), (5, 256, 256, 128, 16, 16, False),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad3x3_fused_taps(case):
+    """The fused nine-tap bf16 weight-gradient kernel through the C ABI against an fp64 reference on the SAME bf16
+    values: products of bf16 pairs are exact in fp32, so only the accumulation order differs (tolerance 2e-5 of
+    the tensor scale).  Reference: torch.nn.grad.conv2d_weight on the explicitly padded input."""
+    from vq_seg_amd import _hip
+    n, c1, c2, cout, h, w, reflect = case
+    cin = c1 + c2
+    L = _hip.lib()
+    seed = sum(case[:6])
+    x = synth.uniform(seed, (n, h, w, cin), -1, 1).bfloat16()
+    gy = synth.uniform(seed + 1, (n, h, w, cout), -1, 1).bfloat16()
+    xp = F.pad(x.double().permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect" if reflect else "constant")
+    ref = torch.nn.grad.conv2d_weight(xp, (cout, cin, 3, 3), gy.double().permute(0, 3, 1, 2))
+    xa = x[..., :c1].contiguous().to(dev())
+    xb = x[..., c1:].contiguous().to(dev()) if c2 else None
+    gyd = gy.to(dev())
+    nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, h, w, cout, 3, 3)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    gw = torch.full((cout, cin, 3, 3), float("nan"), dtype=torch.float32, device=dev())
+    rc = L.vqseg_conv2d_wgrad_f(gyd.data_ptr(), xa.data_ptr(), xb.data_ptr() if c2 else None, c1, n, h, w, cin, h, w, cout, 3, 3,
+                                1, 1, int(reflect), 0, cin, 0, ws.data_ptr(), nbytes, gw.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, L.vqseg_last_error()
+    torch.cuda.synchronize()
+    assert rel(gw, ref) < 2e-5
 
 
 @pytest.mark.parametrize("mode", ["precise", "fast"])

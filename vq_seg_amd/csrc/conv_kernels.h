@@ -27,7 +27,8 @@ struct WgradArgs {
 };
 
 hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st);
-int wgrad_slabs(const WgradArgs& a);
+int wgrad_slabs(const WgradArgs& a, int precise);   // slabs launch_wgrad will write
+int wgrad_slabs_max(const WgradArgs& a);           // upper bound from the shape alone (workspace sizing)
 hipError_t launch_wgrad(const WgradArgs& a, int precise, int slabs, hipStream_t st);
 hipError_t launch_wgrad_reduce(const float* partial, int slabs, int Cout, int Cin, int Cin_out, int KH, int KW, int im2col,
                                float* gw, hipStream_t st);

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_glds_kernel(const ConvArgs
     auto compute = [&](int buf) {
         const char* As = smem + buf * STAGE_BYTES;
         const char* Bs = As + TBM * BK * 2;
-#pragma unroll(MT * NTT >= 8 ? 1 : 4)
+#pragma unroll MT * NTT >= 8 ? 1 : 4
         for (int kk = 0; kk < BK / 16; ++kk) {
             bf16x8 af[MT], bfr[NTT];
 #pragma unroll
@@ -899,6 +899,250 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// =====================================================================================================
+// Weight gradient of 3x3 / stride 1 / pad 1 layers, ALL NINE TAPS IN ONE WORKGROUP (bf16 activations).
+//
+// The per-tap kernel above re-reads the GY tile and a shifted copy of the input for each tap: 64 B of operand
+// per MFMA clock and CU, far above what L2 -> LDS delivers.  Here a workgroup owns (32*COT output channels) x
+// (32*CIT input channels) x 9 taps and walks 4 x 16 blocks of output pixels: per block it stages ONE GY tile
+// [64 px][32*COT] and ONE input patch [6 x 18 px][32*CIT] (halo included) and feeds all nine taps from shifted
+// windows of that patch -- the MFMA K dimension (16 pixels) is one block row, so a tap's window is 16
+// consecutive patch pixels.  Both tiles arrive by LDS-DMA (global_load_lds_dwordx4) into a 3-deep ring with
+// counted vmcnt; rows are unpadded and 16-byte chunks are XOR-swizzled through the SOURCE address so the
+// transposing fragment reads (ds_read_b64_tr_b16, 4 pixel rows x 64 B per half-wave) are conflict-free.
+// Waves split (ci tile) x (co pair) x (tap range); a wave keeps its G fragments for all its taps.
+// Output: the same per-slab fp32 partials [z][Cout][9][Cin] as the per-tap kernel (fixed-order reduction).
+// =====================================================================================================
+template <int COT, int CIT>
+struct Wg3 {
+    static constexpr int PM = COT >= 2 ? 2 : 1;             // co tiles per wave
+    static constexpr int WO = COT / PM, WC = CIT;            // wave groups over co pairs / ci tiles
+    static constexpr int NW = (COT == 4 && CIT == 2) ? 8 : 4;
+    static constexpr int WT = NW / (WO * WC);                // wave groups over taps
+    static constexpr int NTM = (9 + WT - 1) / WT;            // taps per wave (upper bound)
+    static constexpr int RBG = COT * 64, RBA = CIT * 64;     // row bytes of the GY tile / the patch
+    static constexpr int G_INSTR = 64 * RBG / 1024;          // 1 KB DMA wave-instructions for the GY tile
+    static constexpr int G_PER = G_INSTR / NW;
+    static constexpr int P_INSTR = (108 * RBA + 1023) / 1024;
+    static constexpr int P_PER = (P_INSTR + NW - 1) / NW;    // every wave issues the same count (counted vmcnt)
+    static constexpr int G_BYTES = 64 * RBG, P_BYTES = P_PER * NW * 1024;
+    static constexpr int STAGE = G_BYTES + P_BYTES;
+    static constexpr int NBUF = 3;
+    static_assert(G_INSTR % NW == 0, "GY tile must split evenly over the waves");
+};
+
+template <int RB>
+__device__ __forceinline__ int swz_chunk(int row) {
+    return RB == 256 ? ((row & 3) << 2) : (RB == 128 ? (((row >> 1) & 1) << 2) : 0);
+}
+
+// transposing fragment read from an unpadded, chunk-swizzled [rows][RB bytes] bf16 tile:
+// lane (r = lane & 31, h = lane >> 5) gets column col0 + r, rows pix0 + 8h .. +7
+template <int RB>
+__device__ __forceinline__ bf16x8 tr_frag_swz(const char* tile, int pix0, int col0, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int row = pix0 + 8 * (g >> 1) + q;
+    const int cbyte = 2 * col0 + 32 * (g & 1) + 8 * pp;
+    const char* a0 = tile + row * RB + (((cbyte >> 4) ^ swz_chunk<RB>(row)) << 4) + (cbyte & 8);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * RB));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int COT, int CIT>
+__global__ __launch_bounds__((Wg3<COT, CIT>::NW * 64)) void conv_wgrad3x3_kernel(const WgradArgs p, int blocks_per_slab) {
+    using C = Wg3<COT, CIT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave % C::WC, wo = (wave / C::WC) % C::WO, wt = wave / (C::WC * C::WO);
+    const int t0 = (9 * wt + C::WT - 1) / C::WT, t1 = (9 * (wt + 1) + C::WT - 1) / C::WT;
+
+    const int ci0 = blockIdx.x * (32 * CIT), co0 = blockIdx.y * (32 * COT);
+    const int bw = p.Wo >> 4, bh = p.Ho >> 2;
+    const int n_blk = p.N * bh * bw;
+    const int b_begin = blockIdx.z * blocks_per_slab;
+    int b_end = b_begin + blocks_per_slab;
+    if (b_end > n_blk) b_end = n_blk;
+    const int ns = b_end > b_begin ? b_end - b_begin : 0;
+
+    const bool second = ci0 >= p.C1;
+    const char* xsrc = reinterpret_cast<const char*>(second ? p.x2 : p.x);
+    const int csrc = second ? (p.Cin - p.C1) : p.C1;
+    const int cbase = second ? (ci0 - p.C1) : ci0;
+    const char* gsrc = reinterpret_cast<const char*>(p.gy);
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    // ---- stage-invariant lane roles of the DMA instructions
+    int g_rel[C::G_PER];                                   // element offset of this lane's GY chunk inside a block
+#pragma unroll
+    for (int i = 0; i < C::G_PER; ++i) {
+        const int j = wave + C::NW * i;
+        const int bp = j * (1024 / C::RBG) + (lane * 16) / C::RBG;          // block pixel 0..63
+        const int slot = lane & (C::RBG / 16 - 1);
+        const int chunk = slot ^ swz_chunk<C::RBG>(bp);
+        g_rel[i] = ((bp >> 4) * p.Wo + (bp & 15)) * p.Cout + co0 + chunk * 8;
+    }
+    int p_dr[C::P_PER], p_dc[C::P_PER], p_ch[C::P_PER];   // patch row / column (relative to the block) and channel
+#pragma unroll
+    for (int i = 0; i < C::P_PER; ++i) {
+        const int j = wave + C::NW * i;
+        const int pp = j * (1024 / C::RBA) + (lane * 16) / C::RBA;          // patch pixel 0..107 (beyond: zero page)
+        const int slot = lane & (C::RBA / 16 - 1);
+        const int chunk = slot ^ swz_chunk<C::RBA>(pp);
+        const int pr = pp / 18;
+        p_dr[i] = pp < 108 ? pr - 1 : -(1 << 20);
+        p_dc[i] = pp - 18 * pr - 1;
+        p_ch[i] = cbase + chunk * 8;
+    }
+
+    int toff[C::NTM];                                      // patch pixel offset of each of this wave's taps
+#pragma unroll
+    for (int t = 0; t < C::NTM; ++t) {
+        const int tap = t0 + t < 9 ? t0 + t : 8;
+        toff[t] = (tap / 3) * 18 + tap % 3;
+    }
+
+    f32x16 acc[C::PM][C::NTM];
+#pragma unroll
+    for (int a = 0; a < C::PM; ++a)
+#pragma unroll
+        for (int t = 0; t < C::NTM; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][t][i] = 0.0f;
+
+    // block being issued: (image, block row, block column), advanced without divisions
+    int in_ = b_begin / (bh * bw);
+    int iby = (b_begin - in_ * bh * bw) / bw;
+    int ibx = b_begin - (in_ * bh + iby) * bw;
+
+    auto stage = [&](int buf) {
+        char* Gs = smem + buf * C::STAGE;
+        char* Ps = Gs + C::G_BYTES;
+        const int oh0 = iby * 4, ow0 = ibx * 16;
+        const long gbase = (((long)in_ * p.Ho + oh0) * p.Wo + ow0) * p.Cout;
+#pragma unroll
+        for (int i = 0; i < C::G_PER; ++i) glds16(gsrc + (gbase + g_rel[i]) * 2, Gs + (wave + C::NW * i) * 1024);
+#pragma unroll
+        for (int i = 0; i < C::P_PER; ++i) {
+            int ih = oh0 + p_dr[i], iw = ow0 + p_dc[i];
+            if (p.reflect) {
+                if (ih > -(1 << 19)) ih = reflect_idx(ih, p.H);
+                iw = reflect_idx(iw, p.W);
+            }
+            const bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            const long off = (((long)in_ * p.H + ih) * p.W + iw) * csrc + p_ch[i];
+            glds16(ok ? xsrc + off * 2 : zero, Ps + (wave + C::NW * i) * 1024);
+        }
+        if (++ibx == bw) {
+            ibx = 0;
+            if (++iby == bh) {
+                iby = 0;
+                ++in_;
+            }
+        }
+    };
+
+    auto compute = [&](int buf) {
+        const char* Gs = smem + buf * C::STAGE;
+        const char* Ps = Gs + C::G_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {                   // block row kk = 16 pixels = one MFMA K step
+            bf16x8 gf[C::PM];
+#pragma unroll
+            for (int a = 0; a < C::PM; ++a) gf[a] = tr_frag_swz<C::RBG>(Gs, kk * 16, (wo * C::PM + a) * 32, lane);
+#pragma unroll
+            for (int t = 0; t < C::NTM; ++t) {
+                if (t0 + t < t1) {                          // wave-uniform
+                    const bf16x8 af = tr_frag_swz<C::RBA>(Ps, kk * 18 + toff[t], wc * 32, lane);
+#pragma unroll
+                    for (int a = 0; a < C::PM; ++a)
+                        acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[a], af, acc[a][t], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ring: see conv_igemm_glds_kernel
+    constexpr int G = C::G_PER + C::P_PER;
+    auto wait_in_flight = [&](int stages) {
+        if (stages >= 1) __builtin_amdgcn_s_waitcnt((G & 0xF) | ((G >> 4) << 14) | 0x0F70);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+    };
+#pragma unroll
+    for (int i = 0; i < C::NBUF - 1; ++i)
+        if (i < ns) stage(i);
+    int slot_c = 0, slot_i = C::NBUF - 1;
+    for (int s = 0; s < ns; ++s) {
+        const int behind = ns - 1 - s;
+        wait_in_flight(behind < C::NBUF - 2 ? behind : C::NBUF - 2);
+        __builtin_amdgcn_s_barrier();
+        if (s + C::NBUF - 1 < ns) stage(slot_i);
+        compute(slot_c);
+        slot_c = slot_c == C::NBUF - 1 ? 0 : slot_c + 1;
+        slot_i = slot_i == C::NBUF - 1 ? 0 : slot_i + 1;
+    }
+
+    // ---- epilogue: slab [z][Cout][9][Cin] fp32 (row = co on registers, column = ci on lanes)
+    const int r = lane & 31, h = lane >> 5;
+    float* slab = p.partial + (long)blockIdx.z * p.Cout * 9 * p.Cin;
+    const int ci = ci0 + wc * 32 + r;
+#pragma unroll
+    for (int a = 0; a < C::PM; ++a)
+#pragma unroll
+        for (int t = 0; t < C::NTM; ++t) {
+            if (t0 + t < t1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int co = co0 + (wo * C::PM + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    slab[((long)co * 9 + (t0 + t)) * p.Cin + ci] = acc[a][t][i];
+                }
+            }
+        }
+}
+
+struct Wg3Plan {
+    int cot, cit, slabs, blocks_per_slab;                  // cot == 0: not eligible
+};
+
+static Wg3Plan wgrad3x3_plan(const WgradArgs& a, int precise, bool shape_only, int force_cit = 0) {
+    Wg3Plan pl{0, 0, 0, 0};
+    if (precise || a.KH != 3 || a.KW != 3 || a.Ho != a.H || a.Wo != a.W || a.Ho % 4 || a.Wo % 16 || a.Cout % 32 || a.Cin % 32)
+        return pl;
+    if (!shape_only && (a.stride != 1 || a.pad != 1)) return pl;
+    int cit = (a.Cin % 64 == 0 && force_cit != 1) ? 2 : 1;
+    if (!shape_only && a.C1 != a.Cin && a.C1 % (32 * cit)) {
+        if (a.C1 % 32) return pl;
+        cit = 1;
+    }
+    const int cot = a.Cout % 128 == 0 ? 4 : (a.Cout % 64 == 0 ? 2 : 1);
+    const long tiles = (long)(a.Cin / (32 * cit)) * (a.Cout / (32 * cot));
+    const long n_blk = (long)a.N * (a.Ho / 4) * (a.Wo / 16);
+    if (n_blk > (1L << 30)) return pl;
+    const long target = (cot == 4 && cit == 2) ? 512 : 1024;
+    long s = (target + tiles - 1) / tiles;
+    const long max_s = (n_blk + 7) / 8;                     // at least 8 blocks (512 pixels) per slab
+    if (s > max_s) s = max_s;
+    if (s > 256) s = 256;
+    if (s < 1) s = 1;
+    const long bps = (n_blk + s - 1) / s;
+    s = (n_blk + bps - 1) / bps;                            // no empty slabs
+    pl.cot = cot;
+    pl.cit = cit;
+    pl.slabs = (int)s;
+    pl.blocks_per_slab = (int)bps;
+    return pl;
+}
+
+template <int COT, int CIT>
+static void wgrad3x3_launch_t(const WgradArgs& a, const Wg3Plan& pl, hipStream_t st) {
+    using C = Wg3<COT, CIT>;
+    dim3 grid((unsigned)(a.Cin / (32 * CIT)), (unsigned)(a.Cout / (32 * COT)), (unsigned)pl.slabs);
+    hipLaunchKernelGGL((conv_wgrad3x3_kernel<COT, CIT>), grid, dim3(C::NW * 64), (size_t)C::NBUF * C::STAGE, st, a, pl.blocks_per_slab);
+}
+
 template <int TM, int TN, bool PRECISE>
 static void wgrad_launch_t(const WgradArgs& a, int slabs, hipStream_t st) {
     constexpr int GS = TM * 32 + 32, AS = TN * 32 + 32;
@@ -908,7 +1152,7 @@ static void wgrad_launch_t(const WgradArgs& a, int slabs, hipStream_t st) {
     hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, PRECISE>), grid, dim3(256), lds, st, a);
 }
 
-int wgrad_slabs(const WgradArgs& a) {
+static int wgrad_slabs_per_tap(const WgradArgs& a) {
     const int tm = a.Cout >= 128 ? 4 : (a.Cout >= 64 ? 2 : 1);
     const int tn = (a.Cin % 128 == 0) ? 4 : 1;
     const long tiles = (long)a.KH * a.KW * ((a.Cin + tn * 32 - 1) / (tn * 32)) * ((a.Cout + tm * 32 - 1) / (tm * 32));
@@ -921,7 +1165,31 @@ int wgrad_slabs(const WgradArgs& a) {
     return (int)s;
 }
 
+// slabs the launch will use (precise/stride/pad known) ...
+int wgrad_slabs(const WgradArgs& a, int precise) {
+    const Wg3Plan pl = wgrad3x3_plan(a, precise, false);
+    return pl.cot ? pl.slabs : wgrad_slabs_per_tap(a);
+}
+
+// ... and an upper bound from the shape alone (workspace sizing)
+int wgrad_slabs_max(const WgradArgs& a) {
+    int m = wgrad_slabs_per_tap(a);
+    for (int cit = 1; cit <= 2; ++cit) {                    // a channel split may force the narrower ci tile
+        const Wg3Plan pl = wgrad3x3_plan(a, 0, true, cit);
+        if (pl.cot && pl.slabs > m) m = pl.slabs;
+    }
+    return m;
+}
+
 hipError_t launch_wgrad(const WgradArgs& a, int precise, int slabs, hipStream_t st) {
+    const Wg3Plan pl = wgrad3x3_plan(a, precise, false);
+    if (pl.cot) {
+#define WG3_CASE(COT_, CIT_) \
+    if (pl.cot == COT_ && pl.cit == CIT_) wgrad3x3_launch_t<COT_, CIT_>(a, pl, st);
+        WG3_CASE(4, 2) WG3_CASE(2, 2) WG3_CASE(1, 2) WG3_CASE(4, 1) WG3_CASE(2, 1) WG3_CASE(1, 1)
+#undef WG3_CASE
+        return hipGetLastError();
+    }
     const int tm = a.Cout >= 128 ? 4 : (a.Cout >= 64 ? 2 : 1);
     const int tn = (a.Cin % 128 == 0) ? 4 : 1;
 #define WG_CASE(TM_, TN_)                                               \

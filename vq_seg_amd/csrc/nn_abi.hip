@@ -19,7 +19,7 @@ int hipfail(hipError_t e, const char* where) {
     return vqseg_set_error((int)e, buf);
 }
 bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-int conv_wm(int cout) { return cout >= 64 ? 2 : 4; }
+
 int conv_rows_per_slot(int cout) { return cout >= 64 ? 64 : 32; }
 }  // namespace
 
@@ -70,7 +70,7 @@ size_t vqseg_conv2d_wgrad_workspace_bytes(int n, int h, int w, int cin, int ho, 
     if (n <= 0 || cin <= 0 || cout <= 0) return 0;
     vqseg::WgradArgs a{};
     a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Ho = ho; a.Wo = wo; a.Cout = cout; a.KH = kh; a.KW = kw;
-    return (size_t)vqseg::wgrad_slabs(a) * cout * kh * kw * cin * sizeof(float);
+    return (size_t)vqseg::wgrad_slabs_max(a) * cout * kh * kw * cin * sizeof(float);
 }
 
 int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, int n, int h, int w, int cin, int ho, int wo,
@@ -85,7 +85,7 @@ int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, 
     a.gy = gy; a.x = x; a.x2 = x2; a.C1 = c1; a.partial = static_cast<float*>(workspace);
     a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Ho = ho; a.Wo = wo; a.Cout = cout; a.KH = kkh; a.KW = kkw;
     a.stride = stride; a.pad = pad; a.reflect = reflect;
-    const int slabs = vqseg::wgrad_slabs(a);
+    const int slabs = vqseg::wgrad_slabs(a, precise);
     if (workspace_bytes < (size_t)slabs * cout * kkh * kkw * cin * sizeof(float)) return vqseg_set_error(VQSEG_ENOSPC, "conv2d_wgrad: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = vqseg::launch_wgrad(a, precise, slabs, st);
