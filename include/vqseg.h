@@ -39,6 +39,12 @@ const char* vqseg_last_error(void);
 /* Name of the dominant kernel symbol of an entry point (for rocprof matching). */
 const char* vqseg_kernel_name(const char* entry_point);
 
+/* Dispatch tunables (tests use them to reach every kernel with small shapes).  Keys:
+ *   "conv3x3_patch_min_workgroups"  minimum grid of the patch-reuse 3x3 kernel before the generic implicit-GEMM
+ *                                   kernel is preferred (default 256 = one workgroup per CU)
+ * Returns the previous value, or VQSEG_EINVAL for an unknown key / negative value.  Not thread safe. */
+int vqseg_set_option(const char* key, int value);
+
 /* Measurement aid (bench.py roofline leg): while enabled, every launch of the distance+argmin
  * kernel is bracketed by a hipEvent pair on its own stream.  vqseg_profile_collect waits for the
  * recorded launches, writes per-launch (n_rows, channels, n_codes, milliseconds) to HOST arrays,
@@ -156,10 +162,11 @@ int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, 
  * epilogue partials (Welford/Chan, double, fixed order), running stats updated like nn.BatchNorm2d
  * (biased variance to normalise, unbiased into running_var).  Eval: running statistics.
  *   finalize -> scale[c] = gamma*invstd, shift[c] = beta - mean*scale, save_mean, save_invstd
+ *               (`partial` is CONSUMED: the two-level merge folds group results back into it in place)
  *   apply    -> out = relu?( y*scale + shift (+ res) )
  *   backward -> gz = g_out * (out > 0); dgamma, dbeta; g_y (train: with the batch-statistics terms);
  *               g_res = gz when a residual branch exists. */
-int vqseg_bn_finalize_f(const float* partial, int64_t m_rows, int c, const float* gamma, const float* beta,
+int vqseg_bn_finalize_f(float* partial, int64_t m_rows, int c, const float* gamma, const float* beta,
                         float* run_mean, float* run_var, float momentum, float eps, int training,
                         float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
 int vqseg_bn_apply_f(int bf16, const void* y, const void* res, const float* scale, const float* shift,

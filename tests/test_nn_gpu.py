@@ -128,6 +128,78 @@ def test_conv_bn_act_forward_backward(case, training, mode):
         assert int(bn_g.num_batches_tracked) == int(bn.num_batches_tracked) + 1   # (copied after the CPU forward)
 
 
+@pytest.fixture
+def force_patch_kernel():
+    """Let the patch-reuse 3x3 kernel take small grids too (its dispatch normally wants >= 256 workgroups)."""
+    from vq_seg_amd import _hip
+    L = _hip.lib()
+    prev = L.vqseg_set_option(b"conv3x3_patch_min_workgroups", 1)
+    assert prev >= 0, L.vqseg_last_error()
+    yield
+    L.vqseg_set_option(b"conv3x3_patch_min_workgroups", prev)
+
+
+PATCH_CASES = [
+    # n, c1, c2, cout, h, w, reflect
+    (2, 64, 0, 128, 8, 32, False), (1, 128, 64, 256, 16, 64, True), (3, 64, 0, 128, 16, 16, True), (2, 192, 0, 128, 32, 48, False),
+    (1, 64, 64, 384, 16, 32, False), (2, 128, 0, 256, 16, 32, False),
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES)
+def test_conv3x3_patch_kernel(case, force_patch_kernel):
+    """The patch-reuse bf16 3x3 kernel through the C ABI (forward form and, with tap-flipped transposed weights, the
+    data-gradient form) against an fp64 convolution of the SAME bf16 values: products are exact in fp32, only the
+    accumulation order differs, so the bf16-rounded outputs agree to one bf16 ulp (2^-8 relative)."""
+    from vq_seg_amd import _hip
+    n, c1, c2, cout, h, w, reflect = case
+    cin = c1 + c2
+    L = _hip.lib()
+    seed = sum(case[:6]) + 3
+    x = synth.uniform(seed, (n, h, w, cin), -1, 1).bfloat16()
+    wt = (synth.uniform(seed + 1, (cout, cin, 3, 3), -1, 1) * (2.0 / (cin * 9)) ** 0.5).bfloat16().float()
+    xp = F.pad(x.double().permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect" if reflect else "constant")
+    ref = F.conv2d(xp, wt.double()).permute(0, 2, 3, 1)
+    wd = wt.to(dev())
+    ne = L.vqseg_conv_packed_elems(cout, cin, 3, 3, 0)
+    hi = torch.empty(ne, dtype=torch.int16, device=dev())
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.vqseg_conv_pack_weights_f32(wd.data_ptr(), cout, cin, 3, 3, 0, hi.data_ptr(), None, st) == 0
+    xa = x[..., :c1].contiguous().to(dev())
+    xb = x[..., c1:].contiguous().to(dev()) if c2 else None
+    y = torch.full((n, h, w, cout), float("nan"), dtype=torch.bfloat16, device=dev())
+    slots = L.vqseg_conv_stat_slots(n * h * w, cout)
+    stat = torch.full((slots, 2, cout), float("nan"), dtype=torch.float32, device=dev())
+    rc = L.vqseg_conv2d_f(xa.data_ptr(), xb.data_ptr() if c2 else None, c1, hi.data_ptr(), None, y.data_ptr(), stat.data_ptr(),
+                          n, h, w, cin, cout, 3, 3, 1, 1, int(reflect), 1, h, w, 0, st)
+    assert rc == 0, L.vqseg_last_error()
+    torch.cuda.synchronize()
+    assert rel(y.float(), ref) < 2 ** -7
+    # BatchNorm partials of the fp32 accumulators: merged mean / biased variance per channel
+    m = n * h * w
+    n_slots = m // 64
+    sp = stat[:n_slots].double().cpu()
+    mean = sp[:, 0].mean(0)
+    var = (sp[:, 1] + 64 * (sp[:, 0] - mean) ** 2).sum(0) / m
+    flat = ref.reshape(m, cout)
+    assert ((mean - flat.mean(0)).abs().max() / flat.abs().max()).item() < 1e-5
+    assert ((var - flat.var(0, unbiased=False)).abs().max() / flat.var(0, unbiased=False).max()).item() < 1e-4
+    # data-gradient form: conv of gy with the tap-flipped, transposed weights == conv_transpose (zero padding only)
+    if not reflect and c2 == 0:
+        gy = synth.uniform(seed + 2, (n, h, w, cout), -1, 1).bfloat16()
+        gref = F.conv_transpose2d(gy.double().permute(0, 3, 1, 2), wt.double(), padding=1).permute(0, 2, 3, 1)
+        ne = L.vqseg_conv_packed_elems(cout, cin, 3, 3, 1)
+        thi = torch.empty(ne, dtype=torch.int16, device=dev())
+        assert L.vqseg_conv_pack_weights_f32(wd.data_ptr(), cout, cin, 3, 3, 1, thi.data_ptr(), None, st) == 0
+        gx = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev())
+        gyd = gy.to(dev())
+        rc = L.vqseg_conv2d_f(gyd.data_ptr(), None, cout, thi.data_ptr(), None, gx.data_ptr(), None, n, h, w, cout, cin, 3, 3, 1, 1, 0,
+                              1, h, w, 0, st)
+        assert rc == 0, L.vqseg_last_error()
+        torch.cuda.synchronize()
+        assert rel(gx.float(), gref) < 2 ** -7
+
+
 WGRAD_CASES = [
     # n, c1, c2, cout, h, w, reflect
     (2, 64, 0, 128, 8, 32, True), (3, 128, 64, 64, 12, 16, False), (2, 32, 0, 32, 16, 48, False), (1, 96, 32, 32, 8, 16, False),

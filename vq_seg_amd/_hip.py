@@ -21,6 +21,7 @@ SYMBOLS = {
     "vqseg_abi_version": (c_int, []),
     "vqseg_last_error": (c_char_p, []),
     "vqseg_kernel_name": (c_char_p, [c_char_p]),
+    "vqseg_set_option": (c_int, [c_char_p, c_int]),
     "vqseg_profile_begin": (c_int, [c_int]),
     "vqseg_profile_collect": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqseg_vq_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),

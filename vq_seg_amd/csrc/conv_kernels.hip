@@ -20,6 +20,7 @@
 // Optional epilogue: per-wave partial BatchNorm statistics (count, mean, M2 over the wave's 64 rows) for a
 // deterministic two-level Welford merge (no float atomics).
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdint.h>
 
 #include "conv_kernels.h"
@@ -48,9 +49,15 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 }
 
 // ---- shared epilogue: per-wave BN partials from the accumulators, then Y through LDS as 16-byte row segments
-template <int TBM, int BN, bool PRECISE, int MT, int NTT, int NT, int NTHR>
+struct LinearRows {                                          // tile row -> output pixel row (NHWC-flattened)
+    long m0;
+    __device__ __forceinline__ long operator()(int row) const { return m0 + row; }
+};
+
+template <int TBM, int BN, bool PRECISE, int MT, int NTT, int NT, int NTHR, typename RowMap = LinearRows>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const ConvArgs& p, char* smem, long M, long m0, int co0,
-                                              int wm, int wn, int r, int h, int tid) {
+                                              int wm, int wn, int r, int h, int tid, RowMap row_to_m = LinearRows{-1}) {
+    if constexpr (__is_same(RowMap, LinearRows)) row_to_m.m0 = m0;
     const long wrow0 = m0 + (long)wm * MT * 32;
     if (p.stat_partial) {
         // one (mean, M2) partial per SLOT of RPS consecutive rows: 64 rows (two 32-row tiles) or 32 when the wave has one
@@ -113,7 +120,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
         constexpr int CPR = BN / O_EPC;                     // 16-byte chunks per tile row
         for (int idx = tid; idx < TBM * CPR; idx += NTHR) {
             const int row = idx / CPR, ch = idx % CPR;
-            const long m = m0 + row;
+            const long m = row_to_m(row);
             const int co = co0 + ch * O_EPC;
             if (m < M && co < p.Cout) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(ot + ((size_t)row * OS + ch * O_EPC) * (PRECISE ? 4 : 2));
@@ -128,8 +135,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (m < M && co < p.Cout) {
+                    const long mv = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    const long m = row_to_m((int)(mv - m0));
+                    if (mv < M && co < p.Cout) {
                         if (PRECISE) reinterpret_cast<float*>(p.y)[m * p.Cout + co] = acc[a][b][i];
                         else reinterpret_cast<__bf16*>(p.y)[m * p.Cout + co] = (__bf16)acc[a][b][i];
                     }
@@ -552,6 +560,221 @@ static void launch_glds_t(const ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF>), grid, dim3(NW * 64), lds, st, a);
 }
 
+// =====================================================================================================
+// 3x3 / stride 1 / pad 1 convolution with PATCH REUSE (bf16; forward of every such layer and the data gradient
+// of the zero-padded ones).
+//
+// The generic kernel above fetches a shifted copy of the input tile for each of the nine taps (A traffic 9x).
+// Here a workgroup owns a 2-D tile of 256 output pixels (8 x 32, or 16 x 16 for narrow images) x BN output
+// channels.  Per 64-channel chunk of the input it stages ONE haloed patch [(TH+2) x (TW+2) px][64 ci] and feeds
+// all nine taps from shifted windows of it: the MFMA row (32 consecutive tile pixels) of tap (kh, kw) is the same
+// LDS rows displaced by kh * (TW+2) + kw.  Only the weights [BN][64 ci] change per tap.
+//   LDS: two patch buffers (the next chunk's patch arrives, one DMA instruction per wave and tap, under the taps
+//   of the current chunk) + a ring of NBW weight stages; counted vmcnt, one raw barrier per tap.
+// Rows are unpadded 128 B with the 16-byte chunks XOR-swizzled through the DMA source address.
+// =====================================================================================================
+struct TileRows {                                           // tile row -> output pixel row of a 2-D pixel tile
+    long base;                                              // (n * H + oh0) * W + ow0
+    int tw_shift, W;
+    __device__ __forceinline__ long operator()(int row) const {
+        return base + (long)(row >> tw_shift) * W + (row & ((1 << tw_shift) - 1));
+    }
+};
+
+template <int BN, int NBW>
+__global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
+    constexpr int TBM = 256, NW = 8;
+    constexpr int WN = BN / 64, WM = NW / WN;              // wave grid; wave tile (MT*32) px x 64 co
+    constexpr int MT = TBM / (WM * 32), NT = 2;
+    constexpr int PATCH_BYTES = 48 * 1024;                 // 6 DMA instructions (8 rows x 128 B) per wave
+    constexpr int W_BYTES = BN * 128;
+    constexpr int WI = W_BYTES / 1024 / NW;                // weight DMA instructions per wave and tap
+    static_assert(W_BYTES % (1024 * NW) == 0, "weight tile must split evenly over the waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const patch0 = smem;
+    char* const wring = smem + 2 * PATCH_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+
+    // ---- tile geometry (host guarantees H % TH == 0, W % TW == 0, Ho == H, Wo == W)
+    const int tw_shift = (p.W & 31) == 0 ? 5 : 4;
+    const int TW = 1 << tw_shift, TH = TBM >> tw_shift, PW = TW + 2, PH = TH + 2;
+    const int tiles_x = p.W >> tw_shift, tiles_y = p.H / TH;
+    int t = blockIdx.x;
+    const int txi = t % tiles_x;
+    t /= tiles_x;
+    const int tyi = t % tiles_y;
+    const int n = t / tiles_y;
+    const int oh0 = tyi * TH, ow0 = txi * TW;
+    const int co0 = blockIdx.y * BN;
+
+    // ---- this lane's patch rows: instruction i of this wave covers patch pixels 8 * (wave + NW * i) .. + 7
+    const int slot = lane & 7;
+    long p_pix[6];                                          // input pixel index of the row, -1 = zero
+    int p_chunk[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int pp = 8 * (wave + NW * i) + (lane >> 3);
+        const int pr = pp / PW, pc = pp - pr * PW;
+        int ih = oh0 - 1 + pr, iw = ow0 - 1 + pc;
+        bool ok = pr < PH;
+        if (p.reflect && ok) {
+            ih = reflect_idx(ih, p.H);
+            iw = reflect_idx(iw, p.W);
+        }
+        ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        p_pix[i] = ok ? ((long)n * p.H + ih) * p.W + iw : -1;
+        p_chunk[i] = slot ^ ((pp >> 1) & 7);
+    }
+    // ---- this lane's weight rows
+    int b_chunk[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = 8 * (wave * WI + i) + (lane >> 3);
+        b_chunk[i] = slot ^ ((row >> 1) & 7);
+    }
+    // ---- MFMA A rows: tile row -> patch pixel (tap (0, 0))
+    int a_pp[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+        const int row = (wm * MT + a) * 32 + r;
+        a_pp[a] = (row >> tw_shift) * PW + (row & (TW - 1));
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+    const int cin_p = (p.Cin + 31) / 32 * 32;
+    const int n_chunks = p.Cin / 64;
+    const int n_stage = n_chunks * 9;
+    const long w_row = 9L * cin_p;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    auto issue_patch = [&](int chunk, int i) {              // instruction i (0..5) of this wave for input chunk `chunk`
+        const int ci0 = chunk * 64;
+        const bool second = ci0 >= p.C1;
+        const char* src = reinterpret_cast<const char*>(second ? p.x2 : p.x);
+        const int csrc = second ? (p.Cin - p.C1) : p.C1;
+        const int cbase = second ? (ci0 - p.C1) : ci0;
+        const long off = p_pix[i] * csrc + cbase + p_chunk[i] * 8;
+        glds16(p_pix[i] >= 0 ? src + off * 2 : zero, patch0 + (chunk & 1) * PATCH_BYTES + (wave + NW * i) * 1024);
+    };
+    auto issue_weights = [&](int chunk, int tap, int wslot) {
+        char* Bs = wring + wslot * W_BYTES;
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int row = 8 * (wave * WI + i) + (lane >> 3);
+            const int co = co0 + row;
+            const unsigned short* wp = p.w_hi + (long)co * w_row + (long)tap * cin_p + chunk * 64 + b_chunk[i] * 8;
+            glds16(co < p.Cout ? reinterpret_cast<const char*>(wp) : zero, Bs + (wave * WI + i) * 1024);
+        }
+    };
+    auto compute = [&](int chunk, int tapoff, int wslot) {
+        const char* Ps = patch0 + (chunk & 1) * PATCH_BYTES;
+        const char* Bs = wring + wslot * W_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 af[MT], bfr[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int pp = a_pp[a] + tapoff;
+                af[a] = *reinterpret_cast<const bf16x8*>(Ps + pp * 128 + (((kk * 2 + h) ^ ((pp >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int row = (wn * NT + b) * 32 + r;
+                bfr[b] = *reinterpret_cast<const bf16x8*>(Bs + row * 128 + (((kk * 2 + h) ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    // ---- prologue: whole patch of chunk 0, weights of the first NBW - 1 stages
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue_patch(0, i);
+#pragma unroll
+    for (int s = 0; s < NBW - 1; ++s)
+        if (s < n_stage) issue_weights(s / 9, s % 9, s);
+
+    // stage = (chunk, tap).  Issue order inside a stage: [patch piece of chunk + 1 (taps 0..5)] [weights of stage
+    // s + NBW - 1].  At the top of stage s the DMA instructions younger than the weights of stage s are those of the
+    // NBW - 2 later weight stages plus the patch pieces issued with them; vmcnt completes in order.
+    int wslot = 0;
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const bool more = chunk + 1 < n_chunks;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int s = chunk * 9 + tap;
+            // younger instructions still allowed in flight
+            if (NBW == 3) {
+                const bool w1 = s + 1 < n_stage;            // weights of stage s + 1 were issued in stage s - 1
+                const bool pz = tap >= 1 && tap - 1 < 6 && more;   // ... after a patch piece
+                if (w1 && pz) __builtin_amdgcn_s_waitcnt(((WI + 1) & 0xF) | 0x0F70);
+                else if (w1) __builtin_amdgcn_s_waitcnt((WI & 0xF) | 0x0F70);
+                else __builtin_amdgcn_s_waitcnt(0x0F70);
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+            __builtin_amdgcn_s_barrier();
+            if (tap < 6 && more) issue_patch(chunk + 1, tap);
+            {
+                const int s2 = s + NBW - 1;
+                if (s2 < n_stage) {
+                    const int c2 = tap + NBW - 1 >= 9 ? chunk + 1 : chunk, t2 = tap + NBW - 1 >= 9 ? tap + NBW - 1 - 9 : tap + NBW - 1;
+                    int ws2 = wslot + NBW - 1;
+                    if (ws2 >= NBW) ws2 -= NBW;
+                    issue_weights(c2, t2, ws2);
+                }
+            }
+            compute(chunk, (tap / 3) * PW + tap % 3, wslot);
+            wslot = wslot == NBW - 1 ? 0 : wslot + 1;
+        }
+    }
+    __syncthreads();                                       // all MFMAs done: LDS is free for the output tile
+    const long M = (long)p.N * p.H * p.W;
+    const TileRows rows{((long)n * p.H + oh0) * p.W + ow0, tw_shift, p.W};
+    conv_epilogue<TBM, BN, false, MT, NT, NT, NW * 64, TileRows>(acc, p, smem, M, (long)blockIdx.x * TBM, co0, wm, wn, r, h, tid, rows);
+}
+
+static int g_patch_min_wgs = 256;
+
+int conv_set_option(const char* key, int value) {
+    if (key && !strcmp(key, "conv3x3_patch_min_workgroups")) {
+        const int prev = g_patch_min_wgs;
+        g_patch_min_wgs = value;
+        return prev;
+    }
+    return -1;
+}
+
+static bool conv3x3_patch_ok(const ConvArgs& a) {
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.up != 1 || a.Ho != a.H || a.Wo != a.W) return false;
+    if (a.Cin % 64 || (a.C1 != a.Cin && a.C1 % 64) || a.Cout % 128) return false;
+    const int tw = (a.W % 32 == 0) ? 32 : 16, th = 256 / tw;
+    if (a.W % tw || a.H % th) return false;
+    return (long)a.N * (a.H / th) * (a.W / tw) * (a.Cout / 128) >= g_patch_min_wgs;   // at least one workgroup per CU
+}
+
+template <int BN, int NBW>
+static void launch_patch_t(const ConvArgs& a, hipStream_t st) {
+    const size_t lds = 2 * 48 * 1024 + (size_t)NBW * BN * 128;
+    const int tw = (a.W % 32 == 0) ? 32 : 16, th = 256 / tw;
+    dim3 grid((unsigned)((long)a.N * (a.H / th) * (a.W / tw)), (unsigned)(a.Cout / BN));
+    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW>), grid, dim3(512), lds, st, a);
+}
+
 // ------------------------------------------------------------------------------------
 // weight packing: nn.Conv2d weight [Cout][Cin][KH][KW] f32 -> [Cout][KH][KW][Cin] bf16 hi (+ lo)
 //   transpose_flip: data-gradient form  [Cin][KH][KW][Cout] with taps flipped
@@ -605,6 +828,8 @@ hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
         if (bn == 128) launch_t<128, true, 32>(a, st);
         else if (bn == 64) launch_t<64, true, 32>(a, st);
         else launch_t<32, true, 32>(a, st);
+    } else if (k64 && conv3x3_patch_ok(a)) {
+        launch_patch_t<128, 3>(a, st);
     } else if (k64) {
         // L2 -> LDS operand traffic bounds this kernel (~35 B/clk/CU): prefer the largest tile that still yields
         // at least ~2 waves of workgroups over the 256 CUs
@@ -1085,22 +1310,39 @@ __global__ __launch_bounds__((Wg3<COT, CIT>::NW * 64)) void conv_wgrad3x3_kernel
         slot_i = slot_i == C::NBUF - 1 ? 0 : slot_i + 1;
     }
 
-    // ---- epilogue: slab [z][Cout][9][Cin] fp32 (row = co on registers, column = ci on lanes)
+    // ---- epilogue: slab [z][Cout][Cin][9] fp32 = nn.Conv2d's own layout, so the slab reduction is a plain vector
+    // sum.  The accumulators (row = co on registers, column = ci on lanes, tap = register array) go through LDS
+    // 16 output channels at a time as [co][ci][tap] and leave as contiguous 16-byte stores.
     const int r = lane & 31, h = lane >> 5;
     float* slab = p.partial + (long)blockIdx.z * p.Cout * 9 * p.Cin;
-    const int ci = ci0 + wc * 32 + r;
+    float* tile = reinterpret_cast<float*>(smem);
+    constexpr int ROW = 32 * CIT * 9;                      // floats per output channel of this workgroup's tile
+    __syncthreads();                                       // ring slots are free
 #pragma unroll
-    for (int a = 0; a < C::PM; ++a)
+    for (int ag = 0; ag < COT; ++ag) {
 #pragma unroll
-        for (int t = 0; t < C::NTM; ++t) {
-            if (t0 + t < t1) {
+        for (int hf = 0; hf < 2; ++hf) {
+            if (wo == ag / C::PM) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int co = co0 + (wo * C::PM + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    slab[((long)co * 9 + (t0 + t)) * p.Cin + ci] = acc[a][t][i];
+                for (int t = 0; t < C::NTM; ++t) {
+                    if (t0 + t < t1) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+                            tile[(row * (32 * CIT) + wc * 32 + r) * 9 + t0 + t] = acc[ag % C::PM][t][hf * 8 + j];
+                        }
+                    }
                 }
             }
+            __syncthreads();
+            for (int i = tid; i < 16 * (ROW / 4); i += C::NW * 64) {
+                const int row = i / (ROW / 4), q4 = i - row * (ROW / 4);
+                const int co = co0 + ag * 32 + hf * 16 + row;
+                *reinterpret_cast<f32x4*>(slab + ((long)co * p.Cin + ci0) * 9 + q4 * 4) = *reinterpret_cast<const f32x4*>(tile + row * ROW + q4 * 4);
+            }
+            __syncthreads();
         }
+    }
 }
 
 struct Wg3Plan {
@@ -1121,7 +1363,9 @@ static Wg3Plan wgrad3x3_plan(const WgradArgs& a, int precise, bool shape_only, i
     const long tiles = (long)(a.Cin / (32 * cit)) * (a.Cout / (32 * cot));
     const long n_blk = (long)a.N * (a.Ho / 4) * (a.Wo / 16);
     if (n_blk > (1L << 30)) return pl;
-    const long target = (cot == 4 && cit == 2) ? 512 : 1024;
+    // every workgroup writes its whole (co x ci x 9) fp32 tile once, so the partial volume is (#workgroups x tile
+    // bytes) whatever the layer: one resident round of workgroups is the cheapest split
+    const long target = (cot == 4 && cit == 2) ? 256 : 512;
     long s = (target + tiles - 1) / tiles;
     const long max_s = (n_blk + 7) / 8;                     // at least 8 blocks (512 pixels) per slab
     if (s > max_s) s = max_s;
@@ -1181,8 +1425,9 @@ int wgrad_slabs_max(const WgradArgs& a) {
     return m;
 }
 
-hipError_t launch_wgrad(const WgradArgs& a, int precise, int slabs, hipStream_t st) {
+hipError_t launch_wgrad(const WgradArgs& a, int precise, int slabs, int* final_layout, hipStream_t st) {
     const Wg3Plan pl = wgrad3x3_plan(a, precise, false);
+    *final_layout = pl.cot ? 1 : 0;                          // 1: slabs already are [Cout][Cin][KH][KW]
     if (pl.cot) {
 #define WG3_CASE(COT_, CIT_) \
     if (pl.cot == COT_ && pl.cit == CIT_) wgrad3x3_launch_t<COT_, CIT_>(a, pl, st);

@@ -66,6 +66,12 @@ int vqseg_conv2d_f(const void* x, const void* x2, int c1, const void* w_hi, cons
     return e == hipSuccess ? 0 : hipfail(e, "conv_igemm_kernel");
 }
 
+int vqseg_set_option(const char* key, int value) {
+    if (!key || value < 0) return bad("set_option: null key or negative value");
+    const int prev = vqseg::conv_set_option(key, value);
+    return prev < 0 ? bad("set_option: unknown key") : prev;
+}
+
 size_t vqseg_conv2d_wgrad_workspace_bytes(int n, int h, int w, int cin, int ho, int wo, int cout, int kh, int kw) {
     if (n <= 0 || cin <= 0 || cout <= 0) return 0;
     vqseg::WgradArgs a{};
@@ -88,14 +94,17 @@ int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, 
     const int slabs = vqseg::wgrad_slabs(a, precise);
     if (workspace_bytes < (size_t)slabs * cout * kkh * kkw * cin * sizeof(float)) return vqseg_set_error(VQSEG_ENOSPC, "conv2d_wgrad: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipError_t e = vqseg::launch_wgrad(a, precise, slabs, st);
+    int final_layout = 0;
+    hipError_t e = vqseg::launch_wgrad(a, precise, slabs, &final_layout, st);
     if (e != hipSuccess) return hipfail(e, "conv_wgrad_kernel");
-    if (im2col) e = vqseg::launch_wgrad_reduce(a.partial, slabs, cout, cin, cin_out, kh, kw, 1, gw, st);   // kh,kw = ORIGINAL taps here
+    if (final_layout && (cin_out != cin || im2col)) return bad("conv2d_wgrad: internal layout mismatch");
+    if (final_layout) e = vqseg::launch_reduce_partials(a.partial, slabs, (long)cout * cin * kkh * kkw, gw, st);
+    else if (im2col) e = vqseg::launch_wgrad_reduce(a.partial, slabs, cout, cin, cin_out, kh, kw, 1, gw, st);   // kh,kw = ORIGINAL taps here
     else e = vqseg::launch_wgrad_reduce(a.partial, slabs, cout, cin, cin_out, kh, kw, 0, gw, st);
     return e == hipSuccess ? 0 : hipfail(e, "wgrad_reduce_kernel");
 }
 
-int vqseg_bn_finalize_f(const float* partial, int64_t m_rows, int c, const float* gamma, const float* beta, float* run_mean,
+int vqseg_bn_finalize_f(float* partial, int64_t m_rows, int c, const float* gamma, const float* beta, float* run_mean,
                         float* run_var, float momentum, float eps, int training, float* scale, float* shift, float* save_mean,
                         float* save_invstd, void* stream) {
     if (!gamma || !beta || !scale || !shift || !save_mean || !save_invstd || c <= 0 || m_rows <= 0) return bad("bn_finalize: bad argument");

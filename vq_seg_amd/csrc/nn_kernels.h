@@ -6,7 +6,7 @@
 
 namespace vqseg {
 
-hipError_t launch_bn_finalize(const float* partial, long n_slots, int rows_per_slot, long M, int C, const float* gamma,
+hipError_t launch_bn_finalize(float* partial, long n_slots, int rows_per_slot, long M, int C, const float* gamma,
                               const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
                               float* shift, float* save_mean, float* save_invstd, hipStream_t st);
 hipError_t launch_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var,

@@ -60,47 +60,85 @@ __device__ __forceinline__ void stv(T* p, long i, const float (&v)[VecN<T>::N]) 
 // ---------------------------------------------------------------------------------------------
 // BatchNorm forward statistics
 // ---------------------------------------------------------------------------------------------
-// Merge the per-wave partials (mean_s, M2_s over rows_per_slot rows) written by the conv epilogue:
-//   mean = sum n_s mean_s / M ;  M2 = sum (M2_s + n_s (mean_s - mean)^2)      (double, fixed tree order)
-// then scale = gamma * invstd, shift = beta - mean * scale, running-stat update (nn.BatchNorm2d: biased var
-// for normalisation, unbiased for running_var).  One block per channel.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, long n_slots, int rows_per_slot,
-                                                          long M, int C, const float* __restrict__ gamma,
+// Merge the per-slot partials (mean_s, M2_s over rows_per_slot rows) written by the conv epilogue.  In DOUBLE
+// the plain power sums are exact enough (the inputs are floats: 29 spare bits against the cancellation in
+// S2 - M mean^2) and need no divisions:
+//   S1 = sum n_s mean_s        S2 = sum (M2_s + n_s mean_s^2)        mean = S1 / M        M2 = S2 - M mean^2
+// Level 1 (bn_stats_merge_kernel): grid (64-channel groups, slot groups); a block sums its slots (reads coalesced
+// along the channels, fixed order) and writes (S1, S2) back IN PLACE into its first two slots as (hi, lo) float
+// pairs, so the whole merge stays in double.  Level 2 (bn_finalize_kernel) sums the group results and derives
+// scale = gamma * invstd, shift = beta - mean * scale and the running-stat update (nn.BatchNorm2d: biased
+// variance to normalise, unbiased for running_var).
+struct PowerSums {
+    double s1, s2;
+};
+
+// sum slots s0, s0 + step, ... < s1 for 64 channels; `merged`: the slots hold level-1 (hi, lo) results
+__device__ __forceinline__ PowerSums fold_slots(const float* __restrict__ partial, long s0, long s1, long step, bool merged,
+                                                int rows_per_slot, long M, int C, int c, PowerSums* lds) {
+    const int ty = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    PowerSums a{0.0, 0.0};
+    if (c < C)
+        for (long i = s0 + ty * step; i < s1; i += 4 * step) {
+            const double u = (double)partial[(i * 2 + 0) * C + c], v = (double)partial[(i * 2 + 1) * C + c];
+            if (merged) {
+                a.s1 += u;
+                a.s2 += v;
+                if (i + 1 < s1) {                           // low parts in the next slot (groups hold >= 2 slots)
+                    a.s1 += (double)partial[(i * 2 + 2) * C + c];
+                    a.s2 += (double)partial[(i * 2 + 3) * C + c];
+                }
+            } else {
+                long n = M - i * rows_per_slot;
+                n = n < 0 ? 0 : (n > rows_per_slot ? rows_per_slot : n);
+                a.s1 += (double)n * u;
+                a.s2 += v + (double)n * u * u;
+            }
+        }
+    lds[ty * 64 + cl] = a;
+    __syncthreads();
+    PowerSums r = lds[cl];
+    if (ty == 0)
+        for (int t = 1; t < 4; ++t) {
+            r.s1 += lds[t * 64 + cl].s1;
+            r.s2 += lds[t * 64 + cl].s2;
+        }
+    return r;                                               // valid on ty == 0
+}
+
+__global__ __launch_bounds__(256) void bn_stats_merge_kernel(float* __restrict__ partial, long n_slots, long slots_per_group,
+                                                             int rows_per_slot, long M, int C) {
+    __shared__ PowerSums lds[256];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const long s0 = (long)blockIdx.y * slots_per_group;
+    long s1 = s0 + slots_per_group;
+    if (s1 > n_slots) s1 = n_slots;
+    const PowerSums r = fold_slots(partial, s0, s1, 1, false, rows_per_slot, M, C, c, lds);
+    if ((threadIdx.x >> 6) == 0 && c < C) {                 // every read of this block's slots happened before the barrier
+        const float h1 = (float)r.s1, h2 = (float)r.s2;
+        partial[(s0 * 2 + 0) * C + c] = h1;
+        partial[(s0 * 2 + 1) * C + c] = h2;
+        if (s0 + 1 < s1) {
+            partial[(s0 * 2 + 2) * C + c] = (float)(r.s1 - (double)h1);
+            partial[(s0 * 2 + 3) * C + c] = (float)(r.s2 - (double)h2);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, long n_slots, long slots_per_group,
+                                                          int rows_per_slot, long M, int C, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ run_mean,
                                                           float* __restrict__ run_var, float momentum, float eps,
                                                           float* __restrict__ scale, float* __restrict__ shift,
                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-    const int c = blockIdx.x;
-    __shared__ double red[256];
-    double s = 0.0;
-    for (long i = threadIdx.x; i < n_slots; i += 256) {
-        long n = M - i * rows_per_slot;
-        n = n < 0 ? 0 : (n > rows_per_slot ? rows_per_slot : n);
-        s += (double)n * (double)partial[(i * 2 + 0) * C + c];
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int m = 128; m >= 1; m >>= 1) {
-        if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
-        __syncthreads();
-    }
-    const double mean = red[0] / (double)M;
-    __syncthreads();
-    double q = 0.0;
-    for (long i = threadIdx.x; i < n_slots; i += 256) {
-        long n = M - i * rows_per_slot;
-        n = n < 0 ? 0 : (n > rows_per_slot ? rows_per_slot : n);
-        const double d = (double)partial[(i * 2 + 0) * C + c] - mean;
-        q += (double)partial[(i * 2 + 1) * C + c] + (double)n * d * d;
-    }
-    red[threadIdx.x] = q;
-    __syncthreads();
-    for (int m = 128; m >= 1; m >>= 1) {
-        if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const double var = red[0] / (double)M;
+    __shared__ PowerSums lds[256];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const PowerSums r = fold_slots(partial, 0, n_slots, slots_per_group, slots_per_group > 1, rows_per_slot, M, C, c, lds);
+    if ((threadIdx.x >> 6) == 0 && c < C) {
+        const double mean = r.s1 / (double)M;
+        double m2 = r.s2 - (double)M * mean * mean;
+        if (m2 < 0.0) m2 = 0.0;
+        const double var = m2 / (double)M;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = gamma[c] * invstd;
         scale[c] = sc;
@@ -108,7 +146,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         save_mean[c] = (float)mean;
         save_invstd[c] = invstd;
         if (run_mean) {
-            const double unbiased = M > 1 ? red[0] / (double)(M - 1) : var;
+            const double unbiased = M > 1 ? m2 / (double)(M - 1) : var;
             run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
             run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unbiased;
         }
@@ -660,6 +698,53 @@ __global__ __launch_bounds__(256) void im2col_stem_kernel(const TI* __restrict__
     }
 }
 
+// the stem's own shape (7x7x3, compile-time divisors), 8 columns = one 16-byte (bf16) / two 16-byte (f32) stores per thread
+template <typename TO>
+__global__ __launch_bounds__(256) void im2col_stem7_kernel(const float* __restrict__ x, int N, int H, int W, int stride, int pad,
+                                                           int reflect, int Ho, int Wo, int Kp, TO* __restrict__ out) {
+    constexpr int KW = 7, CIN = 3, K = 147;
+    const int cpr = Kp / 8;                                 // 8-column chunks per row
+    const long total = (long)N * Ho * Wo * cpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % cpr);
+        long t = i / cpr;
+        const int ow = (int)(t % Wo);
+        t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ch * 8 + e;
+            v[e] = 0.0f;
+            if (k < K) {
+                const int ci = k % CIN, kw = (k / CIN) % KW, kh = k / (CIN * KW);
+                int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+                if (reflect) {
+                    if (ih < 0) ih = -ih;
+                    if (ih >= H) ih = 2 * H - 2 - ih;
+                    if (iw < 0) iw = -iw;
+                    if (iw >= W) iw = 2 * W - 2 - iw;
+                }
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W) v[e] = x[(((long)n * H + ih) * W + iw) * CIN + ci];
+            }
+        }
+        TO* dst = out + i * 8;
+        if constexpr (sizeof(TO) == 2) {
+            u32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
+                r[e] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+            }
+            *reinterpret_cast<u32x4*>(dst) = r;
+        } else {
+            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+    }
+}
+
 // gradient of reflect padding (pad 1): gp [N, H+2, W+2, C] -> gx [N, H, W, C]
 template <typename T>
 __global__ __launch_bounds__(256) void reflect_fold_kernel(const T* __restrict__ gp, int N, int H, int W, int C, T* __restrict__ gx) {
@@ -702,11 +787,19 @@ static inline unsigned grid_for(long work, int per_block = 256, long cap = 8192)
     return (unsigned)b;
 }
 
-hipError_t launch_bn_finalize(const float* partial, long n_slots, int rows_per_slot, long M, int C, const float* gamma,
+hipError_t launch_bn_finalize(float* partial, long n_slots, int rows_per_slot, long M, int C, const float* gamma,
                               const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
                               float* shift, float* save_mean, float* save_invstd, hipStream_t st_) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st_, partial, n_slots, rows_per_slot, M, C, gamma, beta,
-                       run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd);
+    long spg = 1;                                           // slots per group of level 1
+    if (n_slots > 128) {
+        spg = (n_slots + 127) / 128;
+        if (spg < 16) spg = 16;
+        const long groups = (n_slots + spg - 1) / spg;
+        hipLaunchKernelGGL(bn_stats_merge_kernel, dim3((C + 63) / 64, (unsigned)groups), dim3(256), 0, st_, partial, n_slots, spg,
+                           rows_per_slot, M, C);
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st_, partial, n_slots, spg, rows_per_slot, M, C, gamma,
+                       beta, run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd);
     return hipGetLastError();
 }
 
@@ -835,6 +928,16 @@ hipError_t launch_reduce_partials(const float* partial, long n_blocks, long n, f
 
 hipError_t launch_im2col_stem(int out_bf16, const float* x, int N, int H, int W, int Cin, int KH, int KW, int stride, int pad,
                               int reflect, int Ho, int Wo, int Kp, void* out, hipStream_t st_) {
+    if (KH == 7 && KW == 7 && Cin == 3 && Kp % 8 == 0) {
+        const unsigned g8 = grid_for((long)N * Ho * Wo * (Kp / 8));
+        if (out_bf16)
+            hipLaunchKernelGGL((im2col_stem7_kernel<__bf16>), dim3(g8), dim3(256), 0, st_, x, N, H, W, stride, pad, reflect, Ho, Wo, Kp,
+                               (__bf16*)out);
+        else
+            hipLaunchKernelGGL((im2col_stem7_kernel<float>), dim3(g8), dim3(256), 0, st_, x, N, H, W, stride, pad, reflect, Ho, Wo, Kp,
+                               (float*)out);
+        return hipGetLastError();
+    }
     const unsigned gr = grid_for((long)N * Ho * Wo * Kp);
     if (out_bf16)
         hipLaunchKernelGGL((im2col_stem_kernel<float, __bf16>), dim3(gr), dim3(256), 0, st_, x, N, H, W, Cin, KH, KW, stride, pad,

@@ -186,7 +186,8 @@ class CPSTrainer:
                 for t in list(m.parameters()) + list(m.buffers()):
                     dist.broadcast(t.data, src=0)
         self.buckets = [GradBuckets(list(m.parameters()), cfg.bucket_mb) for m in self.models]
-        self.opts = [torch.optim.Adam(m.parameters(), lr=cfg.learning_rate, betas=(0.9, 0.999)) for m in self.models]
+        self.opts = [torch.optim.Adam(m.parameters(), lr=cfg.learning_rate, betas=(0.9, 0.999), fused=self.device.type == "cuda")
+                     for m in self.models]
         self.sched = CosineAnnealingLR(cfg.learning_rate, cfg.min_lr, cfg.total_iters, cfg.warmup_steps)
         self.ce = nn.CrossEntropyLoss(ignore_index=255)
         self.criterion = make_loss(cfg.criterion, cfg.num_classes, ignore_index=255)
