@@ -165,7 +165,8 @@ int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, 
  *               (`partial` is CONSUMED: the two-level merge folds group results back into it in place)
  *   apply    -> out = relu?( y*scale + shift (+ res) )
  *   backward -> gz = g_out * (out > 0); dgamma, dbeta; g_y (train: with the batch-statistics terms);
- *               g_res = gz when a residual branch exists. */
+ *               g_res = gz when a residual branch exists.  Without a residual `out` may be NULL: the mask is then
+ *               recomputed as fma(y, fwd_scale, fwd_shift) > 0, the forward's own expression (one tensor read less). */
 int vqseg_bn_finalize_f(float* partial, int64_t m_rows, int c, const float* gamma, const float* beta,
                         float* run_mean, float* run_var, float momentum, float eps, int training,
                         float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
@@ -173,12 +174,15 @@ int vqseg_bn_apply_f(int bf16, const void* y, const void* res, const float* scal
                      int64_t m_rows, int c, int relu, void* out, void* stream);
 size_t vqseg_bn_backward_workspace_floats(int64_t m_rows, int c);
 int vqseg_bn_backward_f(int bf16, const void* g_out, const void* out, const void* y, const float* mean,
-                        const float* invstd, const float* gamma, int64_t m_rows, int c, int relu, int training,
+                        const float* invstd, const float* gamma, const float* fwd_scale, const float* fwd_shift,
+                        int64_t m_rows, int c, int relu, int training,
                         float* workspace, float* dgamma, float* dbeta, void* g_y, void* g_res, void* stream);
 
-/* nn.MaxPool2d(3, 2, 1) (resnet.py:167) forward / backward (first maximum in scan order). */
+/* nn.MaxPool2d(3, 2, 1) (resnet.py:167) forward / backward (first maximum in scan order).
+ * idx (nullable, uint8 [n, ho, wo, c]): forward writes the window position (kh*3+kw) of each maximum; backward
+ * reads it instead of recomputing the arg-max from x (x may then be NULL). */
 int vqseg_maxpool3x3s2_f(int bf16, int backward, const void* x, const void* g, int n, int h, int w, int c,
-                         void* out, void* stream);
+                         void* out, unsigned char* idx, void* stream);
 
 /* Bilinear resize: F.interpolate(mode='bilinear') (decoder.py:35, align_corners = 0) and
  * nn.UpsamplingBilinear2d (modified_vqunet/net.py:1172, align_corners = 1).

@@ -581,7 +581,7 @@ struct TileRows {                                           // tile row -> outpu
     }
 };
 
-template <int BN, int NBW>
+template <int BN, int NBW, bool UNROLL_TAPS>
 __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     constexpr int TBM = 256, NW = 8;
     constexpr int WN = BN / 64, WM = NW / WN;              // wave grid; wave tile (MT*32) px x 64 co
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     int wslot = 0;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const bool more = chunk + 1 < n_chunks;
-#pragma unroll
+#pragma unroll UNROLL_TAPS ? 9 : 1
         for (int tap = 0; tap < 9; ++tap) {
             const int s = chunk * 9 + tap;
             // younger instructions still allowed in flight
@@ -749,11 +749,23 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
 }
 
 static int g_patch_min_wgs = 256;
+static int g_patch_wide = 1;                                // 0: never take the 256-channel tile (a/b measurements)
+static int g_patch_unroll = 1;                              // 128-channel tile: tap loop unrolled
 
 int conv_set_option(const char* key, int value) {
     if (key && !strcmp(key, "conv3x3_patch_min_workgroups")) {
         const int prev = g_patch_min_wgs;
         g_patch_min_wgs = value;
+        return prev;
+    }
+    if (key && !strcmp(key, "conv3x3_patch_unroll")) {
+        const int prev = g_patch_unroll;
+        g_patch_unroll = value ? 1 : 0;
+        return prev;
+    }
+    if (key && !strcmp(key, "conv3x3_patch_wide_tile")) {
+        const int prev = g_patch_wide;
+        g_patch_wide = value ? 1 : 0;
         return prev;
     }
     return -1;
@@ -767,12 +779,12 @@ static bool conv3x3_patch_ok(const ConvArgs& a) {
     return (long)a.N * (a.H / th) * (a.W / tw) * (a.Cout / 128) >= g_patch_min_wgs;   // at least one workgroup per CU
 }
 
-template <int BN, int NBW>
+template <int BN, int NBW, bool UNROLL_TAPS>
 static void launch_patch_t(const ConvArgs& a, hipStream_t st) {
     const size_t lds = 2 * 48 * 1024 + (size_t)NBW * BN * 128;
     const int tw = (a.W % 32 == 0) ? 32 : 16, th = 256 / tw;
     dim3 grid((unsigned)((long)a.N * (a.H / th) * (a.W / tw)), (unsigned)(a.Cout / BN));
-    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS>), grid, dim3(512), lds, st, a);
 }
 
 // ------------------------------------------------------------------------------------
@@ -829,7 +841,15 @@ hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
         else if (bn == 64) launch_t<64, true, 32>(a, st);
         else launch_t<32, true, 32>(a, st);
     } else if (k64 && conv3x3_patch_ok(a)) {
-        launch_patch_t<128, 3>(a, st);
+        const int tw = (a.W % 32 == 0) ? 32 : 16, th = 256 / tw;
+        const long tiles = (long)a.N * (a.H / th) * (a.W / tw);
+        // 256-wide channel tile (wave tile 128 px x 64 co: 25 % fewer LDS fragment reads per MFMA) when it still fills the chip
+        if (a.Cout % 256 == 0 && g_patch_wide && tiles * (a.Cout / 256) >= g_patch_min_wgs)
+            launch_patch_t<256, 2, false>(a, st);
+        else if (g_patch_unroll)
+            launch_patch_t<128, 3, true>(a, st);
+        else
+            launch_patch_t<128, 3, false>(a, st);
     } else if (k64) {
         // L2 -> LDS operand traffic bounds this kernel (~35 B/clk/CU): prefer the largest tile that still yields
         // at least ~2 waves of workgroups over the 256 CUs

@@ -134,20 +134,23 @@ size_t vqseg_bn_backward_workspace_floats(int64_t m_rows, int c) {
 }
 
 int vqseg_bn_backward_f(int bf16, const void* g_out, const void* out, const void* y, const float* mean, const float* invstd,
-                        const float* gamma, int64_t m_rows, int c, int relu, int training, float* workspace, float* dgamma,
-                        float* dbeta, void* g_y, void* g_res, void* stream) {
-    if (!g_out || !y || !mean || !invstd || !gamma || !workspace || !dgamma || !dbeta || !g_y || (relu && !out)) return bad("bn_backward: null pointer");
+                        const float* gamma, const float* fwd_scale, const float* fwd_shift, int64_t m_rows, int c, int relu,
+                        int training, float* workspace, float* dgamma, float* dbeta, void* g_y, void* g_res, void* stream) {
+    if (!g_out || !y || !mean || !invstd || !gamma || !workspace || !dgamma || !dbeta || !g_y) return bad("bn_backward: null pointer");
+    if (relu && !out && (!fwd_scale || !fwd_shift)) return bad("bn_backward: with ReLU pass either `out` or the forward scale/shift");
+    if (relu && !out && g_res) return bad("bn_backward: a residual branch needs `out` (the mask depends on the residual)");
     if (c <= 0) return bad("bn_backward: unsupported channel count");
     float* partial = workspace;
     float* coef = workspace + (size_t)vqseg::bn_bwd_blocks(m_rows) * 2 * c;
-    hipError_t e = vqseg::launch_bn_backward(bf16, g_out, out, y, mean, invstd, gamma, m_rows, c, relu, training, partial, coef,
+    hipError_t e = vqseg::launch_bn_backward(bf16, g_out, out, y, mean, invstd, gamma, fwd_scale, fwd_shift, m_rows, c, relu, training, partial, coef,
                                              dgamma, dbeta, g_y, g_res, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hipfail(e, "bn_backward");
 }
 
-int vqseg_maxpool3x3s2_f(int bf16, int backward, const void* x, const void* g, int n, int h, int w, int c, void* out, void* stream) {
-    if (!x || !out || (backward && !g)) return bad("maxpool: null pointer");
-    hipError_t e = vqseg::launch_maxpool(bf16, backward, x, g, n, h, w, c, out, static_cast<hipStream_t>(stream));
+int vqseg_maxpool3x3s2_f(int bf16, int backward, const void* x, const void* g, int n, int h, int w, int c, void* out,
+                         unsigned char* idx, void* stream) {
+    if (!out || (!x && !(backward && idx)) || (backward && !g)) return bad("maxpool: null pointer");
+    hipError_t e = vqseg::launch_maxpool(bf16, backward, x, g, n, h, w, c, out, idx, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hipfail(e, "maxpool");
 }
 

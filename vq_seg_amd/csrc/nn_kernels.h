@@ -15,10 +15,11 @@ hipError_t launch_bn_apply(int bf16, const void* y, const void* res, const float
                            int relu, void* out, hipStream_t st);
 long bn_bwd_blocks(long M);
 hipError_t launch_bn_backward(int bf16, const void* g_out, const void* out, const void* y, const float* mean,
-                              const float* invstd, const float* gamma, long M, int C, int relu, int training, float* partial,
-                              float* coef, float* dgamma, float* dbeta, void* g_y, void* g_res, hipStream_t st);
+                              const float* invstd, const float* gamma, const float* fwd_scale, const float* fwd_shift, long M,
+                              int C, int relu, int training, float* partial, float* coef, float* dgamma, float* dbeta, void* g_y,
+                              void* g_res, hipStream_t st);
 hipError_t launch_maxpool(int bf16, int backward, const void* x, const void* g, int N, int H, int W, int C, void* out,
-                          hipStream_t st);
+                          unsigned char* idx, hipStream_t st);
 hipError_t launch_bilinear(int bf16, int backward, const void* src, int N, int H, int W, int C, int Ho, int Wo, int align,
                            void* dst, hipStream_t st);
 hipError_t launch_head_fwd(int bf16, const void* x, const float* w, long M, int Cin, int Cout, float* y, hipStream_t st);

@@ -230,10 +230,12 @@ constexpr int BNB_CG = 64;         // channels per block
 
 // grid (row chunks, channel groups).  Each thread owns V consecutive channels (one 16-byte load) of every
 // (256 / threads-per-row)-th row of the chunk; row lanes are folded through LDS in a fixed order.
-template <typename T>
+// MASK: 0 no ReLU, 1 mask from `out`, 2 mask recomputed as fma(y, fsc, fsh) > 0 (the forward's expression; no residual)
+template <typename T, int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ g_out, const T* __restrict__ out,
                                                             const T* __restrict__ y, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, long M, int C, int relu,
+                                                            const float* __restrict__ invstd, const float* __restrict__ fsc,
+                                                            const float* __restrict__ fsh, long M, int C, int relu,
                                                             float* __restrict__ partial) {
     constexpr int V = VecN<T>::N;
     __shared__ float sh[2][256 * V];                       // [sum kind][row lane][channel in group]
@@ -250,11 +252,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         rl = threadIdx.x / tpr;
         cv = (threadIdx.x % tpr) * V;
         if (rl < lanes && c0 + cv < C) {
-            float mu[V], is[V];
+            float mu[V], is[V], sc[V], sf[V];
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 mu[e] = mean[c0 + cv + e];
                 is[e] = invstd[c0 + cv + e];
+                sc[e] = MASK == 2 ? fsc[c0 + cv + e] : 0.0f;
+                sf[e] = MASK == 2 ? fsh[c0 + cv + e] : 0.0f;
             }
             for (int rr = rl; rr < BNB_ROWS; rr += lanes) {
                 const long m = row0 + rr;
@@ -262,10 +266,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 float g[V], o[V], yy[V];
                 ldv(g_out, m * C + c0 + cv, g);
                 ldv(y, m * C + c0 + cv, yy);
-                if (relu) ldv(out, m * C + c0 + cv, o);
+                if (MASK == 1) ldv(out, m * C + c0 + cv, o);
+                if (MASK == 2) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) o[e] = __builtin_fmaf(yy[e], sc[e], sf[e]);
+                }
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    const float gz = (relu && !(o[e] > 0.0f)) ? 0.0f : g[e];
+                    const float gz = (MASK != 0 && !(o[e] > 0.0f)) ? 0.0f : g[e];
                     s0[e] += gz;
                     s1[e] = __builtin_fmaf(gz, (yy[e] - mu[e]) * is[e], s1[e]);
                 }
@@ -282,9 +290,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 const long m = row0 + rr;
                 if (m >= M) break;
                 float gz = ld(g_out, m * C + c0 + cv);
-                if (relu && !(ld(out, m * C + c0 + cv) > 0.0f)) gz = 0.0f;
+                const float yv = ld(y, m * C + c0 + cv);
+                if (MASK != 0 && !((MASK == 1 ? ld(out, m * C + c0 + cv) : yv * fsc[c0 + cv] + fsh[c0 + cv]) > 0.0f)) gz = 0.0f;
                 s0[0] += gz;
-                s1[0] = __builtin_fmaf(gz, (ld(y, m * C + c0 + cv) - mu) * is, s1[0]);
+                s1[0] = __builtin_fmaf(gz, (yv - mu) * is, s1[0]);
             }
         }
     }
@@ -340,17 +349,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     }
 }
 
-template <typename T>
+template <typename T, int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ g_out, const T* __restrict__ out,
                                                            const T* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                           const float* __restrict__ fsc, const float* __restrict__ fsh,
                                                            long M, int C, int relu, T* __restrict__ g_y, T* __restrict__ g_res) {
     constexpr int V = VecN<T>::N;
     const long total = M * C;
     if (C % V == 0 && (256 * V) % C == 0) {
         const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * V;
         const int c = (int)(i0 % C);
-        float mu[V], is[V], k0[V], k1[V], k2[V];
+        float mu[V], is[V], k0[V], k1[V], k2[V], sc[V], sf[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             mu[e] = mean[c + e];
@@ -358,15 +368,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             k0[e] = coef[c + e];
             k1[e] = coef[C + c + e];
             k2[e] = coef[2 * C + c + e];
+            sc[e] = MASK == 2 ? fsc[c + e] : 0.0f;
+            sf[e] = MASK == 2 ? fsh[c + e] : 0.0f;
         }
         for (long i = i0; i < total; i += (long)gridDim.x * 256 * V) {
             float g[V], o[V], yy[V], r[V];
             ldv(g_out, i, g);
             ldv(y, i, yy);
-            if (relu) ldv(out, i, o);
+            if (MASK == 1) ldv(out, i, o);
+            if (MASK == 2) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] = __builtin_fmaf(yy[e], sc[e], sf[e]);
+            }
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const float gz = (relu && !(o[e] > 0.0f)) ? 0.0f : g[e];
+                const float gz = (MASK != 0 && !(o[e] > 0.0f)) ? 0.0f : g[e];
                 const float xh = (yy[e] - mu[e]) * is[e];
                 r[e] = gz;
                 g[e] = k0[e] * (gz - k1[e] - xh * k2[e]);
@@ -380,10 +396,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             float g[V], o[V], yy[V], r[V];
             ldv(g_out, i, g);
             ldv(y, i, yy);
-            if (relu) ldv(out, i, o);
+            if (MASK == 1) ldv(out, i, o);
+            if (MASK == 2) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] = __builtin_fmaf(yy[e], fsc[c + e], fsh[c + e]);
+            }
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const float gz = (relu && !(o[e] > 0.0f)) ? 0.0f : g[e];
+                const float gz = (MASK != 0 && !(o[e] > 0.0f)) ? 0.0f : g[e];
                 const float xh = (yy[e] - mean[c + e]) * invstd[c + e];
                 r[e] = gz;
                 g[e] = coef[c + e] * (gz - coef[C + c + e] - xh * coef[2 * C + c + e]);
@@ -395,8 +415,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
             const int c = (int)(i % C);
             float g = ld(g_out, i);
-            if (relu && !(ld(out, i) > 0.0f)) g = 0.0f;
-            const float xh = (ld(y, i) - mean[c]) * invstd[c];
+            const float yv = ld(y, i);
+            if (MASK != 0 && !((MASK == 1 ? ld(out, i) : yv * fsc[c] + fsh[c]) > 0.0f)) g = 0.0f;
+            const float xh = (yv - mean[c]) * invstd[c];
             st(g_y, i, coef[c] * (g - coef[C + c] - xh * coef[2 * C + c]));
             if (g_res) st(g_res, i, g);
         }
@@ -421,7 +442,7 @@ __device__ __forceinline__ void stc(T* p, long i, const float (&v)[VecN<T>::N]) 
 
 template <typename T, int VC>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C, int Ho, int Wo,
-                                                          T* __restrict__ y) {
+                                                          T* __restrict__ y, unsigned char* __restrict__ idx) {
     constexpr int V = VecN<T>::N;
     const int cv = C / VC;
     const long total = (long)N * Ho * Wo * cv;
@@ -433,8 +454,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         const int oh = (int)(t % Ho);
         const int n = (int)(t / Ho);
         float best[V];
+        unsigned char bpos[V];
 #pragma unroll
-        for (int e = 0; e < VC; ++e) best[e] = -__builtin_inff();
+        for (int e = 0; e < VC; ++e) {
+            best[e] = -__builtin_inff();
+            bpos[e] = 255;
+        }
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = oh * 2 - 1 + kh;
             if (ih < 0 || ih >= H) continue;
@@ -445,10 +470,70 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                 ldc<T, VC>(x, (((long)n * H + ih) * W + iw) * C + c, v);
 #pragma unroll
                 for (int e = 0; e < VC; ++e)
-                    if (v[e] > best[e] || v[e] != v[e]) best[e] = v[e];
+                    if (v[e] > best[e] || v[e] != v[e]) {
+                        best[e] = v[e];
+                        bpos[e] = (unsigned char)(kh * 3 + kw);
+                    }
             }
         }
-        stc<T, VC>(y, (((long)n * Ho + oh) * Wo + ow) * C + c, best);
+        const long o = (((long)n * Ho + oh) * Wo + ow) * C + c;
+        stc<T, VC>(y, o, best);
+        if (idx) {                                          // window position (kh * 3 + kw) of the maximum, for the backward
+#pragma unroll
+            for (int e = 0; e < VC; ++e) idx[o + e] = bpos[e];
+        }
+    }
+}
+
+// backward from the saved window positions: an input pixel gathers g of the (at most four) windows whose maximum it is
+template <typename T, int VC>
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const unsigned char* __restrict__ idx, const T* __restrict__ g, int N,
+                                                              int H, int W, int C, int Ho, int Wo, T* __restrict__ gx) {
+    constexpr int V = VecN<T>::N;
+    const int cv = C / VC;
+    const long total = (long)N * H * W * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv) * VC;
+        long t = i / cv;
+        const int iw = (int)(t % W);
+        t /= W;
+        const int ih = (int)(t % H);
+        const int n = (int)(t / H);
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < VC; ++e) acc[e] = 0.0f;
+        for (int oh = ih / 2; oh <= (ih + 1) / 2 && oh < Ho; ++oh) {
+            const int kh = ih - (oh * 2 - 1);
+            if (kh < 0 || kh > 2) continue;
+            for (int ow = iw / 2; ow <= (iw + 1) / 2 && ow < Wo; ++ow) {
+                const int kw = iw - (ow * 2 - 1);
+                if (kw < 0 || kw > 2) continue;
+                const long o = (((long)n * Ho + oh) * Wo + ow) * C + c;
+                const unsigned char me = (unsigned char)(kh * 3 + kw);
+                unsigned char pos[V];
+                if constexpr (VC == 8) {
+                    const unsigned long long raw = *reinterpret_cast<const unsigned long long*>(idx + o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pos[e] = (unsigned char)(raw >> (8 * e));
+                } else if constexpr (VC == 4) {
+                    const unsigned int raw = *reinterpret_cast<const unsigned int*>(idx + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pos[e] = (unsigned char)(raw >> (8 * e));
+                } else {
+                    pos[0] = idx[o];
+                }
+                bool any = false;
+#pragma unroll
+                for (int e = 0; e < VC; ++e) any = any || pos[e] == me;
+                if (!any) continue;
+                float gv[V];
+                ldc<T, VC>(g, o, gv);
+#pragma unroll
+                for (int e = 0; e < VC; ++e)
+                    if (pos[e] == me) acc[e] += gv[e];
+            }
+        }
+        stc<T, VC>(gx, (((long)n * H + ih) * W + iw) * C + c, acc);
     }
 }
 
@@ -746,13 +831,15 @@ __global__ __launch_bounds__(256) void im2col_stem7_kernel(const float* __restri
 }
 
 // gradient of reflect padding (pad 1): gp [N, H+2, W+2, C] -> gx [N, H, W, C]
-template <typename T>
+template <typename T, int VC>
 __global__ __launch_bounds__(256) void reflect_fold_kernel(const T* __restrict__ gp, int N, int H, int W, int C, T* __restrict__ gx) {
-    const long total = (long)N * H * W * C;
+    constexpr int V = VecN<T>::N;
+    const int cv = C / VC;
+    const long total = (long)N * H * W * cv;
     const int Hp = H + 2, Wp = W + 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        long t = i / C;
+        const int c = (int)(i % cv) * VC;
+        long t = i / cv;
         const int w = (int)(t % W);
         t /= W;
         const int h = (int)(t % H);
@@ -765,10 +852,17 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const T* __restrict__
         ws[nw++] = w + 1;
         if (w == 1) ws[nw++] = 0;
         if (w == W - 2) ws[nw++] = Wp - 1;
-        float acc = 0.0f;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < VC; ++e) acc[e] = 0.0f;
         for (int a = 0; a < nh; ++a)
-            for (int b = 0; b < nw; ++b) acc += ld(gp, (((long)n * Hp + hs[a]) * Wp + ws[b]) * C + c);
-        st(gx, i, acc);
+            for (int b = 0; b < nw; ++b) {
+                float v[V];
+                ldc<T, VC>(gp, (((long)n * Hp + hs[a]) * Wp + ws[b]) * C + c, v);
+#pragma unroll
+                for (int e = 0; e < VC; ++e) acc[e] += v[e];
+            }
+        stc<T, VC>(gx, (((long)n * H + h) * W + w) * C + c, acc);
     }
 }
 
@@ -825,26 +919,36 @@ hipError_t launch_bn_apply(int bf16, const void* y, const void* res, const float
 
 long bn_bwd_blocks(long M) { return (M + BNB_ROWS - 1) / BNB_ROWS; }
 
-template <typename T>
+template <typename T, int MASK>
 static hipError_t bn_bwd_t(const void* g_out, const void* out, const void* y, const float* mean, const float* invstd,
-                           const float* gamma, long M, int C, int relu, int training, float* partial, float* coef,
+                           const float* gamma, const float* fsc, const float* fsh, long M, int C, int relu, int training,
+                           float* partial, float* coef,
                            float* dgamma, float* dbeta, void* g_y, void* g_res, hipStream_t st_) {
     const long nb = bn_bwd_blocks(M);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3((unsigned)nb, (unsigned)((C + BNB_CG - 1) / BNB_CG)), dim3(256), 0, st_,
-                       (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, M, C, relu, partial);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK>), dim3((unsigned)nb, (unsigned)((C + BNB_CG - 1) / BNB_CG)), dim3(256), 0, st_,
+                       (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, fsc, fsh, M, C, relu, partial);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st_, partial, nb, M, C, gamma, invstd, training, dgamma,
                        dbeta, coef);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_, (const T*)g_out, (const T*)out,
-                       (const T*)y, mean, invstd, coef, M, C, relu, (T*)g_y, (T*)g_res);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK>), dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_,
+                       (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, coef, fsc, fsh, M, C, relu, (T*)g_y, (T*)g_res);
     return hipGetLastError();
 }
 hipError_t launch_bn_backward(int bf16, const void* g_out, const void* out, const void* y, const float* mean,
-                              const float* invstd, const float* gamma, long M, int C, int relu, int training, float* partial,
+                              const float* invstd, const float* gamma, const float* fsc, const float* fsh, long M, int C, int relu,
+                              int training, float* partial,
                               float* coef, float* dgamma, float* dbeta, void* g_y, void* g_res, hipStream_t st_) {
-    return bf16 ? bn_bwd_t<__bf16>(g_out, out, y, mean, invstd, gamma, M, C, relu, training, partial, coef, dgamma, dbeta, g_y,
-                                   g_res, st_)
-                : bn_bwd_t<float>(g_out, out, y, mean, invstd, gamma, M, C, relu, training, partial, coef, dgamma, dbeta, g_y,
-                                  g_res, st_);
+    const int mask = !relu ? 0 : (out ? 1 : 2);
+#define BN_BWD_CASE(T_, MASK_)                                                                                                   \
+    if (mask == MASK_)                                                                                                            \
+        return bn_bwd_t<T_, MASK_>(g_out, out, y, mean, invstd, gamma, fsc, fsh, M, C, relu, training, partial, coef, dgamma, dbeta, \
+                                   g_y, g_res, st_);
+    if (bf16) {
+        BN_BWD_CASE(__bf16, 0) BN_BWD_CASE(__bf16, 1) BN_BWD_CASE(__bf16, 2)
+    } else {
+        BN_BWD_CASE(float, 0) BN_BWD_CASE(float, 1) BN_BWD_CASE(float, 2)
+    }
+#undef BN_BWD_CASE
+    return hipErrorInvalidValue;
 }
 
 #define DISPATCH_T(bf16, CALL_F, CALL_B) \
@@ -854,24 +958,27 @@ hipError_t launch_bn_backward(int bf16, const void* g_out, const void* out, cons
 
 template <typename T, int VC>
 static void maxpool_t(int backward, const void* x, const void* g, int N, int H, int W, int C, int Ho, int Wo, void* out,
-                      hipStream_t st_) {
+                      unsigned char* idx, hipStream_t st_) {
     if (!backward)
         hipLaunchKernelGGL((maxpool_fwd_kernel<T, VC>), dim3(grid_for((long)N * Ho * Wo * (C / VC))), dim3(256), 0, st_, (const T*)x, N, H,
-                           W, C, Ho, Wo, (T*)out);
+                           W, C, Ho, Wo, (T*)out, idx);
+    else if (idx)
+        hipLaunchKernelGGL((maxpool_bwd_idx_kernel<T, VC>), dim3(grid_for((long)N * H * W * (C / VC))), dim3(256), 0, st_, idx,
+                           (const T*)g, N, H, W, C, Ho, Wo, (T*)out);
     else
         hipLaunchKernelGGL((maxpool_bwd_kernel<T, VC>), dim3(grid_for((long)N * H * W * (C / VC))), dim3(256), 0, st_, (const T*)x,
                            (const T*)g, N, H, W, C, Ho, Wo, (T*)out);
 }
 
 hipError_t launch_maxpool(int bf16, int backward, const void* x, const void* g, int N, int H, int W, int C, void* out,
-                          hipStream_t st_) {
+                          unsigned char* idx, hipStream_t st_) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     if (bf16) {
-        if (C % 8 == 0) maxpool_t<__bf16, 8>(backward, x, g, N, H, W, C, Ho, Wo, out, st_);
-        else maxpool_t<__bf16, 1>(backward, x, g, N, H, W, C, Ho, Wo, out, st_);
+        if (C % 8 == 0) maxpool_t<__bf16, 8>(backward, x, g, N, H, W, C, Ho, Wo, out, idx, st_);
+        else maxpool_t<__bf16, 1>(backward, x, g, N, H, W, C, Ho, Wo, out, idx, st_);
     } else {
-        if (C % 4 == 0) maxpool_t<float, 4>(backward, x, g, N, H, W, C, Ho, Wo, out, st_);
-        else maxpool_t<float, 1>(backward, x, g, N, H, W, C, Ho, Wo, out, st_);
+        if (C % 4 == 0) maxpool_t<float, 4>(backward, x, g, N, H, W, C, Ho, Wo, out, idx, st_);
+        else maxpool_t<float, 1>(backward, x, g, N, H, W, C, Ho, Wo, out, idx, st_);
     }
     return hipGetLastError();
 }
@@ -948,10 +1055,20 @@ hipError_t launch_im2col_stem(int out_bf16, const float* x, int N, int H, int W,
     return hipGetLastError();
 }
 
+template <typename T, int VC>
+static void reflect_fold_t(const void* gp, int N, int H, int W, int C, void* gx, hipStream_t st_) {
+    hipLaunchKernelGGL((reflect_fold_kernel<T, VC>), dim3(grid_for((long)N * H * W * (C / VC))), dim3(256), 0, st_, (const T*)gp, N, H,
+                       W, C, (T*)gx);
+}
+
 hipError_t launch_reflect_fold(int bf16, const void* gp, int N, int H, int W, int C, void* gx, hipStream_t st_) {
-    const unsigned gr = grid_for((long)N * H * W * C);
-    DISPATCH_T(bf16, hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3(gr), dim3(256), 0, st_, (const float*)gp, N, H, W, C, (float*)gx),
-               hipLaunchKernelGGL(reflect_fold_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, (const __bf16*)gp, N, H, W, C, (__bf16*)gx));
+    if (bf16) {
+        if (C % 8 == 0) reflect_fold_t<__bf16, 8>(gp, N, H, W, C, gx, st_);
+        else reflect_fold_t<__bf16, 1>(gp, N, H, W, C, gx, st_);
+    } else {
+        if (C % 4 == 0) reflect_fold_t<float, 4>(gp, N, H, W, C, gx, st_);
+        else reflect_fold_t<float, 1>(gp, N, H, W, C, gx, st_);
+    }
     return hipGetLastError();
 }
 

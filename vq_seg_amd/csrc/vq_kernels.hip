@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void vq_unpack_keys(const unsigned long long* 
 // gather + straight-through + commitment partial sums + code histogram (HBM-bound)
 // ------------------------------------------------------------------------------------
 constexpr int GATHER_BLOCKS_MAX = 2048;
-constexpr int GATHER_ROWS_PER_BLOCK = 4;
+constexpr int GATHER_ROWS_PER_BLOCK = 16;   // 4 waves x 4 rows in flight
 
 __global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                         const long long* __restrict__ idx, long N, int C,
@@ -320,27 +320,40 @@ __global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4 = C >> 2;
     float sq = 0.0f;
-    // one wave per row, grid-stride over rows
-    for (long row = (long)blockIdx.x * 4 + wave; row < N; row += (long)gridDim.x * 4) {
-        const long long k = idx[row];
-        if (lane == 0) atomicAdd(hist + k, 1);
-        const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * (long)C);
-        const f32x4* wr = reinterpret_cast<const f32x4*>(W + k * (long)C);
-        f32x4* qr = reinterpret_cast<f32x4*>(quant + row * (long)C);
-        for (int v = lane; v < c4; v += 64) {
-            const f32x4 e = wr[v];
-            if (training) {
-                const f32x4 xv = xr[v];
-                f32x4 q;
+    // one wave per group of RG consecutive rows (their loads are all issued before the first use), grid-stride over groups.
+    // (Per-lane squared-error partials accumulate in a fixed (group, chunk, row) order: deterministic.)
+    constexpr int RG = 4;
+    for (long row0 = ((long)blockIdx.x * 4 + wave) * RG; row0 < N; row0 += (long)gridDim.x * 4 * RG) {
+        long long k[RG];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    q[i] = xv[i] + (e[i] - xv[i]);             // vq_img.py:236, fp32
-                    const float dlt = q[i] - xv[i];
-                    sq = __builtin_fmaf(dlt, dlt, sq);
+        for (int j = 0; j < RG; ++j) k[j] = row0 + j < N ? idx[row0 + j] : 0;
+        if (lane < RG && row0 + lane < N) atomicAdd(hist + idx[row0 + lane], 1);
+        for (int v = lane; v < c4; v += 64) {
+            f32x4 e[RG], xv[RG];
+#pragma unroll
+            for (int j = 0; j < RG; ++j) {
+                if (row0 + j < N) {
+                    e[j] = reinterpret_cast<const f32x4*>(W + k[j] * (long)C)[v];
+                    if (training) xv[j] = reinterpret_cast<const f32x4*>(x + (row0 + j) * (long)C)[v];
                 }
-                qr[v] = q;
-            } else {
-                qr[v] = e;
+            }
+#pragma unroll
+            for (int j = 0; j < RG; ++j) {
+                if (row0 + j < N) {
+                    f32x4* qr = reinterpret_cast<f32x4*>(quant + (row0 + j) * (long)C);
+                    if (training) {
+                        f32x4 q;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            q[i] = xv[j][i] + (e[j][i] - xv[j][i]);   // vq_img.py:236, fp32
+                            const float dlt = q[i] - xv[j][i];
+                            sq = __builtin_fmaf(dlt, dlt, sq);
+                        }
+                        qr[v] = q;
+                    } else {
+                        qr[v] = e[j];
+                    }
+                }
             }
         }
     }

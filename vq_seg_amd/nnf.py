@@ -157,8 +157,10 @@ class _ConvBNAct(torch.autograd.Function):
         ws = torch.empty(L.vqseg_bn_backward_workspace_floats(m, cout), dtype=torch.float32, device=dev)
         dgb = torch.empty(2, cout, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _check(L.vqseg_bn_backward_f(bf, g.data_ptr(), out.data_ptr(), y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
-                                         _dev(gamma.detach(), torch.float32, "bn.weight"), m, cout, int(relu), int(training),
+            # without a residual the ReLU mask is recomputed from y with the forward's scale / shift: `out` is not re-read
+            _check(L.vqseg_bn_backward_f(bf, g.data_ptr(), out.data_ptr() if has_res else None, y.data_ptr(), coef[2].data_ptr(),
+                                         coef[3].data_ptr(), _dev(gamma.detach(), torch.float32, "bn.weight"),
+                                         coef[0].data_ptr(), coef[1].data_ptr(), m, cout, int(relu), int(training),
                                          ws.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), g_y.data_ptr(), _p(g_res),
                                          _stream()), "vqseg_bn_backward_f")
         # ---- weight gradient
@@ -266,21 +268,23 @@ class _MaxPool(torch.autograd.Function):
         n, h, w, c = xr.shape
         ho, wo = _out_size(h, 3, 2, 1), _out_size(w, 3, 2, 1)
         y = torch.empty((n, ho, wo, c), dtype=xr.dtype, device=xr.device)
+        idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=xr.device) if ctx.needs_input_grad[0] else None
         with torch.cuda.device(xr.device):
-            _check(lib().vqseg_maxpool3x3s2_f(_is_bf16(xr), 0, xr.data_ptr(), None, n, h, w, c, y.data_ptr(), _stream()),
+            _check(lib().vqseg_maxpool3x3s2_f(_is_bf16(xr), 0, xr.data_ptr(), None, n, h, w, c, y.data_ptr(), _p(idx), _stream()),
                    "vqseg_maxpool3x3s2_f")
-        ctx.save_for_backward(xr)
+        ctx.save_for_backward(idx)                          # window position of every maximum: the input is not kept
+        ctx.cfg = (n, h, w, c, xr.dtype)
         return _nchw(y)
 
     @staticmethod
     def backward(ctx, g):
-        (xr,) = ctx.saved_tensors
-        n, h, w, c = xr.shape
-        gr = _rows(g).to(xr.dtype)
-        gx = torch.empty_like(xr)
-        with torch.cuda.device(xr.device):
-            _check(lib().vqseg_maxpool3x3s2_f(_is_bf16(xr), 1, xr.data_ptr(), gr.data_ptr(), n, h, w, c, gx.data_ptr(), _stream()),
-                   "vqseg_maxpool3x3s2_f")
+        (idx,) = ctx.saved_tensors
+        n, h, w, c, dt = ctx.cfg
+        gr = _rows(g).to(dt)
+        gx = torch.empty((n, h, w, c), dtype=dt, device=gr.device)
+        with torch.cuda.device(gr.device):
+            _check(lib().vqseg_maxpool3x3s2_f(int(dt == torch.bfloat16), 1, None, gr.data_ptr(), n, h, w, c, gx.data_ptr(),
+                                              idx.data_ptr(), _stream()), "vqseg_maxpool3x3s2_f")
         return _nchw(gx)
 
 
