@@ -153,6 +153,15 @@ int vqseg_conv2d_f(const void* x, const void* x2, int c1, const void* w_hi, cons
 /* Weight gradient of the same convolution: gw[co][ci][kh][kw] (nn.Conv2d layout, f32) =
  * sum_m gy[m][co] * in_tap[m][ci].  im2col = 1: x is a [M][cin] patch matrix of a kh x kw x cin_out
  * convolution (the 7x7 stem) and gw gets [cout][cin_out][kh][kw]. */
+/* The same convolution with a fused per-channel affine epilogue: y = relu?( conv * scale[c] + shift[c] (+ res) ).
+ * This is conv -> eval-mode nn.BatchNorm2d (scale = gamma * rsqrt(running_var + eps), shift = beta - running_mean *
+ * scale; vqseg_bn_finalize_f with training = 0 yields both) -> [+ residual] -> [ReLU] in one pass, for the
+ * no-grad pseudo-label forwards (train_vqreptunet1x1v2.py eval passes). */
+int vqseg_conv2d_affine_f(const void* x, const void* x2, int c1, const void* w_hi, const void* w_lo,
+                          const float* scale, const float* shift, const void* res, int relu, void* y,
+                          int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int reflect,
+                          int ho, int wo, int precise, void* stream);
+
 size_t vqseg_conv2d_wgrad_workspace_bytes(int n, int h, int w, int cin, int ho, int wo, int cout, int kh, int kw);
 int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, int n, int h, int w, int cin,
                          int ho, int wo, int cout, int kh, int kw, int stride, int pad, int reflect, int precise,

@@ -128,6 +128,45 @@ def test_conv_bn_act_forward_backward(case, training, mode):
         assert int(bn_g.num_batches_tracked) == int(bn.num_batches_tracked) + 1   # (copied after the CPU forward)
 
 
+@pytest.mark.parametrize("mode", ["precise", "fast"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bn_act_eval_nograd_fused(case, mode):
+    """Eval-mode, no-grad forward: BatchNorm (running statistics) + residual + ReLU ride in the convolution epilogue
+    (vqseg_conv2d_affine_f).  Same reference and tolerances as the unfused forward."""
+    from vq_seg_amd import nnf
+    import copy
+    n, cin, cout, h, w, k, s, p, reflect, c2, use_res = case
+    if mode == "fast" and (cin % 8 or c2 % 8 or cout % 8):
+        pytest.skip("bf16 mode needs channel counts that are multiples of 8")
+    seed = sum(case[:8]) + 11
+    conv = nn.Conv2d(cin + c2, cout, k, s, p, bias=False, padding_mode="reflect" if reflect else "zeros")
+    bn = nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        conv.weight.copy_(synth.uniform(seed, tuple(conv.weight.shape), -1, 1) * (2.0 / ((cin + c2) * k * k)) ** 0.5)
+        bn.weight.copy_(synth.uniform(seed + 1, (cout,), 0.5, 1.5))
+        bn.bias.copy_(synth.uniform(seed + 2, (cout,), -0.3, 0.3))
+        bn.running_mean.copy_(synth.uniform(seed + 3, (cout,), -0.2, 0.2))
+        bn.running_var.copy_(synth.uniform(seed + 4, (cout,), 0.5, 1.5))
+    conv.eval(), bn.eval()
+    dt = torch.float32 if mode == "precise" else torch.bfloat16
+    x = synth.uniform(seed + 5, (n, cin, h, w), -1, 1).to(dt).float()
+    x2 = synth.uniform(seed + 6, (n, c2, h, w), -1, 1).to(dt).float() if c2 else None
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    res = synth.uniform(seed + 7, (n, cout, ho, wo), -1, 1).to(dt).float() if use_res else None
+    with torch.no_grad():
+        ref = F.relu(bn(conv(torch.cat((x, x2), 1) if c2 else x)) + (res if use_res else 0))
+        conv_g, bn_g = copy.deepcopy(conv).to(dev()), copy.deepcopy(bn).to(dev())
+        out = nnf.conv_bn_act(cl(x).to(dt), conv_g, bn_g, relu=True, residual=cl(res).to(dt) if use_res else None,
+                              x2=cl(x2).to(dt) if c2 else None)
+        lin = nnf.conv_bn_act(cl(x).to(dt), conv_g, bn_g, relu=False, x2=cl(x2).to(dt) if c2 else None)
+        ref_lin = bn(conv(torch.cat((x, x2), 1) if c2 else x))
+    assert out.dtype == dt and not out.requires_grad
+    tol = 2e-4 if mode == "precise" else 3e-2
+    assert rel(out.float(), ref) < tol
+    assert rel(lin.float(), ref_lin) < tol
+    assert torch.equal(bn_g.running_mean.cpu(), bn.running_mean) and int(bn_g.num_batches_tracked) == 0
+
+
 @pytest.fixture
 def force_patch_kernel():
     """Let the patch-reuse 3x3 kernel take small grids too (its dispatch normally wants >= 256 workgroups)."""

@@ -43,6 +43,8 @@ SYMBOLS = {
     "vqseg_conv_pack_weights_f32": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
     "vqseg_conv_stat_slots": (c_int64, [c_int64, c_int]),
     "vqseg_conv2d_f": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 14 + [c_void_p]),
+    "vqseg_conv2d_affine_f": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p] +
+                              [c_int] * 13 + [c_void_p]),
     "vqseg_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int] * 9),
     "vqseg_conv2d_wgrad_f": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 16 + [c_void_p, c_size_t, c_void_p, c_void_p]),
     "vqseg_bn_finalize_f": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,

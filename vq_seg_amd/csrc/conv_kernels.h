@@ -15,6 +15,11 @@ struct ConvArgs {
     void* y;                    // output rows [N, Ho, Wo, Cout]
     float* stat_partial;        // optional [ceil(M/128) * WM][2][Cout] per-wave (mean, M2), else null
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, reflect, up;
+    // optional fused epilogue (eval-mode BatchNorm): y = relu?( conv * ep_scale[c] + ep_shift[c] (+ ep_res) )
+    const float* ep_scale;      // null: plain convolution output
+    const float* ep_shift;
+    const void* ep_res;         // optional residual rows [N, Ho, Wo, Cout] of the activation type
+    int ep_relu;
 };
 
 struct WgradArgs {

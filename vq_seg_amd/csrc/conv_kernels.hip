@@ -104,16 +104,24 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
         // the main loop's last barrier has passed: LDS is free.  Tile [BM][BN] of the output element type.
         constexpr int OS = BN + O_EPC;                      // row stride (elements) -- padded against bank conflicts
         char* ot = smem;
+        const bool ep = p.ep_scale != nullptr, ep_res = ep && p.ep_res != nullptr;
 #pragma unroll
         for (int b = 0; b < NTT; ++b) {
             const int col = (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
+            const bool cok = co0 + col < p.Cout;
+            const float esc = ep && cok ? p.ep_scale[co0 + col] : 1.0f, esh = ep && cok ? p.ep_shift[co0 + col] : 0.0f;
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int row = (wm * MT + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (PRECISE) reinterpret_cast<float*>(ot)[row * OS + col] = acc[a][b][i];
-                    else reinterpret_cast<__bf16*>(ot)[row * OS + col] = (__bf16)acc[a][b][i];
+                    float v = acc[a][b][i];
+                    if (ep) {
+                        v = __builtin_fmaf(v, esc, esh);
+                        if (p.ep_relu && !ep_res && !(v > 0.0f)) v = 0.0f;
+                    }
+                    if (PRECISE) reinterpret_cast<float*>(ot)[row * OS + col] = v;
+                    else reinterpret_cast<__bf16*>(ot)[row * OS + col] = (__bf16)v;
                 }
         }
         __syncthreads();
@@ -123,7 +131,29 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
             const long m = row_to_m(row);
             const int co = co0 + ch * O_EPC;
             if (m < M && co < p.Cout) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(ot + ((size_t)row * OS + ch * O_EPC) * (PRECISE ? 4 : 2));
+                u32x4 v = *reinterpret_cast<const u32x4*>(ot + ((size_t)row * OS + ch * O_EPC) * (PRECISE ? 4 : 2));
+                if (ep_res) {                               // residual add (+ ReLU) on the way out
+                    const u32x4 rv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.ep_res) + (m * p.Cout + co) * (PRECISE ? 4 : 2));
+                    if (PRECISE) {
+                        f32x4 a4 = __builtin_bit_cast(f32x4, v);
+                        const f32x4 r4 = __builtin_bit_cast(f32x4, rv);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a4[e] += r4[e];
+                            if (p.ep_relu && !(a4[e] > 0.0f)) a4[e] = 0.0f;
+                        }
+                        v = __builtin_bit_cast(u32x4, a4);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float lo = __builtin_bit_cast(float, v[e] << 16) + __builtin_bit_cast(float, rv[e] << 16);
+                            float hi = __builtin_bit_cast(float, v[e] & 0xFFFF0000u) + __builtin_bit_cast(float, rv[e] & 0xFFFF0000u);
+                            if (p.ep_relu && !(lo > 0.0f)) lo = 0.0f;
+                            if (p.ep_relu && !(hi > 0.0f)) hi = 0.0f;
+                            v[e] = pack2(lo, hi);
+                        }
+                    }
+                }
                 *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.y) + (m * p.Cout + co) * (PRECISE ? 4 : 2)) = v;
             }
         }
@@ -138,8 +168,18 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
                     const long mv = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                     const long m = row_to_m((int)(mv - m0));
                     if (mv < M && co < p.Cout) {
-                        if (PRECISE) reinterpret_cast<float*>(p.y)[m * p.Cout + co] = acc[a][b][i];
-                        else reinterpret_cast<__bf16*>(p.y)[m * p.Cout + co] = (__bf16)acc[a][b][i];
+                        float v = acc[a][b][i];
+                        if (p.ep_scale) {
+                            v = __builtin_fmaf(v, p.ep_scale[co], p.ep_shift[co]);
+                            if (p.ep_res) {
+                                if (!PRECISE) v = (float)((__bf16)v);       // same rounding points as the staged path
+                                v += PRECISE ? reinterpret_cast<const float*>(p.ep_res)[m * p.Cout + co]
+                                             : (float)reinterpret_cast<const __bf16*>(p.ep_res)[m * p.Cout + co];
+                            }
+                            if (p.ep_relu && !(v > 0.0f)) v = 0.0f;
+                        }
+                        if (PRECISE) reinterpret_cast<float*>(p.y)[m * p.Cout + co] = v;
+                        else reinterpret_cast<__bf16*>(p.y)[m * p.Cout + co] = (__bf16)v;
                     }
                 }
         }

@@ -43,9 +43,10 @@ int64_t vqseg_conv_stat_slots(int64_t m_rows, int cout) {
     return (m_rows + 255) / 256 * (256 / conv_rows_per_slot(cout));       // whole 256-row tiles, 64- or 32-row slots
 }
 
-int vqseg_conv2d_f(const void* x, const void* x2, int c1, const void* w_hi, const void* w_lo, void* y, float* stat_partial,
-                   int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int reflect, int up, int ho,
-                   int wo, int precise, void* stream) {
+static int conv2d_impl(const void* x, const void* x2, int c1, const void* w_hi, const void* w_lo, void* y, float* stat_partial,
+                       const float* ep_scale, const float* ep_shift, const void* ep_res, int ep_relu,
+                       int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int reflect, int up, int ho,
+                       int wo, int precise, void* stream) {
     if (!x || !w_hi || !y || (precise && !w_lo)) return bad("conv2d: null pointer");
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || ho <= 0 || wo <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || up <= 0)
         return bad("conv2d: non-positive dimension");
@@ -62,8 +63,25 @@ int vqseg_conv2d_f(const void* x, const void* x2, int c1, const void* w_hi, cons
     a.y = y; a.stat_partial = stat_partial;
     a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Ho = ho; a.Wo = wo; a.Cout = cout; a.KH = kh; a.KW = kw;
     a.stride = stride; a.pad = pad; a.reflect = reflect; a.up = up;
+    a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_res = ep_res; a.ep_relu = ep_relu;
     hipError_t e = vqseg::launch_conv(a, precise, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hipfail(e, "conv_igemm_kernel");
+}
+
+int vqseg_conv2d_f(const void* x, const void* x2, int c1, const void* w_hi, const void* w_lo, void* y, float* stat_partial,
+                   int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int reflect, int up, int ho,
+                   int wo, int precise, void* stream) {
+    return conv2d_impl(x, x2, c1, w_hi, w_lo, y, stat_partial, nullptr, nullptr, nullptr, 0, n, h, w, cin, cout, kh, kw, stride, pad,
+                       reflect, up, ho, wo, precise, stream);
+}
+
+int vqseg_conv2d_affine_f(const void* x, const void* x2, int c1, const void* w_hi, const void* w_lo, const float* scale,
+                          const float* shift, const void* res, int relu, void* y, int n, int h, int w, int cin, int cout, int kh,
+                          int kw, int stride, int pad, int reflect, int ho, int wo, int precise, void* stream) {
+    if (!scale || !shift) return bad("conv2d_affine: null scale / shift");
+    if (res && !a16(res)) return bad("conv2d_affine: pointers must be 16-byte aligned");
+    return conv2d_impl(x, x2, c1, w_hi, w_lo, y, nullptr, scale, shift, res, relu, n, h, w, cin, cout, kh, kw, stride, pad, reflect, 1,
+                       ho, wo, precise, stream);
 }
 
 int vqseg_set_option(const char* key, int value) {

@@ -95,7 +95,7 @@ def _out_size(h, k, s, p):
 # ------------------------------------------------------------------------------------------------
 class _ConvBNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, x2, residual, weight, gamma, beta, bn, stride, pad, reflect, relu, patches_of):
+    def forward(ctx, x, x2, residual, weight, gamma, beta, bn, stride, pad, reflect, relu, patches_of, fuse_eval=False):
         """x (N,C1,H,W) [+ x2 (N,C2,H,W)] -> out (N,Cout,Ho,Wo).  `patches_of` = (kh, kw, cin, stride, pad, reflect,
         H, W) when x is an im2col patch matrix of the stem (then the convolution itself is 1x1)."""
         xr = _rows(x)
@@ -115,12 +115,28 @@ class _ConvBNAct(torch.autograd.Function):
             w_hi, w_lo = _stem_weights(weight, precise, cin)
         else:
             w_hi, w_lo = packed_weights(weight, precise, False)
-        stat = torch.empty(L.vqseg_conv_stat_slots(m, cout) * 2 * cout, dtype=torch.float32, device=dev) if training else None
-        y = _conv_raw(xr, x2r, c1, w_hi, w_lo, (n, ho, wo, cout), stat, n, h, w, cin, cout, kh, kw, stride, pad, reflect, 1,
-                      ho, wo)
         coef = torch.empty(4, cout, dtype=torch.float32, device=dev)       # scale, shift, mean, invstd
         if bn.momentum is None:
             raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not used by the path")
+        if fuse_eval and not training:
+            # eval-mode BatchNorm is a fixed per-channel affine map: it rides in the convolution's epilogue together with
+            # the residual add and the ReLU (the no-grad pseudo-label passes; nothing is kept for a backward)
+            rr = _rows(residual) if residual is not None else None
+            if rr is not None and rr.dtype != xr.dtype:
+                raise _hip.HipLibraryError("residual dtype differs from the activation dtype")
+            out = torch.empty((n, ho, wo, cout), dtype=xr.dtype, device=dev)
+            with torch.cuda.device(dev):
+                _check(L.vqseg_bn_finalize_f(None, m, cout, _dev(gamma, torch.float32, "bn.weight"),
+                                             _dev(beta, torch.float32, "bn.bias"), _p(bn.running_mean), _p(bn.running_var),
+                                             float(bn.momentum), float(bn.eps), 0, coef[0].data_ptr(), coef[1].data_ptr(),
+                                             coef[2].data_ptr(), coef[3].data_ptr(), _stream()), "vqseg_bn_finalize_f")
+                _check(L.vqseg_conv2d_affine_f(xr.data_ptr(), _p(x2r), c1, w_hi.data_ptr(), _p(w_lo), coef[0].data_ptr(),
+                                               coef[1].data_ptr(), _p(rr), int(relu), out.data_ptr(), n, h, w, cin, cout, kh, kw,
+                                               stride, pad, int(reflect), ho, wo, int(precise), _stream()), "vqseg_conv2d_affine_f")
+            return _nchw(out)
+        stat = torch.empty(L.vqseg_conv_stat_slots(m, cout) * 2 * cout, dtype=torch.float32, device=dev) if training else None
+        y = _conv_raw(xr, x2r, c1, w_hi, w_lo, (n, ho, wo, cout), stat, n, h, w, cin, cout, kh, kw, stride, pad, reflect, 1,
+                      ho, wo)
         with torch.cuda.device(dev):
             _check(L.vqseg_bn_finalize_f(_p(stat), m, cout, _dev(gamma, torch.float32, "bn.weight"),
                                          _dev(beta, torch.float32, "bn.bias"), _p(bn.running_mean), _p(bn.running_var),
@@ -206,7 +222,7 @@ class _ConvBNAct(torch.autograd.Function):
                 gx = _nchw(dgrad(0, c1))
             if need2 and x2r is not None:
                 gx2 = _nchw(dgrad(c1, cin - c1))
-        return gx, gx2, (_nchw(g_res) if has_res else None), gw, dgb[0], dgb[1], None, None, None, None, None, None
+        return gx, gx2, (_nchw(g_res) if has_res else None), gw, dgb[0], dgb[1], None, None, None, None, None, None, None
 
 
 def _stem_weights(weight, precise, kp):
@@ -237,7 +253,7 @@ def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None):
         raise _hip.HipLibraryError(f"the HIP path needs 'cuda' (ROCm) tensors, got {x.device}; there is no CPU fallback")
     pad = conv.padding[0]
     return _ConvBNAct.apply(x, x2, residual, conv.weight, bn.weight, bn.bias, bn, conv.stride[0], pad,
-                            conv.padding_mode == "reflect" and pad > 0, relu, None)
+                            conv.padding_mode == "reflect" and pad > 0, relu, None, not bn.training and not torch.is_grad_enabled())
 
 
 def stem_conv_bn_act(x, conv, bn):
@@ -257,7 +273,7 @@ def stem_conv_bn_act(x, conv, bn):
         _check(lib().vqseg_im2col_f(int(dt == torch.bfloat16), xr.data_ptr(), n, h, w, cin, kh, kw, s, p, int(reflect), ho, wo, kp,
                                     patches.data_ptr(), _stream()), "vqseg_im2col_f")
     return _ConvBNAct.apply(_nchw(patches), None, None, conv.weight, bn.weight, bn.bias, bn, 1, 0, False, True,
-                            (kh, kw, cin, s, p, reflect, h, w))
+                            (kh, kw, cin, s, p, reflect, h, w), not bn.training and not torch.is_grad_enabled())
 
 
 # ------------------------------------------------------------------------------------------------
