@@ -162,10 +162,13 @@ int vqseg_conv2d_affine_f(const void* x, const void* x2, int c1, const void* w_h
                           int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int reflect,
                           int ho, int wo, int precise, void* stream);
 
+/* `accumulate` (here and in vqseg_bn_backward_f): the parameter gradient is ADDED to gw / dgamma / dbeta (the
+ * optimiser's gradient buffer) instead of overwriting it -- autograd's own accumulate kernel is then not needed. */
 size_t vqseg_conv2d_wgrad_workspace_bytes(int n, int h, int w, int cin, int ho, int wo, int cout, int kh, int kw);
 int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, int n, int h, int w, int cin,
                          int ho, int wo, int cout, int kh, int kw, int stride, int pad, int reflect, int precise,
-                         int cin_out, int im2col, void* workspace, size_t workspace_bytes, float* gw, void* stream);
+                         int cin_out, int im2col, int accumulate, void* workspace, size_t workspace_bytes, float* gw,
+                         void* stream);
 
 /* nn.BatchNorm2d (+ fused residual add and ReLU).  Training: batch statistics merged from the conv
  * epilogue partials (Welford/Chan, double, fixed order), running stats updated like nn.BatchNorm2d
@@ -184,7 +187,7 @@ int vqseg_bn_apply_f(int bf16, const void* y, const void* res, const float* scal
 size_t vqseg_bn_backward_workspace_floats(int64_t m_rows, int c);
 int vqseg_bn_backward_f(int bf16, const void* g_out, const void* out, const void* y, const float* mean,
                         const float* invstd, const float* gamma, const float* fwd_scale, const float* fwd_shift,
-                        int64_t m_rows, int c, int relu, int training,
+                        int64_t m_rows, int c, int relu, int training, int accumulate,
                         float* workspace, float* dgamma, float* dbeta, void* g_y, void* g_res, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) (resnet.py:167) forward / backward (first maximum in scan order).

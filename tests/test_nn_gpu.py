@@ -267,11 +267,17 @@ def test_wgrad3x3_fused_taps(case):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
     gw = torch.full((cout, cin, 3, 3), float("nan"), dtype=torch.float32, device=dev())
     rc = L.vqseg_conv2d_wgrad_f(gyd.data_ptr(), xa.data_ptr(), xb.data_ptr() if c2 else None, c1, n, h, w, cin, h, w, cout, 3, 3,
-                                1, 1, int(reflect), 0, cin, 0, ws.data_ptr(), nbytes, gw.data_ptr(),
+                                1, 1, int(reflect), 0, cin, 0, 0, ws.data_ptr(), nbytes, gw.data_ptr(),
                                 torch.cuda.current_stream().cuda_stream)
     assert rc == 0, L.vqseg_last_error()
     torch.cuda.synchronize()
     assert rel(gw, ref) < 2e-5
+    # accumulate = 1 adds the same gradient onto gw (the trainer's bucket view)
+    rc = L.vqseg_conv2d_wgrad_f(gyd.data_ptr(), xa.data_ptr(), xb.data_ptr() if c2 else None, c1, n, h, w, cin, h, w, cout, 3, 3,
+                                1, 1, int(reflect), 0, cin, 0, 1, ws.data_ptr(), nbytes, gw.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, L.vqseg_last_error()
+    assert rel(gw, 2 * ref) < 2e-5
 
 
 @pytest.mark.parametrize("mode", ["precise", "fast"])
@@ -362,3 +368,28 @@ def test_kernels_are_deterministic():
         outs.append((o.detach().clone(), xg.grad.clone(), conv.weight.grad.clone()))
     for o in outs[1:]:
         assert all(torch.equal(a, b) for a, b in zip(o, outs[0])), "run-to-run differences"
+
+
+def test_grad_sink_accumulates_in_place():
+    """A parameter marked with `_vq_grad_sink` receives its gradient by in-place accumulation from the HIP kernels:
+    two uses of the same conv+bn in one graph add up in p.grad exactly like autograd's own accumulation, the callback
+    fires once per parameter (after the last contribution), and autograd adds nothing on top."""
+    from vq_seg_amd import nnf
+    import copy
+    torch.manual_seed(0)
+    conv = nn.Conv2d(64, 64, 3, 1, 1, bias=False).to(dev())
+    bn = nn.BatchNorm2d(64).to(dev())
+    conv2, bn2 = copy.deepcopy(conv), copy.deepcopy(bn)
+    xa = cl(synth.uniform(1, (2, 64, 16, 16), -1, 1))
+    xb = cl(synth.uniform(2, (2, 64, 16, 16), -1, 1))
+    # plain autograd accumulation
+    (nnf.conv_bn_act(xa, conv, bn).square().sum() + nnf.conv_bn_act(xb, conv, bn).sum()).backward()
+    # sinks
+    fired = []
+    for p_ in list(conv2.parameters()) + list(bn2.parameters()):
+        p_.grad = torch.full_like(p_, 0.5)
+        p_._vq_grad_sink = lambda q: fired.append(id(q))
+    (nnf.conv_bn_act(xa, conv2, bn2).square().sum() + nnf.conv_bn_act(xb, conv2, bn2).sum()).backward()
+    assert sorted(fired) == sorted(id(q) for q in list(conv2.parameters()) + list(bn2.parameters()))
+    for a_, b_ in zip(list(conv.parameters()) + list(bn.parameters()), list(conv2.parameters()) + list(bn2.parameters())):
+        assert rel(b_.grad - 0.5, a_.grad) < 1e-5

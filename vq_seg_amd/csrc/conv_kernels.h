@@ -36,7 +36,7 @@ int conv_set_option(const char* key, int value);   // previous value, or -1 (unk
 int wgrad_slabs(const WgradArgs& a, int precise);   // slabs launch_wgrad will write
 int wgrad_slabs_max(const WgradArgs& a);           // upper bound from the shape alone (workspace sizing)
 hipError_t launch_wgrad(const WgradArgs& a, int precise, int slabs, int* final_layout, hipStream_t st);
-hipError_t launch_wgrad_reduce(const float* partial, int slabs, int Cout, int Cin, int Cin_out, int KH, int KW, int im2col,
+hipError_t launch_wgrad_reduce(const float* partial, int slabs, int Cout, int Cin, int Cin_out, int KH, int KW, int im2col, int accumulate,
                                float* gw, hipStream_t st);
 size_t packed_elems(int Cout, int Cin, int KH, int KW, int transpose_flip);
 hipError_t launch_pack_weights(const float* w, int Cout, int Cin, int KH, int KW, int transpose_flip, unsigned short* hi,

@@ -1157,7 +1157,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 // sum the slabs in order; emit nn.Conv2d layout [Cout][Cin_out][KH][KW] (Cin_out <= Cin: the stem's padded
 // im2col columns are dropped)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int slabs, int Cout, int Cin,
-                                                           int Cin_out, int KH, int KW, int im2col, float* __restrict__ gw) {
+                                                           int Cin_out, int KH, int KW, int im2col, int accumulate,
+                                                           float* __restrict__ gw) {
     // threads walk the SOURCE (packed) layout so the slabs are read coalesced; the transposing write happens once
     const long slab = (long)Cout * (im2col ? 1 : KH * KW) * Cin;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < slab; i += (long)gridDim.x * 256) {
@@ -1180,7 +1181,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
         double s = 0.0;
         for (int z = 0; z < slabs; ++z) s += (double)partial[(long)z * slab + i];
-        gw[(((long)co * Cin_out + ci) * KH + kh) * KW + kw] = (float)s;
+        float* dst = gw + (((long)co * Cin_out + ci) * KH + kh) * KW + kw;
+        *dst = accumulate ? *dst + (float)s : (float)s;
     }
 }
 
@@ -1508,12 +1510,12 @@ hipError_t launch_wgrad(const WgradArgs& a, int precise, int slabs, int* final_l
 }
 
 hipError_t launch_wgrad_reduce(const float* partial, int slabs, int Cout, int Cin, int Cin_out, int KH, int KW, int im2col,
-                               float* gw, hipStream_t st) {
+                               int accumulate, float* gw, hipStream_t st) {
     const long total = (long)Cout * (im2col ? 1 : KH * KW) * Cin;
     long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, partial, slabs, Cout, Cin, Cin_out, KH, KW,
-                       im2col, gw);
+                       im2col, accumulate, gw);
     return hipGetLastError();
 }
 

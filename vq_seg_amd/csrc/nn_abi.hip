@@ -99,7 +99,7 @@ size_t vqseg_conv2d_wgrad_workspace_bytes(int n, int h, int w, int cin, int ho, 
 
 int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, int n, int h, int w, int cin, int ho, int wo,
                          int cout, int kh, int kw, int stride, int pad, int reflect, int precise, int cin_out, int im2col,
-                         void* workspace, size_t workspace_bytes, float* gw, void* stream) {
+                         int accumulate, void* workspace, size_t workspace_bytes, float* gw, void* stream) {
     if (!gy || !x || !workspace || !gw) return bad("conv2d_wgrad: null pointer");
     const int epc = precise ? 4 : 8;
     if (cin % epc || cout % epc) return bad("conv2d_wgrad: Cin and Cout must be multiples of 4 (f32) / 8 (bf16)");
@@ -116,9 +116,9 @@ int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, 
     hipError_t e = vqseg::launch_wgrad(a, precise, slabs, &final_layout, st);
     if (e != hipSuccess) return hipfail(e, "conv_wgrad_kernel");
     if (final_layout && (cin_out != cin || im2col)) return bad("conv2d_wgrad: internal layout mismatch");
-    if (final_layout) e = vqseg::launch_reduce_partials(a.partial, slabs, (long)cout * cin * kkh * kkw, gw, st);
-    else if (im2col) e = vqseg::launch_wgrad_reduce(a.partial, slabs, cout, cin, cin_out, kh, kw, 1, gw, st);   // kh,kw = ORIGINAL taps here
-    else e = vqseg::launch_wgrad_reduce(a.partial, slabs, cout, cin, cin_out, kh, kw, 0, gw, st);
+    if (final_layout) e = vqseg::launch_reduce_partials(a.partial, slabs, (long)cout * cin * kkh * kkw, gw, accumulate, st);
+    else if (im2col) e = vqseg::launch_wgrad_reduce(a.partial, slabs, cout, cin, cin_out, kh, kw, 1, accumulate, gw, st);   // kh,kw = ORIGINAL taps here
+    else e = vqseg::launch_wgrad_reduce(a.partial, slabs, cout, cin, cin_out, kh, kw, 0, accumulate, gw, st);
     return e == hipSuccess ? 0 : hipfail(e, "wgrad_reduce_kernel");
 }
 
@@ -153,14 +153,15 @@ size_t vqseg_bn_backward_workspace_floats(int64_t m_rows, int c) {
 
 int vqseg_bn_backward_f(int bf16, const void* g_out, const void* out, const void* y, const float* mean, const float* invstd,
                         const float* gamma, const float* fwd_scale, const float* fwd_shift, int64_t m_rows, int c, int relu,
-                        int training, float* workspace, float* dgamma, float* dbeta, void* g_y, void* g_res, void* stream) {
+                        int training, int accumulate, float* workspace, float* dgamma, float* dbeta, void* g_y, void* g_res,
+                        void* stream) {
     if (!g_out || !y || !mean || !invstd || !gamma || !workspace || !dgamma || !dbeta || !g_y) return bad("bn_backward: null pointer");
     if (relu && !out && (!fwd_scale || !fwd_shift)) return bad("bn_backward: with ReLU pass either `out` or the forward scale/shift");
     if (relu && !out && g_res) return bad("bn_backward: a residual branch needs `out` (the mask depends on the residual)");
     if (c <= 0) return bad("bn_backward: unsupported channel count");
     float* partial = workspace;
     float* coef = workspace + (size_t)vqseg::bn_bwd_blocks(m_rows) * 2 * c;
-    hipError_t e = vqseg::launch_bn_backward(bf16, g_out, out, y, mean, invstd, gamma, fwd_scale, fwd_shift, m_rows, c, relu, training, partial, coef,
+    hipError_t e = vqseg::launch_bn_backward(bf16, g_out, out, y, mean, invstd, gamma, fwd_scale, fwd_shift, m_rows, c, relu, training, accumulate, partial, coef,
                                              dgamma, dbeta, g_y, g_res, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hipfail(e, "bn_backward");
 }

@@ -16,7 +16,7 @@ hipError_t launch_bn_apply(int bf16, const void* y, const void* res, const float
 long bn_bwd_blocks(long M);
 hipError_t launch_bn_backward(int bf16, const void* g_out, const void* out, const void* y, const float* mean,
                               const float* invstd, const float* gamma, const float* fwd_scale, const float* fwd_shift, long M,
-                              int C, int relu, int training, float* partial, float* coef, float* dgamma, float* dbeta, void* g_y,
+                              int C, int relu, int training, int accumulate, float* partial, float* coef, float* dgamma, float* dbeta, void* g_y,
                               void* g_res, hipStream_t st);
 hipError_t launch_maxpool(int bf16, int backward, const void* x, const void* g, int N, int H, int W, int C, void* out,
                           unsigned char* idx, hipStream_t st);
@@ -26,7 +26,7 @@ hipError_t launch_head_fwd(int bf16, const void* x, const float* w, long M, int 
 long head_bwd_blocks(long M);
 hipError_t launch_head_bwd(int bf16, const void* x, const float* w, const float* g, long M, int Cin, int Cout, void* gx,
                            float* gw, float* partial, hipStream_t st);
-hipError_t launch_reduce_partials(const float* partial, long n_blocks, long n, float* out, hipStream_t st);
+hipError_t launch_reduce_partials(const float* partial, long n_blocks, long n, float* out, int accumulate, hipStream_t st);
 hipError_t launch_im2col_stem(int out_bf16, const float* x, int N, int H, int W, int Cin, int KH, int KW, int stride, int pad,
                               int reflect, int Ho, int Wo, int Kp, void* out, hipStream_t st);
 hipError_t launch_reflect_fold(int bf16, const void* gp, int N, int H, int W, int C, void* gx, hipStream_t st);

@@ -321,8 +321,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 //   eval : g_y = k0[c] * gz
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, long n_blocks, long M, int C,
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                                              int training, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ coef) {
+                                                              int training, int accumulate, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ coef) {
     const int c = blockIdx.x;
     __shared__ double r0[256], r1[256];
     double a = 0.0, b = 0.0;
@@ -341,8 +341,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        dbeta[c] = (float)r0[0];
-        dgamma[c] = (float)r1[0];
+        dbeta[c] = accumulate ? dbeta[c] + (float)r0[0] : (float)r0[0];
+        dgamma[c] = accumulate ? dgamma[c] + (float)r1[0] : (float)r1[0];
         coef[0 * C + c] = gamma[c] * invstd[c];
         coef[1 * C + c] = training ? (float)(r0[0] / (double)M) : 0.0f;
         coef[2 * C + c] = training ? (float)(r1[0] / (double)M) : 0.0f;
@@ -742,12 +742,12 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const T* __restric
 
 // sum partial[blk][n] over blk in fixed order -> out[n] (double accumulate)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, long n_blocks, long n,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, int accumulate) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     double s = 0.0;
     for (long b = 0; b < n_blocks; ++b) s += (double)partial[b * n + i];
-    out[i] = (float)s;
+    out[i] = accumulate ? out[i] + (float)s : (float)s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -922,12 +922,12 @@ long bn_bwd_blocks(long M) { return (M + BNB_ROWS - 1) / BNB_ROWS; }
 template <typename T, int MASK>
 static hipError_t bn_bwd_t(const void* g_out, const void* out, const void* y, const float* mean, const float* invstd,
                            const float* gamma, const float* fsc, const float* fsh, long M, int C, int relu, int training,
-                           float* partial, float* coef,
+                           int accumulate, float* partial, float* coef,
                            float* dgamma, float* dbeta, void* g_y, void* g_res, hipStream_t st_) {
     const long nb = bn_bwd_blocks(M);
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK>), dim3((unsigned)nb, (unsigned)((C + BNB_CG - 1) / BNB_CG)), dim3(256), 0, st_,
                        (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, fsc, fsh, M, C, relu, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st_, partial, nb, M, C, gamma, invstd, training, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st_, partial, nb, M, C, gamma, invstd, training, accumulate, dgamma,
                        dbeta, coef);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK>), dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_,
                        (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, coef, fsc, fsh, M, C, relu, (T*)g_y, (T*)g_res);
@@ -935,12 +935,12 @@ static hipError_t bn_bwd_t(const void* g_out, const void* out, const void* y, co
 }
 hipError_t launch_bn_backward(int bf16, const void* g_out, const void* out, const void* y, const float* mean,
                               const float* invstd, const float* gamma, const float* fsc, const float* fsh, long M, int C, int relu,
-                              int training, float* partial,
+                              int training, int accumulate, float* partial,
                               float* coef, float* dgamma, float* dbeta, void* g_y, void* g_res, hipStream_t st_) {
     const int mask = !relu ? 0 : (out ? 1 : 2);
 #define BN_BWD_CASE(T_, MASK_)                                                                                                   \
     if (mask == MASK_)                                                                                                            \
-        return bn_bwd_t<T_, MASK_>(g_out, out, y, mean, invstd, gamma, fsc, fsh, M, C, relu, training, partial, coef, dgamma, dbeta, \
+        return bn_bwd_t<T_, MASK_>(g_out, out, y, mean, invstd, gamma, fsc, fsh, M, C, relu, training, accumulate, partial, coef, dgamma, dbeta, \
                                    g_y, g_res, st_);
     if (bf16) {
         BN_BWD_CASE(__bf16, 0) BN_BWD_CASE(__bf16, 1) BN_BWD_CASE(__bf16, 2)
@@ -1024,12 +1024,12 @@ hipError_t launch_head_bwd(int bf16, const void* x, const float* w, const float*
     const long nb = head_bwd_blocks(M);
     DISPATCH_T(bf16, hipLaunchKernelGGL(head_bwd_weight_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st_, (const float*)x, g, M, Cin, Cout, partial),
                hipLaunchKernelGGL(head_bwd_weight_kernel<__bf16>, dim3((unsigned)nb), dim3(256), 0, st_, (const __bf16*)x, g, M, Cin, Cout, partial));
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, st_, partial, nb, (long)Cin * Cout, gw);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, st_, partial, nb, (long)Cin * Cout, gw, 0);
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_partials(const float* partial, long n_blocks, long n, float* out, hipStream_t st_) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st_, partial, n_blocks, n, out);
+hipError_t launch_reduce_partials(const float* partial, long n_blocks, long n, float* out, int accumulate, hipStream_t st_) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st_, partial, n_blocks, n, out, accumulate);
     return hipGetLastError();
 }
 

@@ -91,6 +91,34 @@ def _out_size(h, k, s, p):
 
 
 # ------------------------------------------------------------------------------------------------
+# Gradient sinks.  A trainer that owns the parameters' .grad storage (trainer.GradBuckets: flat fp32 buckets) marks a
+# parameter with `p._vq_grad_sink = callback-or-None`; the weight-gradient kernels then ADD into p.grad themselves
+# (`accumulate` flag of the C entry points) and autograd gets None for that parameter -- one tiny add kernel per
+# parameter and backward pass less.  The callback (if any) is told, as a post-accumulate-grad hook would be.
+# ------------------------------------------------------------------------------------------------
+def _sink_ready(p) -> bool:
+    g = getattr(p, "grad", None)
+    return hasattr(p, "_vq_grad_sink") and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.is_cuda
+
+
+def _sink_use(*params) -> None:
+    """forward (called where the grad mode is still visible): one more gradient contribution will arrive for each
+    of these parameters in the coming backward"""
+    if torch.is_grad_enabled():
+        for p in params:
+            if p.requires_grad and hasattr(p, "_vq_grad_sink"):
+                p._vq_uses = getattr(p, "_vq_uses", 0) + 1
+
+
+def _sink_done(p) -> None:
+    """backward: one contribution has been added into p.grad; the callback fires with the last one"""
+    p._vq_uses = getattr(p, "_vq_uses", 1) - 1
+    cb = p._vq_grad_sink
+    if cb is not None and p._vq_uses <= 0:
+        cb(p)
+
+
+# ------------------------------------------------------------------------------------------------
 # Conv (no bias) -> BatchNorm -> [+ residual] -> [ReLU], optional channel concat of two inputs
 # ------------------------------------------------------------------------------------------------
 class _ConvBNAct(torch.autograd.Function):
@@ -152,6 +180,7 @@ class _ConvBNAct(torch.autograd.Function):
             _check(L.vqseg_bn_apply_f(bf, y.data_ptr(), _p(rr), coef[0].data_ptr(), coef[1].data_ptr(), m, cout, int(relu),
                                       out.data_ptr(), _stream()), "vqseg_bn_apply_f")
         ctx.save_for_backward(xr, x2r, y, out, coef, weight, gamma)
+        ctx.params = (weight, gamma, beta)                                  # the Parameter objects (see grad sinks)
         ctx.cfg = (stride, pad, bool(reflect), bool(relu), training, residual is not None, patches_of, (n, h, w, c1, cin, cout,
                                                                                                          kh, kw, ho, wo))
         return _nchw(out)
@@ -171,31 +200,39 @@ class _ConvBNAct(torch.autograd.Function):
         g_y = torch.empty_like(y)
         g_res = torch.empty_like(y) if has_res else None
         ws = torch.empty(L.vqseg_bn_backward_workspace_floats(m, cout), dtype=torch.float32, device=dev)
-        dgb = torch.empty(2, cout, dtype=torch.float32, device=dev)
+        p_w, p_g, p_b = ctx.params
+        sink_bn = _sink_ready(p_g) and _sink_ready(p_b) and ctx.needs_input_grad[4] and ctx.needs_input_grad[5]
+        sink_w = _sink_ready(p_w) and ctx.needs_input_grad[3]
+        dgb = None if sink_bn else torch.empty(2, cout, dtype=torch.float32, device=dev)
+        dgamma, dbeta = (p_g.grad, p_b.grad) if sink_bn else (dgb[0], dgb[1])
         with torch.cuda.device(dev):
             # without a residual the ReLU mask is recomputed from y with the forward's scale / shift: `out` is not re-read
             _check(L.vqseg_bn_backward_f(bf, g.data_ptr(), out.data_ptr() if has_res else None, y.data_ptr(), coef[2].data_ptr(),
                                          coef[3].data_ptr(), _dev(gamma.detach(), torch.float32, "bn.weight"),
-                                         coef[0].data_ptr(), coef[1].data_ptr(), m, cout, int(relu), int(training),
-                                         ws.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), g_y.data_ptr(), _p(g_res),
+                                         coef[0].data_ptr(), coef[1].data_ptr(), m, cout, int(relu), int(training), int(sink_bn),
+                                         ws.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), g_y.data_ptr(), _p(g_res),
                                          _stream()), "vqseg_bn_backward_f")
+        if sink_bn:
+            _sink_done(p_g), _sink_done(p_b)
         # ---- weight gradient
-        gw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+        gw = p_w.grad if sink_w else torch.empty(weight.shape, dtype=torch.float32, device=dev)
         if patches_of:
             okh, okw, ocin = patches_of[0], patches_of[1], patches_of[2]
             nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, 1, 1)
             wsw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
                 _check(L.vqseg_conv2d_wgrad_f(g_y.data_ptr(), xr.data_ptr(), None, cin, n, h, w, cin, ho, wo, cout, okh, okw, 1, 0,
-                                              0, int(precise), ocin, 1, wsw.data_ptr(), nbytes, gw.data_ptr(), _stream()),
+                                              0, int(precise), ocin, 1, int(sink_w), wsw.data_ptr(), nbytes, gw.data_ptr(), _stream()),
                        "vqseg_conv2d_wgrad_f")
         else:
             nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, kh, kw)
             wsw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
                 _check(L.vqseg_conv2d_wgrad_f(g_y.data_ptr(), xr.data_ptr(), _p(x2r), c1, n, h, w, cin, ho, wo, cout, kh, kw,
-                                              stride, pad, int(reflect), int(precise), cin, 0, wsw.data_ptr(), nbytes,
+                                              stride, pad, int(reflect), int(precise), cin, 0, int(sink_w), wsw.data_ptr(), nbytes,
                                               gw.data_ptr(), _stream()), "vqseg_conv2d_wgrad_f")
+        if sink_w:
+            _sink_done(p_w)
         # ---- data gradient(s): the same implicit-GEMM kernel on g_y with tap-flipped, transposed weights
         gx = gx2 = None
         need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -222,7 +259,8 @@ class _ConvBNAct(torch.autograd.Function):
                 gx = _nchw(dgrad(0, c1))
             if need2 and x2r is not None:
                 gx2 = _nchw(dgrad(c1, cin - c1))
-        return gx, gx2, (_nchw(g_res) if has_res else None), gw, dgb[0], dgb[1], None, None, None, None, None, None, None
+        return (gx, gx2, (_nchw(g_res) if has_res else None), None if sink_w else gw, None if sink_bn else dgb[0],
+                None if sink_bn else dgb[1], None, None, None, None, None, None, None)
 
 
 def _stem_weights(weight, precise, kp):
@@ -252,6 +290,7 @@ def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None):
     if not x.is_cuda:
         raise _hip.HipLibraryError(f"the HIP path needs 'cuda' (ROCm) tensors, got {x.device}; there is no CPU fallback")
     pad = conv.padding[0]
+    _sink_use(conv.weight, bn.weight, bn.bias)
     return _ConvBNAct.apply(x, x2, residual, conv.weight, bn.weight, bn.bias, bn, conv.stride[0], pad,
                             conv.padding_mode == "reflect" and pad > 0, relu, None, not bn.training and not torch.is_grad_enabled())
 
@@ -272,6 +311,7 @@ def stem_conv_bn_act(x, conv, bn):
     with torch.cuda.device(x.device):
         _check(lib().vqseg_im2col_f(int(dt == torch.bfloat16), xr.data_ptr(), n, h, w, cin, kh, kw, s, p, int(reflect), ho, wo, kp,
                                     patches.data_ptr(), _stream()), "vqseg_im2col_f")
+    _sink_use(conv.weight, bn.weight, bn.bias)
     return _ConvBNAct.apply(_nchw(patches), None, None, conv.weight, bn.weight, bn.bias, bn, 1, 0, False, True,
                             (kh, kw, cin, s, p, reflect, h, w), not bn.training and not torch.is_grad_enabled())
 

@@ -61,13 +61,18 @@ class GradBuckets:
         self._pending = list(self._sizes)
         self._launched = [False] * len(groups)
         self._handles = []
-        if self.world > 1:
-            for p in self.params:
+        for p in self.params:
+            # the HIP weight-gradient kernels add straight into the bucket views (nnf grad sinks) and report here;
+            # parameters whose gradient still comes from autograd (VQ-free torch ops) report through the hook
+            p._vq_grad_sink = self._on_grad if self.world > 1 else None
+            if self.world > 1:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
     def zero(self):
         for b in self.buckets:
             b.zero_()
+        for p in self.params:
+            p._vq_uses = 0
         self._pending = list(self._sizes)
         self._launched = [False] * len(self.buckets)
         self._handles = []
