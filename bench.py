@@ -50,7 +50,9 @@ def cpu_baseline():
     (oracle/cps_ref.py runs exactly that sequence; the loss block and the Adam steps are < 2 % and left out)."""
     from oracle import torch_ref as R
     from tests import golden_io, synth
-    cores = os.cpu_count() or 1
+    # threads: the CPUs this process may run on, capped at the GPU box's per-GPU CPU share (16) -- asking for all 256
+    # hardware threads of the host over-subscribes that share and is ~10x slower
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
     sd = synth.synth_state_dict(golden_io.layout("vqreptunet1x1"), 77)
     ks = (0, 0, K_CODES, K_CODES, K_CODES)
@@ -76,6 +78,26 @@ def cpu_baseline():
             "sample": f"oracle/torch_ref.py on one {CS}x{CS} crop, fp32, {cores} threads: eval forward {t_eval:.2f}s, train "
                       f"forward+backward {t_train:.2f}s (single cold run each); scaled x{area:.0f} to 512x512 and composed "
                       f"as a CPS iteration on 1 labelled + 1 unlabelled image = 2*eval + 4*train = {dt:.1f}s per 2 images"}
+
+
+def pmc_traffic(per_shape):
+    """HBM bytes per launch of the distance+argmin kernel (launch-weighted over this run's shapes) from the committed
+    rocprofv3 --pmc summary of this same command (profiles/*_vq_assign_pmc.json: FETCH_SIZE x 2 + WRITE_SIZE, corrected
+    as MI355X_MICROARCH.md prescribes).  PMC passes serialise kernels, so they cannot run inside the timed bench."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_vq_assign_pmc.json")))
+    if not files:
+        return None, None
+    shapes = json.load(open(files[-1]))["shapes"]
+    total, launches = 0.0, 0
+    for name, (n_launch, _ms, _fl) in per_shape.items():
+        rows = name.split("x")[0]                                      # "N131072"
+        cands = [(int(k.split("_T")[1]), v) for k, v in shapes.items() if k.split("_T")[0] == rows]
+        if not cands:
+            return None, None
+        total += max(cands)[1]["hbm_bytes"] * n_launch               # the forward's plan is the widest tile count
+        launches += n_launch
+    return (round(total / launches) if launches else None), os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
@@ -150,6 +172,7 @@ def main():
             e[0] += 1
             e[1] += m
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(per_shape)
         images = 2 * args.batch * world * args.steps
         line = {
             "metric": "train images/sec @512x512 vqreptunet1x1 K=512",
@@ -166,7 +189,7 @@ def main():
                        "final_loss": round(loss, 5)},
             "roofline": {"kernel": "vq_assign_f32_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "launches": len(recs), "avg_launch_us": round(ms / max(len(recs), 1) * 1e3, 2),
                          "per_shape": {s: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2),
                                            "tflops": round(v[2] / (v[1] / v[0] * 1e-3) / 1e12, 2)}

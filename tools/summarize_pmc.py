@@ -1,0 +1,37 @@
+"""Summarise the rocprofv3 --pmc passes of tools/pmc_vq.sh (gpurun_out/pmc_r1/*.csv) for vq_assign_f32_kernel into
+profiles/<round>_vq_assign_pmc.{json,md}.  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
+FETCH_SIZE is in KiB and reports HALF of the bytes of wide coalesced reads on gfx950 -> x 1024 x 2; WRITE_SIZE is
+in KiB and exact -> x 1024.  GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy fraction =
+SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs).
+usage: python tools/summarize_pmc.py gpurun_out/pmc_r1 profiles/r01"""
+import csv, json, os, sys
+from collections import defaultdict
+
+src, dst = sys.argv[1], sys.argv[2]
+K = 512                                                      # bench.py's codebook size
+acc = defaultdict(lambda: defaultdict(list))
+for name in ("fetch", "write", "mfma"):
+    for r in csv.DictReader(open(os.path.join(src, name + ".csv"))):
+        t = int(r["Kernel_Name"].split("<")[1].split(">")[0])
+        wgs = int(r["Grid_Size"]) // 256
+        n_rows = wgs * 128 // (K // (32 * t))
+        key = f"N{n_rows}_T{t}"
+        acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[key]["ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+out = {}
+for key, c in sorted(acc.items()):
+    avg = {k: sum(v) / len(v) for k, v in c.items()}
+    e = {"launches_sampled": len(c["FETCH_SIZE"]), "fetch_bytes": avg["FETCH_SIZE"] * 1024 * 2, "write_bytes": avg["WRITE_SIZE"] * 1024,
+         "mfma_busy_frac": avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (avg["GRBM_GUI_ACTIVE"] / 8 * 1024),
+         "cycles_per_xcd": avg["GRBM_GUI_ACTIVE"] / 8}
+    e["hbm_bytes"] = e["fetch_bytes"] + e["write_bytes"]
+    out[key] = e
+json.dump({"kernel": "vq_assign_f32_kernel", "source": "rocprofv3 --pmc passes over `python bench.py --steps 2 --warmup 1` (tools/pmc_vq.sh)",
+           "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950 half-count), WRITE_SIZE KiB x1024, GRBM_GUI_ACTIVE / 8 XCDs", "shapes": out},
+          open(dst + "_vq_assign_pmc.json", "w"), indent=1)
+with open(dst + "_vq_assign_pmc.md", "w") as f:
+    f.write("# vq_assign_f32_kernel: PMC summary (per launch, averages)\n\n")
+    f.write("| shape (rows, tiles/wave) | launches | HBM fetch MB (x2 corrected) | HBM write MB | MFMA busy | cycles / XCD |\n|---|---|---|---|---|---|\n")
+    for k, e in out.items():
+        f.write(f"| {k} | {e['launches_sampled']} | {e['fetch_bytes'] / 1e6:.1f} | {e['write_bytes'] / 1e6:.2f} | {e['mfma_busy_frac'] * 100:.1f} % | {e['cycles_per_xcd']:.0f} |\n")
+print(open(dst + "_vq_assign_pmc.md").read())

@@ -16,7 +16,8 @@ struct VqPlan {
 };
 struct KmPlan {
     VqPlan vq;
-    size_t off_idx, off_counts, off_offsets, off_members, off_sums, off_counts64, bytes;
+    size_t off_idx, off_counts, off_offsets, off_members, off_sums, off_counts64, off_hist, off_segoff, off_partial, bytes;
+    int row_blocks, max_segments;
 };
 
 struct ProfShape {

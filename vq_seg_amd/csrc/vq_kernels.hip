@@ -410,68 +410,138 @@ __global__ __launch_bounds__(256) void vq_backward_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------
-// k-means: per-cluster member lists in row order, sequential sums (== CPU scatter_add_ order)
+// k-means update step: per-cluster sums of the member rows, deterministic and insensitive to skewed cluster sizes.
+//   1. km_hist:    row blocks of KM_RB rows -> hist[block][k] (LDS histogram, no global atomics)
+//   2. km_scan:    counts[k], member-list offsets[k], per-(block, k) write cursors, and segment offsets
+//                  (a cluster's member list is cut into segments of KM_SEG members)
+//   3. km_lists:   one wave per row block walks its rows in order and appends them to the member lists (stable:
+//                  lists are in row order)
+//   4. km_segsum:  block = (segment, 64-channel group): 4 waves stride the segment's members, combine in wave order
+//   5. km_sums:    per cluster, its segment partials are added in segment order
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void km_count_kernel(const long long* __restrict__ idx, long N, int* __restrict__ counts) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) atomicAdd(counts + idx[i], 1);
+constexpr int KM_RB = 1024;    // rows per block of the histogram / list passes
+constexpr int KM_SEG = 128;    // members per segment of the sum pass
+
+__global__ __launch_bounds__(256) void km_hist_kernel(const long long* __restrict__ idx, long N, int K, int* __restrict__ hist) {
+    extern __shared__ int lh[];
+    for (int k = threadIdx.x; k < K; k += 256) lh[k] = 0;
+    __syncthreads();
+    const long r0 = (long)blockIdx.x * KM_RB;
+    for (int i = threadIdx.x; i < KM_RB; i += 256)
+        if (r0 + i < N) atomicAdd(&lh[idx[r0 + i]], 1);
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) hist[(long)blockIdx.x * K + k] = lh[k];
 }
 
-__global__ __launch_bounds__(1024) void km_scan_kernel(const int* __restrict__ counts, int K, int* __restrict__ offsets) {
-    // single block exclusive scan, K <= 1024 * items
-    __shared__ int part[1024];
+// single block: counts, exclusive scans (member offsets, segment offsets), per-block cursors (in place of hist)
+__global__ __launch_bounds__(1024) void km_scan_kernel(int* __restrict__ hist, int n_blocks, int K, int* __restrict__ counts,
+                                                       int* __restrict__ offsets, int* __restrict__ segoff) {
+    __shared__ int part[1024], spart[1024];
     const int per = (K + 1023) / 1024;
     const int b = threadIdx.x * per;
-    int s = 0;
+    int s = 0, ss = 0;
     for (int i = 0; i < per; ++i)
-        if (b + i < K) s += counts[b + i];
+        if (b + i < K) {
+            int c = 0;
+            for (int j = 0; j < n_blocks; ++j) c += hist[(long)j * K + b + i];
+            counts[b + i] = c;
+            s += c;
+            ss += (c + KM_SEG - 1) / KM_SEG;
+        }
     part[threadIdx.x] = s;
+    spart[threadIdx.x] = ss;
     __syncthreads();
     for (int m = 1; m < 1024; m <<= 1) {
         const int v = (threadIdx.x >= m) ? part[threadIdx.x - m] : 0;
+        const int w = (threadIdx.x >= m) ? spart[threadIdx.x - m] : 0;
         __syncthreads();
         part[threadIdx.x] += v;
+        spart[threadIdx.x] += w;
         __syncthreads();
     }
-    int run = part[threadIdx.x] - s;
+    int run = part[threadIdx.x] - s, srun = spart[threadIdx.x] - ss;
     for (int i = 0; i < per; ++i)
         if (b + i < K) {
+            const int c = counts[b + i];
             offsets[b + i] = run;
-            run += counts[b + i];
+            segoff[b + i] = srun;
+            int cur = run;                                  // cursor of each row block inside this cluster's list
+            for (int j = 0; j < n_blocks; ++j) {
+                const int h = hist[(long)j * K + b + i];
+                hist[(long)j * K + b + i] = cur;
+                cur += h;
+            }
+            run += c;
+            srun += (c + KM_SEG - 1) / KM_SEG;
         }
-    if (threadIdx.x == 1023) offsets[K] = part[1023];
-}
-
-__global__ __launch_bounds__(64) void km_lists_kernel(const long long* __restrict__ idx, long N,
-                                                      const int* __restrict__ offsets, int* __restrict__ members) {
-    // one wave per cluster: stable (row-ordered) member list
-    const int k = blockIdx.x;
-    const int lane = threadIdx.x;
-    int pos = offsets[k];
-    for (long base = 0; base < N; base += 64) {
-        const long i = base + lane;
-        const bool hit = (i < N) && (idx[i] == k);
-        const unsigned long long m = __ballot(hit);
-        if (hit) members[pos + __popcll(m & ((1ull << lane) - 1ull))] = (int)i;
-        pos += __popcll(m);
+    if (threadIdx.x == 1023) {
+        offsets[K] = part[1023];
+        segoff[K] = spart[1023];
     }
 }
 
-__global__ __launch_bounds__(256) void km_sums_kernel(const float* __restrict__ samples, int C,
-                                                      const int* __restrict__ offsets, const int* __restrict__ members,
-                                                      float* __restrict__ sums) {
-    // block = (cluster k, 64-channel group); 4 waves stride the member list (wave w takes members w, w+4, ...);
-    // each lane owns one channel; the 4 partial sums are combined in wave order: deterministic.
-    const int k = blockIdx.x;
+__global__ __launch_bounds__(64) void km_lists_kernel(const long long* __restrict__ idx, long N, int K,
+                                                      const int* __restrict__ cursors, int* __restrict__ members) {
+    // one wave per row block; rows in order, 64 at a time; equal clusters inside a chunk are ranked by lane
+    extern __shared__ int cur[];
+    const int lane = threadIdx.x;
+    for (int k = lane; k < K; k += 64) cur[k] = cursors[(long)blockIdx.x * K + k];
+    __syncthreads();
+    const long r0 = (long)blockIdx.x * KM_RB;
+    for (int base = 0; base < KM_RB && r0 + base < N; base += 64) {
+        const long i = r0 + base + lane;
+        const bool valid = i < N;
+        const int k = valid ? (int)idx[i] : -1;
+        bool todo = valid;
+        while (__ballot(todo)) {
+            const int lead = __ffsll((long long)__ballot(todo)) - 1;
+            const int kk = __shfl(k, lead);
+            const unsigned long long same = __ballot(todo && k == kk);
+            if (todo && k == kk) {
+                members[cur[kk] + __popcll(same & ((1ull << lane) - 1ull))] = (int)i;
+                todo = false;
+            }
+            __syncthreads();                                // (one wave) order the cursor update after the reads
+            if (lane == lead) cur[kk] += __popcll(same);
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void km_segsum_kernel(const float* __restrict__ samples, int C, int K,
+                                                        const int* __restrict__ offsets, const int* __restrict__ segoff,
+                                                        const int* __restrict__ members, float* __restrict__ partial) {
+    const int seg = blockIdx.x;
+    if (seg >= segoff[K]) return;
+    int lo = 0, hi = K;                                     // cluster of this segment: last k with segoff[k] <= seg
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (segoff[mid] <= seg) lo = mid;
+        else hi = mid;
+    }
+    const int k = lo;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + lane;
-    const int b = offsets[k], e = offsets[k + 1];
+    const int b = offsets[k] + (seg - segoff[k]) * KM_SEG;
+    int e = b + KM_SEG;
+    if (e > offsets[k + 1]) e = offsets[k + 1];
     float s = 0.0f;
     if (c < C)
         for (int m = b + wave; m < e; m += 4) s += samples[(size_t)members[m] * C + c];
     __shared__ float sh[4][64];
     sh[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && c < C) sums[(size_t)k * C + c] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+    if (wave == 0 && c < C) partial[(size_t)seg * C + c] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+}
+
+__global__ __launch_bounds__(256) void km_sums_kernel(const float* __restrict__ partial, int C, const int* __restrict__ segoff,
+                                                      float* __restrict__ sums) {
+    const int k = blockIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.0f;
+    for (int g = segoff[k]; g < segoff[k + 1]; ++g) s += partial[(size_t)g * C + c];
+    sums[(size_t)k * C + c] = s;
 }
 
 __global__ __launch_bounds__(256) void km_counts64_kernel(const int* __restrict__ counts, int K, long long* __restrict__ out) {
@@ -659,6 +729,14 @@ KmPlan km_plan(int64_t N, int C, int K) {
     off += (size_t)K * C * sizeof(float);
     p.off_counts64 = off;
     off += (size_t)round_up(K, 32) * sizeof(int64_t);
+    p.row_blocks = (int)((N + KM_RB - 1) / KM_RB);
+    p.max_segments = (int)(N / KM_SEG + K);
+    p.off_hist = off;
+    off += (size_t)round_up(p.row_blocks * K, 64) * sizeof(int);
+    p.off_segoff = off;
+    off += (size_t)round_up(K + 1, 64) * sizeof(int);
+    p.off_partial = off;
+    off += (size_t)p.max_segments * C * sizeof(float);
     p.bytes = (off + 255) & ~(size_t)255;
     return p;
 }
@@ -673,17 +751,16 @@ hipError_t launch_km_accumulate(const float* samples, const float* means, int64_
     int* counts = reinterpret_cast<int*>(ws + p.off_counts);
     int* offsets = reinterpret_cast<int*>(ws + p.off_offsets);
     int* members = reinterpret_cast<int*>(ws + p.off_members);
-    e = hipMemsetAsync(counts, 0, (size_t)(K + 1) * sizeof(int), st);
-    if (e != hipSuccess) return e;
-    long cb = (N + 255) / 256;
-    if (cb > 2048) cb = 2048;
-    if (cb < 1) cb = 1;
-    hipLaunchKernelGGL(km_count_kernel, dim3((unsigned)cb), dim3(256), 0, st, reinterpret_cast<const long long*>(idx),
-                       (long)N, counts);
-    hipLaunchKernelGGL(km_scan_kernel, dim3(1), dim3(1024), 0, st, counts, K, offsets);
-    hipLaunchKernelGGL(km_lists_kernel, dim3(K), dim3(64), 0, st, reinterpret_cast<const long long*>(idx), (long)N,
-                       offsets, members);
-    hipLaunchKernelGGL(km_sums_kernel, dim3(K, (C + 63) / 64), dim3(256), 0, st, samples, C, offsets, members, sums);
+    int* hist = reinterpret_cast<int*>(ws + p.off_hist);
+    int* segoff = reinterpret_cast<int*>(ws + p.off_segoff);
+    float* partial = reinterpret_cast<float*>(ws + p.off_partial);
+    const long long* idx64 = reinterpret_cast<const long long*>(idx);
+    hipLaunchKernelGGL(km_hist_kernel, dim3(p.row_blocks), dim3(256), (size_t)K * sizeof(int), st, idx64, (long)N, K, hist);
+    hipLaunchKernelGGL(km_scan_kernel, dim3(1), dim3(1024), 0, st, hist, p.row_blocks, K, counts, offsets, segoff);
+    hipLaunchKernelGGL(km_lists_kernel, dim3(p.row_blocks), dim3(64), (size_t)K * sizeof(int), st, idx64, (long)N, K, hist, members);
+    hipLaunchKernelGGL(km_segsum_kernel, dim3(p.max_segments, (C + 63) / 64), dim3(256), 0, st, samples, C, K, offsets, segoff, members,
+                       partial);
+    hipLaunchKernelGGL(km_sums_kernel, dim3(K, (C + 255) / 256), dim3(256), 0, st, partial, C, segoff, sums);
     hipLaunchKernelGGL(km_counts64_kernel, dim3((K + 255) / 256), dim3(256), 0, st, counts, K,
                        reinterpret_cast<long long*>(counts64));
     return hipGetLastError();
