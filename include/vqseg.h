@@ -104,8 +104,11 @@ int vqseg_vq_backward_f32(const float* grad_quant, const float* grad_loss, const
  * k-means codebook initialisation, Lloyd iterations GIVEN the initial means.
  * Replaces kmeans() (vq_img.py:29-63, euclidean branch) after its RNG draw (:10-17,
  * done by the host with torch.randperm):  per iteration  assign (argmax of -cdist ==
- * argmin of cdist) -> per-cluster counts -> per-cluster sums in ROW ORDER (the order
- * scatter_add_ uses on the CPU) -> divide -> clusters with no member keep their mean.
+ * argmin of cdist) -> per-cluster counts -> per-cluster sums -> divide -> clusters with no
+ * member keep their mean.  The sums are deterministic but not in scatter_add_'s single running order:
+ * member lists are in row order, cut into segments of 128 members, four interleaved partial sums per
+ * segment, segments added in order (fp32; agreement with the CPU order is at rounding level, asserted
+ * at 1e-5 in tests/test_vq_gpu.py).
  *
  *   samples [N, C] f32, means [K, C] f32 in/out, bins [K] i64 out (last iteration).
  *
