@@ -42,6 +42,19 @@ __device__ __forceinline__ unsigned int pack2(float a, float b) {
 }
 __device__ __forceinline__ float bf16_round(float a) { return (float)((__bf16)a); }
 
+// pixel row m -> (image n, offset inside the image): 32-bit division whenever the row count allows (a 64-bit
+// division is ~100 emulated instructions, which matters in layers whose whole K loop is one or two stages)
+__device__ __forceinline__ void split_row(long m, int hw, long M, int& n, int& rem) {
+    if (M <= 0x7fffffffL) {
+        const unsigned int um = (unsigned int)m;
+        n = (int)(um / (unsigned int)hw);
+        rem = (int)(um - (unsigned int)n * (unsigned int)hw);
+    } else {
+        n = (int)(m / hw);
+        rem = (int)(m - (long)n * hw);
+    }
+}
+
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     if (i < 0) i = -i;
     if (i >= n) i = 2 * n - 2 - i;
@@ -229,8 +242,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         long m = m0 + a_row0 + A_RPP * i;
         a_ok[i] = m < M;
         if (!a_ok[i]) m = M - 1;
-        const int n = (int)(m / ((long)p.Ho * p.Wo));
-        const int rem = (int)(m - (long)n * p.Ho * p.Wo);
+        int n, rem;
+        split_row(m, p.Ho * p.Wo, M, n, rem);
         a_n[i] = n;
         a_oh[i] = rem / p.Wo;
         a_ow[i] = rem - a_oh[i] * p.Wo;
@@ -424,8 +437,8 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int TBM, int BN, int NW, int NBUF>
-__global__ __launch_bounds__(NW * 64) void conv_igemm_glds_kernel(const ConvArgs p) {
+template <int TBM, int BN, int NW, int NBUF, int MINW = 1>
+__global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const ConvArgs p) {
     constexpr int BK = 64;
     // wave grid WM x WN over the TBM x BN tile; wave tile (MT*32) x (NT*32)
     constexpr int WN = (BN >= 256) ? 4 : (BN >= 64 ? 2 : 1);
@@ -459,8 +472,8 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_glds_kernel(const ConvArgs
         long m = m0 + trow;
         a_ok[i] = m < M;
         if (!a_ok[i]) m = M - 1;
-        const int n = (int)(m / ((long)p.Ho * p.Wo));
-        const int rem = (int)(m - (long)n * p.Ho * p.Wo);
+        int n, rem;
+        split_row(m, p.Ho * p.Wo, M, n, rem);
         a_n[i] = n;
         a_oh[i] = rem / p.Wo;
         a_ow[i] = rem - a_oh[i] * p.Wo;
@@ -590,14 +603,17 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_glds_kernel(const ConvArgs
     conv_epilogue<TBM, BN, false, MT, NTT, NT, NW * 64>(acc, p, smem, M, m0, co0, wm, wn, r, h, tid);
 }
 
-template <int TBM, int BN, int NW, int NBUF>
+template <int TBM, int BN, int NW, int NBUF, int MINW = 1>
 static void launch_glds_t(const ConvArgs& a, hipStream_t st) {
-    size_t lds = (size_t)(TBM + BN) * 64 * 2 * NBUF;                       // the ring slots
+    const int n_stage = a.KH * a.KW * (a.Cin / 64);
+    // ring slots actually used: a short K loop (1x1 layers with 64..128 input channels) then leaves LDS for more
+    // resident workgroups, whose loads overlap each other's epilogues
+    size_t lds = (size_t)(TBM + BN) * 64 * 2 * (n_stage < NBUF ? n_stage : NBUF);
     const size_t out_tile = (size_t)TBM * (BN + 8) * 2;
     if (out_tile > lds) lds = out_tile;
     const long M = (long)a.N * a.Ho * a.Wo;
     dim3 grid((unsigned)((M + TBM - 1) / TBM), (unsigned)((a.Cout + BN - 1) / BN));
-    hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF>), grid, dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW>), grid, dim3(NW * 64), lds, st, a);
 }
 
 // =====================================================================================================
@@ -643,7 +659,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     const int tw_shift = (p.W & 31) == 0 ? 5 : 4;
     const int TW = 1 << tw_shift, TH = TBM >> tw_shift, PW = TW + 2, PH = TH + 2;
     const int tiles_x = p.W >> tw_shift, tiles_y = p.H / TH;
-    int t = blockIdx.x;
+    const int tile_id = blockIdx.x;
+    int t = tile_id;
     const int txi = t % tiles_x;
     t /= tiles_x;
     const int tyi = t % tiles_y;
@@ -785,17 +802,23 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     __syncthreads();                                       // all MFMAs done: LDS is free for the output tile
     const long M = (long)p.N * p.H * p.W;
     const TileRows rows{((long)n * p.H + oh0) * p.W + ow0, tw_shift, p.W};
-    conv_epilogue<TBM, BN, false, MT, NT, NT, NW * 64, TileRows>(acc, p, smem, M, (long)blockIdx.x * TBM, co0, wm, wn, r, h, tid, rows);
+    conv_epilogue<TBM, BN, false, MT, NT, NT, NW * 64, TileRows>(acc, p, smem, M, (long)tile_id * TBM, co0, wm, wn, r, h, tid, rows);
 }
 
 static int g_patch_min_wgs = 256;
 static int g_patch_wide = 1;                                // 0: never take the 256-channel tile (a/b measurements)
+static int g_short_k_small = 2;                             // K loops of up to this many stages take the 128x128 tile at 4 waves/SIMD
 static int g_patch_unroll = 1;                              // 128-channel tile: tap loop unrolled
 
 int conv_set_option(const char* key, int value) {
     if (key && !strcmp(key, "conv3x3_patch_min_workgroups")) {
         const int prev = g_patch_min_wgs;
         g_patch_min_wgs = value;
+        return prev;
+    }
+    if (key && !strcmp(key, "conv_short_k_small_tile")) {
+        const int prev = g_short_k_small;
+        g_short_k_small = value;
         return prev;
     }
     if (key && !strcmp(key, "conv3x3_patch_unroll")) {
@@ -896,7 +919,9 @@ hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
         const long M = (long)a.N * a.Ho * a.Wo;
         const long t256 = ((M + 255) / 256) * ((a.Cout + 255) / 256), t256x128 = ((M + 255) / 256) * ((a.Cout + 127) / 128);
         (void)t256;
-        if (a.Cout % 128 == 0 && t256x128 >= 512) launch_glds_t<256, 128, 8, 3>(a, st);
+        const int n_stage = a.KH * a.KW * (a.Cin / 64);
+        if (n_stage <= g_short_k_small && bn == 128) launch_glds_t<128, 128, 4, 2, 4>(a, st);   // epilogue-bound: more, independent workgroups per CU
+        else if (a.Cout % 128 == 0 && t256x128 >= 512) launch_glds_t<256, 128, 8, 3>(a, st);
         else if (bn == 128) launch_glds_t<128, 128, 4, 2>(a, st);
         else if (bn == 64) launch_glds_t<128, 64, 4, 3>(a, st);
         else launch_glds_t<128, 32, 4, 3>(a, st);
