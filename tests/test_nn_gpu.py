@@ -280,6 +280,37 @@ def test_wgrad3x3_fused_taps(case):
     assert rel(gw, 2 * ref) < 2e-5
 
 
+WGRAD1_CASES = [
+    # n, cin, cout, h, w, stride   (every tile config of the 1x1 weight-gradient kernel; ragged pixel counts; stride 2)
+    (2, 128, 256, 16, 16, 1), (3, 64, 256, 9, 7, 1), (2, 128, 128, 8, 24, 1), (1, 64, 128, 20, 20, 1), (2, 256, 64, 12, 12, 1),
+    (2, 256, 512, 16, 16, 2), (1, 128, 256, 15, 9, 2), (4, 1024, 256, 8, 8, 1),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD1_CASES)
+def test_wgrad1x1(case):
+    """bf16 1x1 weight-gradient kernel through the C ABI against fp64 on the same bf16 values (2e-5 of scale)."""
+    from vq_seg_amd import _hip
+    n, cin, cout, h, w, stride = case
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    L = _hip.lib()
+    seed = sum(case) + 5
+    x = synth.uniform(seed, (n, h, w, cin), -1, 1).bfloat16()
+    gy = synth.uniform(seed + 1, (n, ho, wo, cout), -1, 1).bfloat16()
+    xs = x[:, ::stride, ::stride, :].double().reshape(-1, cin)
+    ref = (gy.double().reshape(-1, cout).t() @ xs).reshape(cout, cin, 1, 1)
+    xd, gyd = x.to(dev()), gy.to(dev())
+    nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, 1, 1)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    gw = torch.full((cout, cin, 1, 1), float("nan"), dtype=torch.float32, device=dev())
+    for acc in (0, 1):
+        rc = L.vqseg_conv2d_wgrad_f(gyd.data_ptr(), xd.data_ptr(), None, cin, n, h, w, cin, ho, wo, cout, 1, 1, stride, 0, 0, 0, cin, 0,
+                                    acc, ws.data_ptr(), nbytes, gw.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, L.vqseg_last_error()
+        torch.cuda.synchronize()
+        assert rel(gw, (1 + acc) * ref) < 2e-5
+
+
 @pytest.mark.parametrize("mode", ["precise", "fast"])
 @pytest.mark.parametrize("reflect", [True, False])
 def test_stem(reflect, mode):

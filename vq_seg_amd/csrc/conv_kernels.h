@@ -29,6 +29,7 @@ struct WgradArgs {
     int C1;
     float* partial;             // [slabs][Cout][KH*KW][Cin] fp32
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, reflect;
+    int per_tap_only;           // 1: x is an im2col patch matrix whose padded columns are dropped by the reduction
 };
 
 hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st);

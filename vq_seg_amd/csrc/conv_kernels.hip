@@ -1432,13 +1432,222 @@ __global__ __launch_bounds__((Wg3<COT, CIT>::NW * 64)) void conv_wgrad3x3_kernel
     }
 }
 
+// =====================================================================================================
+// Weight gradient of 1x1 layers (bf16; stride 1 or 2, no padding): dW[co][ci] = sum_m GY[m][co] * X[m'][ci].
+// Same machinery as the nine-tap kernel without the halo: 64 pixel rows per stage, GY tile [64][32*COT] and X tile
+// [64][32*CIT] by LDS-DMA into a 3-deep ring (counted vmcnt), swizzled transposing fragment reads, 8 waves each owning
+// PM x PN accumulator tiles.  The weight is small, the pixel count large: most workgroups are pixel slabs, so each
+// operand row is fetched once or twice in total -- these layers are HBM-bound.  Partials [z][Cout][Cin] are already
+// in nn.Conv2d's layout (fixed-order slab sum afterwards).
+// =====================================================================================================
+template <int COT, int CIT>
+struct Wg1 {
+    static constexpr int NW = 8;
+    static constexpr int WO = COT < 4 ? COT : 4, PM = COT / WO;   // wave groups over co, co tiles per wave
+    static constexpr int WC = NW / WO, PN = CIT / WC;             // wave groups over ci, ci tiles per wave
+    static constexpr int RBG = COT * 64, RBA = CIT * 64;         // row bytes
+    static constexpr int G_BYTES = 64 * RBG, A_BYTES = 64 * RBA;
+    static constexpr int G_PER = G_BYTES / 1024 / NW, A_PER = (A_BYTES / 1024 + NW - 1) / NW;
+    static constexpr int STAGE = G_BYTES + A_PER * NW * 1024;
+    static constexpr int NBUF = 3;
+    static_assert(WO * WC == NW && PN >= 1 && PM >= 1 && (G_BYTES / 1024) % NW == 0, "unsupported tile");
+    static_assert(RBG <= 256 || RBG == 512, "GY rows: 64..256 B swizzle classes, or 512 B");
+};
+
+// chunk swizzle for 512-byte rows (32 chunks): as for 256-byte rows, rows q = 0..3 of a fragment read land in
+// different 64-byte bank groups
+template <int RB>
+__device__ __forceinline__ int swz_chunk_w(int row) {
+    return RB >= 256 ? ((row & 3) << 2) : (RB == 128 ? (((row >> 1) & 1) << 2) : 0);
+}
+template <int RB>
+__device__ __forceinline__ bf16x8 tr_frag_w(const char* tile, int pix0, int col0, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int row = pix0 + 8 * (g >> 1) + q;
+    const int cbyte = 2 * col0 + 32 * (g & 1) + 8 * pp;
+    const char* a0 = tile + row * RB + (((cbyte >> 4) ^ swz_chunk_w<RB>(row)) << 4) + (cbyte & 8);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * RB));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int COT, int CIT>
+__global__ __launch_bounds__(512) void conv_wgrad1x1_kernel(const WgradArgs p, int stages_per_slab) {
+    using C = Wg1<COT, CIT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave % C::WO, wc = wave / C::WO;
+    const int ci0 = blockIdx.x * (32 * CIT), co0 = blockIdx.y * (32 * COT);
+    const long M = (long)p.N * p.Ho * p.Wo;
+    const long n_stage_all = (M + 63) / 64;
+    const long s_begin = (long)blockIdx.z * stages_per_slab;
+    long s_end = s_begin + stages_per_slab;
+    if (s_end > n_stage_all) s_end = n_stage_all;
+    const int ns = s_end > s_begin ? (int)(s_end - s_begin) : 0;
+    const char* gsrc = reinterpret_cast<const char*>(p.gy);
+    const char* xsrc = reinterpret_cast<const char*>(p.x);
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    // ---- lane roles of the DMA instructions: instruction j covers tile rows j * (1024 / RB) ...
+    int g_row[C::G_PER], g_col[C::G_PER];
+#pragma unroll
+    for (int i = 0; i < C::G_PER; ++i) {
+        const int j = wave + C::NW * i;
+        g_row[i] = j * (1024 / C::RBG) + (lane * 16) / C::RBG;
+        const int slot = lane & (C::RBG / 16 - 1);
+        g_col[i] = co0 + ((slot ^ swz_chunk_w<C::RBG>(g_row[i])) << 3);
+    }
+    int a_row[C::A_PER], a_col[C::A_PER];
+    int a_n[C::A_PER], a_oh[C::A_PER], a_ow[C::A_PER];     // output pixel of the row in the stage being issued
+#pragma unroll
+    for (int i = 0; i < C::A_PER; ++i) {
+        const int j = wave + C::NW * i;
+        a_row[i] = j * (1024 / C::RBA) + (lane * 16) / C::RBA;   // rows >= 64: instruction beyond the tile (zero page)
+        const int slot = lane & (C::RBA / 16 - 1);
+        a_col[i] = ci0 + ((slot ^ swz_chunk_w<C::RBA>(a_row[i])) << 3);
+        long m = s_begin * 64 + a_row[i];
+        if (m >= M) m = M - 1;
+        int rem;
+        split_row(m, p.Ho * p.Wo, M, a_n[i], rem);
+        a_oh[i] = rem / p.Wo;
+        a_ow[i] = rem - a_oh[i] * p.Wo;
+    }
+
+    f32x16 acc[C::PM][C::PN];
+#pragma unroll
+    for (int a = 0; a < C::PM; ++a)
+#pragma unroll
+        for (int b = 0; b < C::PN; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+    long issue_m0 = s_begin * 64;                          // first pixel row of the stage being issued
+    auto stage = [&](int buf) {
+        char* Gs = smem + buf * C::STAGE;
+        char* As = Gs + C::G_BYTES;
+#pragma unroll
+        for (int i = 0; i < C::G_PER; ++i) {
+            const long m = issue_m0 + g_row[i];
+            glds16(m < M ? gsrc + (m * p.Cout + g_col[i]) * 2 : zero, Gs + (wave + C::NW * i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < C::A_PER; ++i) {
+            const long m = issue_m0 + a_row[i];
+            const bool ok = a_row[i] < 64 && m < M;
+            const long pix = ((long)a_n[i] * p.H + a_oh[i] * p.stride) * p.W + a_ow[i] * p.stride;
+            glds16(ok ? xsrc + (pix * p.Cin + a_col[i]) * 2 : zero, As + (wave + C::NW * i) * 1024);
+            a_ow[i] += 64;                                  // this lane's row of the next stage
+            while (a_ow[i] >= p.Wo) {
+                a_ow[i] -= p.Wo;
+                if (++a_oh[i] >= p.Ho) {
+                    a_oh[i] = 0;
+                    ++a_n[i];
+                }
+            }
+        }
+        issue_m0 += 64;
+    };
+    auto compute = [&](int buf) {
+        const char* Gs = smem + buf * C::STAGE;
+        const char* As = Gs + C::G_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 gf[C::PM], af[C::PN];
+#pragma unroll
+            for (int a = 0; a < C::PM; ++a) gf[a] = tr_frag_w<C::RBG>(Gs, kk * 16, (wo * C::PM + a) * 32, lane);
+#pragma unroll
+            for (int b = 0; b < C::PN; ++b) af[b] = tr_frag_w<C::RBA>(As, kk * 16, (wc * C::PN + b) * 32, lane);
+#pragma unroll
+            for (int a = 0; a < C::PM; ++a)
+#pragma unroll
+                for (int b = 0; b < C::PN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[a], af[b], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    constexpr int G = C::G_PER + C::A_PER;
+    auto wait_in_flight = [&](int stages) {
+        if (stages >= 1) __builtin_amdgcn_s_waitcnt((G & 0xF) | ((G >> 4) << 14) | 0x0F70);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+    };
+#pragma unroll
+    for (int i = 0; i < C::NBUF - 1; ++i)
+        if (i < ns) stage(i);
+    int slot_c = 0, slot_i = C::NBUF - 1;
+    for (int s = 0; s < ns; ++s) {
+        const int behind = ns - 1 - s;
+        wait_in_flight(behind < C::NBUF - 2 ? behind : C::NBUF - 2);
+        __builtin_amdgcn_s_barrier();
+        if (s + C::NBUF - 1 < ns) stage(slot_i);
+        compute(slot_c);
+        slot_c = slot_c == C::NBUF - 1 ? 0 : slot_c + 1;
+        slot_i = slot_i == C::NBUF - 1 ? 0 : slot_i + 1;
+    }
+
+    // ---- slab [z][Cout][Cin] fp32 (row = co on registers, column = ci on lanes: 128-byte runs)
+    const int r = lane & 31, h = lane >> 5;
+    float* slab = p.partial + (long)blockIdx.z * p.Cout * p.Cin;
+#pragma unroll
+    for (int a = 0; a < C::PM; ++a)
+#pragma unroll
+        for (int b = 0; b < C::PN; ++b) {
+            const int ci = ci0 + (wc * C::PN + b) * 32 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = co0 + (wo * C::PM + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                slab[(long)co * p.Cin + ci] = acc[a][b][i];
+            }
+        }
+}
+
+struct Wg1Plan {
+    int cot, cit, slabs, stages_per_slab;                  // cot == 0: not eligible
+};
+
+static Wg1Plan wgrad1x1_plan(const WgradArgs& a, int precise, bool shape_only) {
+    Wg1Plan pl{0, 0, 0, 0};
+    if (precise || a.per_tap_only || a.KH != 1 || a.KW != 1 || (!shape_only && a.C1 != a.Cin)) return pl;
+    if (!shape_only && (a.pad != 0 || (a.stride != 1 && a.stride != 2))) return pl;
+    int cot, cit;
+    if (a.Cout % 256 == 0 && a.Cin % 128 == 0) cot = 8, cit = 4;
+    else if (a.Cout % 256 == 0 && a.Cin % 64 == 0) cot = 8, cit = 2;
+    else if (a.Cout % 128 == 0 && a.Cin % 128 == 0) cot = 4, cit = 4;
+    else if (a.Cout % 128 == 0 && a.Cin % 64 == 0) cot = 4, cit = 2;
+    else if (a.Cout % 64 == 0 && a.Cin % 128 == 0) cot = 2, cit = 4;
+    else return pl;
+    const long tiles = (long)(a.Cin / (32 * cit)) * (a.Cout / (32 * cot));
+    const long n_stage = ((long)a.N * a.Ho * a.Wo + 63) / 64;
+    if (n_stage > (1L << 30)) return pl;
+    long s = (256 + tiles - 1) / tiles;                     // one resident round of 8-wave workgroups
+    const long max_s = (n_stage + 3) / 4;                   // at least 4 stages (256 pixels) per slab
+    if (s > max_s) s = max_s;
+    if (s > 256) s = 256;
+    if (s < 1) s = 1;
+    const long sps = (n_stage + s - 1) / s;
+    s = (n_stage + sps - 1) / sps;
+    pl.cot = cot;
+    pl.cit = cit;
+    pl.slabs = (int)s;
+    pl.stages_per_slab = (int)sps;
+    return pl;
+}
+
+template <int COT, int CIT>
+static void wgrad1x1_launch_t(const WgradArgs& a, const Wg1Plan& pl, hipStream_t st) {
+    using C = Wg1<COT, CIT>;
+    dim3 grid((unsigned)(a.Cin / (32 * CIT)), (unsigned)(a.Cout / (32 * COT)), (unsigned)pl.slabs);
+    hipLaunchKernelGGL((conv_wgrad1x1_kernel<COT, CIT>), grid, dim3(512), (size_t)C::NBUF * C::STAGE, st, a, pl.stages_per_slab);
+}
+
 struct Wg3Plan {
     int cot, cit, slabs, blocks_per_slab;                  // cot == 0: not eligible
 };
 
 static Wg3Plan wgrad3x3_plan(const WgradArgs& a, int precise, bool shape_only, int force_cit = 0) {
     Wg3Plan pl{0, 0, 0, 0};
-    if (precise || a.KH != 3 || a.KW != 3 || a.Ho != a.H || a.Wo != a.W || a.Ho % 4 || a.Wo % 16 || a.Cout % 32 || a.Cin % 32)
+    if (precise || a.per_tap_only || a.KH != 3 || a.KW != 3 || a.Ho != a.H || a.Wo != a.W || a.Ho % 4 || a.Wo % 16 || a.Cout % 32 || a.Cin % 32)
         return pl;
     if (!shape_only && (a.stride != 1 || a.pad != 1)) return pl;
     int cit = (a.Cin % 64 == 0 && force_cit != 1) ? 2 : 1;
@@ -1499,7 +1708,9 @@ static int wgrad_slabs_per_tap(const WgradArgs& a) {
 // slabs the launch will use (precise/stride/pad known) ...
 int wgrad_slabs(const WgradArgs& a, int precise) {
     const Wg3Plan pl = wgrad3x3_plan(a, precise, false);
-    return pl.cot ? pl.slabs : wgrad_slabs_per_tap(a);
+    if (pl.cot) return pl.slabs;
+    const Wg1Plan p1 = wgrad1x1_plan(a, precise, false);
+    return p1.cot ? p1.slabs : wgrad_slabs_per_tap(a);
 }
 
 // ... and an upper bound from the shape alone (workspace sizing)
@@ -1509,6 +1720,8 @@ int wgrad_slabs_max(const WgradArgs& a) {
         const Wg3Plan pl = wgrad3x3_plan(a, 0, true, cit);
         if (pl.cot && pl.slabs > m) m = pl.slabs;
     }
+    const Wg1Plan p1 = wgrad1x1_plan(a, 0, true);
+    if (p1.cot && p1.slabs > m) m = p1.slabs;
     return m;
 }
 
@@ -1520,6 +1733,15 @@ hipError_t launch_wgrad(const WgradArgs& a, int precise, int slabs, int* final_l
     if (pl.cot == COT_ && pl.cit == CIT_) wgrad3x3_launch_t<COT_, CIT_>(a, pl, st);
         WG3_CASE(4, 2) WG3_CASE(2, 2) WG3_CASE(1, 2) WG3_CASE(4, 1) WG3_CASE(2, 1) WG3_CASE(1, 1)
 #undef WG3_CASE
+        return hipGetLastError();
+    }
+    const Wg1Plan p1 = wgrad1x1_plan(a, precise, false);
+    if (p1.cot) {
+        *final_layout = 1;                                  // [Cout][Cin] == [Cout][Cin][1][1]
+#define WG1_CASE(COT_, CIT_) \
+    if (p1.cot == COT_ && p1.cit == CIT_) wgrad1x1_launch_t<COT_, CIT_>(a, p1, st);
+        WG1_CASE(8, 4) WG1_CASE(8, 2) WG1_CASE(4, 4) WG1_CASE(4, 2) WG1_CASE(2, 4)
+#undef WG1_CASE
         return hipGetLastError();
     }
     const int tm = a.Cout >= 128 ? 4 : (a.Cout >= 64 ? 2 : 1);

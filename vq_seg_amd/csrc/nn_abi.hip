@@ -108,7 +108,7 @@ int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, 
     const int kkh = im2col ? 1 : kh, kkw = im2col ? 1 : kw;     // a patch matrix is convolved 1x1
     a.gy = gy; a.x = x; a.x2 = x2; a.C1 = c1; a.partial = static_cast<float*>(workspace);
     a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Ho = ho; a.Wo = wo; a.Cout = cout; a.KH = kkh; a.KW = kkw;
-    a.stride = stride; a.pad = pad; a.reflect = reflect;
+    a.stride = stride; a.pad = pad; a.reflect = reflect; a.per_tap_only = im2col;
     const int slabs = vqseg::wgrad_slabs(a, precise);
     if (workspace_bytes < (size_t)slabs * cout * kkh * kkw * cin * sizeof(float)) return vqseg_set_error(VQSEG_ENOSPC, "conv2d_wgrad: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
