@@ -182,6 +182,7 @@ PATCH_CASES = [
     # n, c1, c2, cout, h, w, reflect
     (2, 64, 0, 128, 8, 32, False), (1, 128, 64, 256, 16, 64, True), (3, 64, 0, 128, 16, 16, True), (2, 192, 0, 128, 32, 48, False),
     (1, 64, 64, 384, 16, 32, False), (2, 128, 0, 256, 16, 32, False),
+    (2, 64, 0, 64, 8, 32, True), (1, 128, 64, 32, 16, 32, False), (2, 64, 0, 32, 16, 16, True), (2, 128, 0, 64, 32, 32, False),
 ]
 
 
@@ -216,10 +217,11 @@ def test_conv3x3_patch_kernel(case, force_patch_kernel):
     assert rel(y.float(), ref) < 2 ** -7
     # BatchNorm partials of the fp32 accumulators: merged mean / biased variance per channel
     m = n * h * w
-    n_slots = m // 64
+    rps = 64 if cout >= 64 else 32                         # rows per statistics slot (vqseg_conv_stat_slots)
+    n_slots = m // rps
     sp = stat[:n_slots].double().cpu()
     mean = sp[:, 0].mean(0)
-    var = (sp[:, 1] + 64 * (sp[:, 0] - mean) ** 2).sum(0) / m
+    var = (sp[:, 1] + rps * (sp[:, 0] - mean) ** 2).sum(0) / m
     flat = ref.reshape(m, cout)
     assert ((mean - flat.mean(0)).abs().max() / flat.abs().max()).item() < 1e-5
     assert ((var - flat.var(0, unbiased=False)).abs().max() / flat.var(0, unbiased=False).max()).item() < 1e-4

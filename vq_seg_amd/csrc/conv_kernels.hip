@@ -640,10 +640,12 @@ struct TileRows {                                           // tile row -> outpu
 template <int BN, int NBW, bool UNROLL_TAPS>
 __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     constexpr int TBM = 256, NW = 8;
-    constexpr int WN = BN / 64, WM = NW / WN;              // wave grid; wave tile (MT*32) px x 64 co
-    constexpr int MT = TBM / (WM * 32), NT = 2;
+    constexpr int NT = BN >= 128 ? 2 : 1;                  // 32-channel tiles per wave
+    constexpr int WN = BN / (32 * NT), WM = NW / WN;       // wave grid; wave tile (MT*32) px x (NT*32) co
+    constexpr int MT = TBM / (WM * 32);                    // BN 256/128/64/32 -> MT 4/2/2/1 (64/32-row BN stat slots)
     constexpr int PATCH_BYTES = 48 * 1024;                 // 6 DMA instructions (8 rows x 128 B) per wave
-    constexpr int W_BYTES = BN * 128;
+    constexpr int W_ROWS = BN >= 64 ? BN : 64;             // weight rows staged per tap (rows >= Cout: zero page)
+    constexpr int W_BYTES = W_ROWS * 128;
     constexpr int WI = W_BYTES / 1024 / NW;                // weight DMA instructions per wave and tap
     static_assert(W_BYTES % (1024 * NW) == 0, "weight tile must split evenly over the waves");
 
@@ -836,15 +838,18 @@ int conv_set_option(const char* key, int value) {
 
 static bool conv3x3_patch_ok(const ConvArgs& a) {
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.up != 1 || a.Ho != a.H || a.Wo != a.W) return false;
-    if (a.Cin % 64 || (a.C1 != a.Cin && a.C1 % 64) || a.Cout % 128) return false;
+    if (a.Cin % 64 || (a.C1 != a.Cin && a.C1 % 64) || (a.Cout % 128 && a.Cout != 64 && a.Cout != 32)) return false;
     const int tw = (a.W % 32 == 0) ? 32 : 16, th = 256 / tw;
     if (a.W % tw || a.H % th) return false;
-    return (long)a.N * (a.H / th) * (a.W / tw) * (a.Cout / 128) >= g_patch_min_wgs;   // at least one workgroup per CU
+    const int bn = a.Cout % 128 == 0 ? 128 : a.Cout;
+    return (long)a.N * (a.H / th) * (a.W / tw) * (a.Cout / bn) >= g_patch_min_wgs;   // at least one workgroup per CU
 }
 
 template <int BN, int NBW, bool UNROLL_TAPS>
 static void launch_patch_t(const ConvArgs& a, hipStream_t st) {
-    const size_t lds = 2 * 48 * 1024 + (size_t)NBW * BN * 128;
+    size_t lds = 2 * 48 * 1024 + (size_t)NBW * (BN >= 64 ? BN : 64) * 128;
+    const size_t out_tile = (size_t)256 * (BN + 8) * 2;
+    if (out_tile > lds) lds = out_tile;
     const int tw = (a.W % 32 == 0) ? 32 : 16, th = 256 / tw;
     dim3 grid((unsigned)((long)a.N * (a.H / th) * (a.W / tw)), (unsigned)(a.Cout / BN));
     hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS>), grid, dim3(512), lds, st, a);
@@ -907,7 +912,9 @@ hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
         const int tw = (a.W % 32 == 0) ? 32 : 16, th = 256 / tw;
         const long tiles = (long)a.N * (a.H / th) * (a.W / tw);
         // 256-wide channel tile (wave tile 128 px x 64 co: 25 % fewer LDS fragment reads per MFMA) when it still fills the chip
-        if (a.Cout % 256 == 0 && g_patch_wide && tiles * (a.Cout / 256) >= g_patch_min_wgs)
+        if (a.Cout == 64) launch_patch_t<64, 3, true>(a, st);
+        else if (a.Cout == 32) launch_patch_t<32, 3, true>(a, st);
+        else if (a.Cout % 256 == 0 && g_patch_wide && tiles * (a.Cout / 256) >= g_patch_min_wgs)
             launch_patch_t<256, 2, false>(a, st);
         else if (g_patch_unroll)
             launch_patch_t<128, 3, true>(a, st);
