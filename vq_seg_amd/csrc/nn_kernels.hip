@@ -740,14 +740,56 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const T* __restric
     }
 }
 
-// sum partial[blk][n] over blk in fixed order -> out[n] (double accumulate)
+// sum partial[blk][n] over blk -> out[n] (double accumulate, fixed order).  A block covers 64 x 4 consecutive
+// elements (float4 per thread); its 4 thread rows take the slabs b = row, row + 4, ... (two independent chains
+// each, so several loads are in flight) and are folded through LDS in row order.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, long n_blocks, long n,
                                                               float* __restrict__ out, int accumulate) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (long b = 0; b < n_blocks; ++b) s += (double)partial[b * n + i];
-    out[i] = accumulate ? out[i] + (float)s : (float)s;
+    __shared__ double sh[4][64][4];
+    const int col = threadIdx.x & 63, rowl = threadIdx.x >> 6;
+    const long i = ((long)blockIdx.x * 64 + col) * 4;
+    double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool vec = (n & 3) == 0 && i + 3 < n;      // 16-byte aligned slab rows
+    if (i < n) {
+        long b = rowl;
+        for (; b + 4 < n_blocks; b += 8) {
+            if (vec) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(partial + b * n + i);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (b + 4) * n + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s0[e] += (double)u[e];
+                    s1[e] += (double)v[e];
+                }
+            } else {
+                for (int e = 0; e < 4 && i + e < n; ++e) {
+                    s0[e] += (double)partial[b * n + i + e];
+                    s1[e] += (double)partial[(b + 4) * n + i + e];
+                }
+            }
+        }
+        if (b < n_blocks) {
+            if (vec) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(partial + b * n + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s0[e] += (double)u[e];
+            } else {
+                for (int e = 0; e < 4 && i + e < n; ++e) s0[e] += (double)partial[b * n + i + e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sh[rowl][col][e] = s0[e] + s1[e];
+    __syncthreads();
+    if (rowl == 0 && i < n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (i + e < n) {
+                const double t = ((sh[0][col][e] + sh[1][col][e]) + sh[2][col][e]) + sh[3][col][e];
+                out[i + e] = accumulate ? out[i + e] + (float)t : (float)t;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
