@@ -113,11 +113,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # VQSEG_DIST_REHEARSAL=1: every rank on cuda:0 with gloo -- a functional rehearsal of the N > 1 code path on a
+    # one-GPU box (gradient sinks, buckets, distributed k-means init); its timings mean nothing.
+    rehearsal = os.environ.get("VQSEG_DIST_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)          # "nccl" IS RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)      # "nccl" IS RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from vq_seg_amd import _hip
@@ -161,6 +169,13 @@ def main():
     elapsed = float(t.item())
     loss = float(out["loss"])
     note(f"{args.steps} timed steps done in {elapsed:.2f}s")
+    if world > 1 and rehearsal:
+        # data-parallel invariant: after the same averaged updates every rank holds bit-identical parameters
+        chk = torch.stack([p.detach().double().sum() for m in trainer.models for p in m.parameters()]).cpu()
+        gathered = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(gathered, chk)
+        assert all(torch.equal(g, gathered[0]) for g in gathered), "ranks diverged"
+        note(f"rank {rank}: parameter checksums identical on all {world} ranks")
 
     if rank == 0:
         recs = _hip.profile_collect(64 * args.steps)
