@@ -1,0 +1,37 @@
+"""CPSTrainer.step on the GPU: running the two networks of the pair on their own HIP streams must not change a single
+bit of the result (every kernel of the path is deterministic, so any difference would be a missing stream dependency),
+in both recipes and both activation precisions."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(two_streams, recipe, amp):
+    from vq_seg_amd.trainer import CPSConfig, CPSTrainer, SyntheticCropWeed
+    dev = torch.device("cuda:0")
+    name = "vqreptunet1x1" if recipe == "v1" else "vqreptunet1x1v2"
+    model = {"name": name, "params": {"encoder_name": "resnet50", "num_classes": 3, "depth": 5,
+                                      "vq_cfg": {"num_embeddings": [0, 0, 64, 64, 64], "distance": "euclidean", "kmeans_init": True},
+                                      "margin": 0.0, "scale": 1.0, "use_feature": False, "encoder_weights": None}}
+    torch.manual_seed(0)
+    cfg = CPSConfig(model=model, recipe=recipe, total_iters=10, amp_dtype=torch.bfloat16 if amp else None, two_streams=two_streams)
+    tr = CPSTrainer(cfg, dev)
+    assert tr._two_streams == two_streams
+    data = SyntheticCropWeed(64, 2, dev, seed=5)
+    (l_in, l_tg), ul_in = data.labelled(), data.unlabelled()
+    losses = []
+    for _ in range(3):
+        losses.append(tr.step(l_in, l_tg, ul_in)["loss"].item())
+    torch.cuda.synchronize()
+    chk = torch.stack([p.detach().double().sum() for m in tr.models for p in m.parameters()]).cpu()
+    return losses, chk
+
+
+@pytest.mark.parametrize("recipe,amp", [("v1", True), ("v2", False)])
+def test_two_streams_change_nothing(recipe, amp):
+    la, ca = _run(False, recipe, amp)
+    lb, cb = _run(True, recipe, amp)
+    assert all(l == l and abs(l) < 1e6 for l in la)           # finite
+    assert la == lb, (la, lb)
+    assert torch.equal(ca, cb)

@@ -150,6 +150,7 @@ class CPSConfig:
     bn_momentum: float = 0.1
     amp_dtype: Optional[torch.dtype] = None   # torch.bfloat16 = the ROCm-native counterpart of the reference's fp16 AMP
     bucket_mb: float = 64.0
+    two_streams: bool = True                  # each network of the pair on its own HIP stream (see CPSTrainer.__init__)
     seed: int = 42
     extra: dict = field(default_factory=dict)
 
@@ -191,6 +192,12 @@ class CPSTrainer:
                 for t in list(m.parameters()) + list(m.buffers()):
                     dist.broadcast(t.data, src=0)
         self.buckets = [GradBuckets(list(m.parameters()), cfg.bucket_mb) for m in self.models]
+        # the two networks of a CPS pair are independent until the loss: each runs on its own HIP stream so that one
+        # model's small, latency-bound kernels (statistics merges, reductions, packs) hide under the other's large ones
+        import os as _os
+        self._two_streams = device.type == "cuda" and cfg.two_streams and _os.environ.get("VQSEG_TWO_STREAMS", "1") == "1"
+        self._streams = [torch.cuda.Stream(device) for _ in self.models] if self._two_streams else []
+        self._pending_sides = set()
         self.opts = [torch.optim.Adam(m.parameters(), lr=cfg.learning_rate, betas=(0.9, 0.999), fused=self.device.type == "cuda")
                      for m in self.models]
         self.sched = CosineAnnealingLR(cfg.learning_rate, cfg.min_lr, cfg.total_iters, cfg.warmup_steps)
@@ -200,6 +207,32 @@ class CPSTrainer:
 
     # -- one model forward under the configured precision
     def _fwd(self, model, *a, **kw):
+        side = self._side_stream(model)
+        if side is None:
+            return self._fwd_here(model, *a, **kw)
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)                                          # inputs / zeroed buckets come from the caller's stream
+        with torch.cuda.stream(side):
+            out = self._fwd_here(model, *a, **kw)
+        for t in out:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(main)                                   # consumed on the caller's stream
+        self._pending_sides.add(side)
+        return out
+
+    def _join(self):
+        """the caller's stream waits for everything queued on the per-model streams"""
+        main = torch.cuda.current_stream()
+        for s_ in self._pending_sides:
+            main.wait_stream(s_)
+        self._pending_sides.clear()
+
+    def _side_stream(self, model):
+        if not self._two_streams:
+            return None
+        return self._streams[self.models.index(model)]
+
+    def _fwd_here(self, model, *a, **kw):
         if self.cfg.amp_dtype is None:
             return model(*a, **kw)
         with torch.autocast("cuda", dtype=self.cfg.amp_dtype):
@@ -214,8 +247,10 @@ class CPSTrainer:
             b.zero()
         with torch.no_grad():                                           # pseudo labels from eval passes
             m1.eval(); m2.eval()
-            score_1 = self._fwd(m1, ul_input)[0].float()
-            score_2 = self._fwd(m2, ul_input)[0].float()
+            score_1 = self._fwd(m1, ul_input)[0]
+            score_2 = self._fwd(m2, ul_input)[0]
+            self._join()
+            score_1, score_2 = score_1.float(), score_2.float()
             m1.train(); m2.train()
         if cfg.recipe == "v1":
             percent = 100 - cfg.unsup_loss_drop_percent * (1 - epoch_frac)
@@ -228,6 +263,7 @@ class CPSTrainer:
         ps2, c_l2, _u, p_l2 = self._fwd(m2, l_input, l_target, **kw)
         pu1, c_u1, _u, p_u1 = self._fwd(m1, ul_input, gt_ul_1, **kw)
         pu2, c_u2, usage, p_u2 = self._fwd(m2, ul_input, gt_ul_2, **kw)
+        self._join()
         ps1, ps2, pu1, pu2 = ps1.float(), ps2.float(), pu1.float(), pu2.float()
         pred_1, pred_2 = torch.cat([ps1, pu1], dim=0), torch.cat([ps2, pu2], dim=0)
         if cfg.recipe == "v1":
@@ -249,6 +285,9 @@ class CPSTrainer:
             o.param_groups[0]["lr"] = lr
         loss = sup_1 + sup_2 + cfg.cps_loss_weight * cps + commitment.sum() + prototype.float()
         loss.backward()
+        if self._two_streams:                                           # the sinks wrote p.grad on the per-model streams
+            for s_ in self._streams:
+                torch.cuda.current_stream().wait_stream(s_)
         for b in self.buckets:
             b.finish()
         for o in self.opts:
@@ -267,9 +306,12 @@ class CPSTrainer:
         m.train()
         kw = dict(percent=80.0) if self.cfg.recipe == "v1" else dict(th=self.cfg.confidence_threshold)
         pred, closs, _u, ploss = self._fwd(m, l_input, l_target, **kw)
+        self._join()
         pred = pred.float()
         loss = 0.5 * self.ce(pred, l_target) + self.criterion(pred, l_target) + closs.sum() + 0.01 * ploss.float()
         loss.backward()
+        if self._two_streams:
+            torch.cuda.current_stream().wait_stream(self._streams[0])
         self.buckets[0].finish()
         self.opts[0].step()
         return loss.detach()
