@@ -670,24 +670,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     const int oh0 = tyi * TH, ow0 = txi * TW;
     const int co0 = blockIdx.y * BN;
 
-    // ---- this lane's patch rows: instruction i of this wave covers patch pixels 8 * (wave + NW * i) .. + 7
     const int slot = lane & 7;
-    long p_pix[6];                                          // input pixel index of the row, -1 = zero
-    int p_chunk[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int pp = 8 * (wave + NW * i) + (lane >> 3);
-        const int pr = pp / PW, pc = pp - pr * PW;
-        int ih = oh0 - 1 + pr, iw = ow0 - 1 + pc;
-        bool ok = pr < PH;
-        if (p.reflect && ok) {
-            ih = reflect_idx(ih, p.H);
-            iw = reflect_idx(iw, p.W);
-        }
-        ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-        p_pix[i] = ok ? ((long)n * p.H + ih) * p.W + iw : -1;
-        p_chunk[i] = slot ^ ((pp >> 1) & 7);
-    }
     // ---- this lane's weight rows
     int b_chunk[WI];
 #pragma unroll
@@ -717,14 +700,26 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     const long w_row = 9L * cin_p;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
-    auto issue_patch = [&](int chunk, int i) {              // instruction i (0..5) of this wave for input chunk `chunk`
+    // patch rows: instruction i (0..5) of this wave covers patch pixels 8 * (wave + NW * i) .. + 7.  The row's input
+    // pixel is recomputed per instruction (a handful of VALU ops per tap) rather than kept in 18 registers.
+    auto issue_patch = [&](int chunk, int i) {
+        const int pp = 8 * (wave + NW * i) + (lane >> 3);
+        const int pr = pp / PW, pc = pp - pr * PW;
+        int ih = oh0 - 1 + pr, iw = ow0 - 1 + pc;
+        bool ok = pr < PH;
+        if (p.reflect && ok) {
+            ih = reflect_idx(ih, p.H);
+            iw = reflect_idx(iw, p.W);
+        }
+        ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        const long pix = ((long)n * p.H + ih) * p.W + iw;
         const int ci0 = chunk * 64;
         const bool second = ci0 >= p.C1;
         const char* src = reinterpret_cast<const char*>(second ? p.x2 : p.x);
         const int csrc = second ? (p.Cin - p.C1) : p.C1;
         const int cbase = second ? (ci0 - p.C1) : ci0;
-        const long off = p_pix[i] * csrc + cbase + p_chunk[i] * 8;
-        glds16(p_pix[i] >= 0 ? src + off * 2 : zero, patch0 + (chunk & 1) * PATCH_BYTES + (wave + NW * i) * 1024);
+        const long off = pix * csrc + cbase + ((slot ^ ((pp >> 1) & 7)) << 3);
+        glds16(ok ? src + off * 2 : zero, patch0 + (chunk & 1) * PATCH_BYTES + (wave + NW * i) * 1024);
     };
     auto issue_weights = [&](int chunk, int tap, int wslot) {
         char* Bs = wring + wslot * W_BYTES;
@@ -808,7 +803,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
 }
 
 static int g_patch_min_wgs = 256;
-static int g_patch_wide = 1;                                // 0: never take the 256-channel tile (a/b measurements)
+static int g_patch_wide = 0;                                // 1: take the 256-channel tile where it fills the chip (measured 3-5 % slower than the unrolled 128 tile)
 static int g_short_k_small = 2;                             // K loops of up to this many stages take the 128x128 tile at 4 waves/SIMD
 static int g_patch_unroll = 1;                              // 128-channel tile: tap loop unrolled
 
