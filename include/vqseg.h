@@ -219,6 +219,22 @@ int vqseg_im2col_f(int out_bf16, const float* x, int n, int h, int w, int cin, i
 int vqseg_reflect_fold_f(int bf16, const void* gp, int n, int h, int w, int c, void* gx, void* stream);
 int vqseg_cast_f(int to_bf16, const void* x, int64_t n, void* y, void* stream);
 
+/* Reliable prototype losses (models/modules/prototype.py:500-613 ReliablePrototypeLoss = variant 1, :778-888
+ * ReliablePrototypeLossv2 = variant 2) after the host-side label resize / entropy threshold: fused forward (scalar loss,
+ * double) and backward (d loss / d x in the activation type; variant 2 also d loss / d prototypes [k][c], nullable).
+ *   x [m][c] decoder features (f32 or bf16), proto [k][c] L2-normalised, labels [m] i64,
+ *   keep [m] u8 (variant 1: entropy <= percentile; NULL = all), conf [m] f32 (variant 2 confidence mask; NULL = 1),
+ *   margin / scale / easy_margin: the module's ArcFace parameters; g_loss: upstream gradient (device scalar). */
+size_t vqseg_proto_loss_workspace_bytes(int64_t m_rows, int c, int k);
+int vqseg_proto_loss_forward_f(int bf16, const void* x, const float* proto, const int64_t* labels,
+                               const unsigned char* keep, const float* conf, int64_t m_rows, int c, int k,
+                               int variant, float scale, float margin, int easy_margin,
+                               void* workspace, size_t workspace_bytes, double* loss, void* stream);
+int vqseg_proto_loss_backward_f(int bf16, const void* x, const float* proto, const int64_t* labels,
+                                const unsigned char* keep, const float* conf, int64_t m_rows, int c, int k,
+                                int variant, float scale, float margin, int easy_margin, const float* g_loss,
+                                void* gx, float* gproto, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,66 @@
+"""Fused prototype-loss kernels (vqseg_proto_loss_*) against the module's own tensor-op formulation of the reference
+(models/modules/prototype.py), which the golden fixtures pin on the CPU: both variants, margins, scales, margin modes,
+fp32 and bf16 features, with and without the entropy / confidence masks; forward value and gradients."""
+import pytest
+import torch
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def _run(module, x, args, fused):
+    from vq_seg_amd import nnf
+    saved = nnf.proto_loss_supported
+    if not fused:
+        nnf.proto_loss_supported = lambda *_a, **_k: False
+    try:
+        module.embedding.weight.grad = None
+        xx = x.clone().requires_grad_(True)
+        loss = module(xx, *args)
+        (loss.double() * 3.0).backward()
+        g_emb = None if module.embedding.weight.grad is None else module.embedding.weight.grad.clone()
+        return loss.detach(), xx.grad, g_emb
+    finally:
+        nnf.proto_loss_supported = saved
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("margin,scale,easy", [(0.0, 1.0, True), (0.3, 8.0, True), (1.5, 1.0, False), (0.0, 4.0, False)])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_proto_loss_matches_tensor_ops(variant, margin, scale, easy, dtype):
+    from vq_seg_amd.models.modules.prototype import ReliablePrototypeLoss, ReliablePrototypeLossv2
+    b, c, h, w, k = 3, 32, 20, 12, 3
+    cls = ReliablePrototypeLoss if variant == 1 else ReliablePrototypeLossv2
+    mod = cls(k, c, scale=scale, margin=margin, init="normal", easy_margin=easy).to(dev())
+    with torch.no_grad():
+        mod.embedding.weight.copy_(synth.uniform(3, (k, c), -1, 1))
+    mod.train()
+    x = (synth.uniform(4, (b, c, h, w), -1, 1) * 2).to(dev()).contiguous(memory_format=torch.channels_last).to(dtype)
+    gt = (synth.uniform(5, (b, h, w), 0, 1) * k).long().clamp_(0, k - 1).to(dev())
+    if variant == 1:
+        entropy = synth.uniform(6, (b * h * w,), 0, 1).to(dev())
+        cases = [(gt, 80.0, entropy), (gt, 100.0, entropy)]
+    else:
+        scores = synth.uniform(7, (b, k, h, w), -2, 2).to(dev())
+        cases = [(gt, 0.7), (scores, 0.5)]
+    for args in cases:
+        l_ref, gx_ref, ge_ref = _run(mod, x, args, fused=False)
+        l_hip, gx_hip, ge_hip = _run(mod, x, args, fused=True)
+        assert l_hip.dtype == l_ref.dtype
+        assert abs(l_hip.item() - l_ref.item()) <= 2e-6 * max(1.0, abs(l_ref.item()))
+        assert gx_hip.dtype == dtype and gx_hip.shape == gx_ref.shape
+        assert rel(gx_hip, gx_ref) < (1e-4 if dtype == torch.float32 else 1e-2)
+        if variant == 2:
+            assert ge_ref is not None and ge_hip is not None and rel(ge_hip, ge_ref) < 1e-4
+        else:
+            assert ge_ref is None and ge_hip is None

@@ -8,6 +8,8 @@
 #include "../../include/vqseg.h"
 #include "conv_kernels.h"
 #include "nn_kernels.h"
+#include "loss_kernels.h"
+#include <math.h>
 
 extern "C" int vqseg_set_error(int code, const char* msg);   // vqseg_abi.hip
 
@@ -215,6 +217,48 @@ int vqseg_cast_f(int to_bf16, const void* x, int64_t n, void* y, void* stream) {
     if (!x || !y || n <= 0) return bad("cast: bad argument");
     hipError_t e = vqseg::launch_cast(to_bf16, x, n, y, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hipfail(e, "cast_kernel");
+}
+
+static int proto_args(vqseg::ProtoArgs& a, int bf16, const void* x, const float* proto, const int64_t* labels, const unsigned char* keep,
+                      const float* conf, int64_t m, int c, int k, int variant, float scale, float margin, int easy_margin) {
+    if (!x || !proto || !labels || m <= 0) return bad("proto_loss: null pointer or empty input");
+    if (c <= 0 || c > 64 || c % 8 || k <= 0 || k > 4) return bad("proto_loss: needs channels % 8 == 0, <= 64 and at most 4 classes");
+    if (variant != 1 && variant != 2) return bad("proto_loss: variant must be 1 or 2");
+    a.x = x; a.bf16 = bf16; a.proto = proto; a.labels = reinterpret_cast<const long long*>(labels); a.keep = keep; a.conf = conf;
+    a.M = m; a.C = c; a.K = k; a.variant = variant; a.scale = scale;
+    a.cos_m = (float)cos((double)margin); a.sin_m = (float)sin((double)margin);
+    a.th = (float)cos(M_PI - (double)margin); a.mm = (float)(sin(M_PI - (double)margin) * (double)margin);
+    a.easy_margin = easy_margin; a.use_margin = margin != 0.0f;
+    return 0;
+}
+
+size_t vqseg_proto_loss_workspace_bytes(int64_t m, int c, int k) {
+    if (m <= 0 || c <= 0 || k <= 0) return 0;
+    const size_t nb = (size_t)vqseg::proto_blocks(m);
+    return nb * sizeof(double) + nb * (size_t)k * c * sizeof(float);
+}
+
+int vqseg_proto_loss_forward_f(int bf16, const void* x, const float* proto, const int64_t* labels, const unsigned char* keep,
+                               const float* conf, int64_t m, int c, int k, int variant, float scale, float margin, int easy_margin,
+                               void* workspace, size_t workspace_bytes, double* loss, void* stream) {
+    vqseg::ProtoArgs a;
+    if (int rc = proto_args(a, bf16, x, proto, labels, keep, conf, m, c, k, variant, scale, margin, easy_margin)) return rc;
+    if (!workspace || !loss) return bad("proto_loss: null pointer");
+    if (workspace_bytes < vqseg_proto_loss_workspace_bytes(m, c, k)) return vqseg_set_error(VQSEG_ENOSPC, "proto_loss: workspace too small");
+    hipError_t e = vqseg::launch_proto_forward(a, static_cast<double*>(workspace), loss, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "proto_fwd_kernel");
+}
+
+int vqseg_proto_loss_backward_f(int bf16, const void* x, const float* proto, const int64_t* labels, const unsigned char* keep,
+                                const float* conf, int64_t m, int c, int k, int variant, float scale, float margin, int easy_margin,
+                                const float* g_loss, void* gx, float* gproto, void* workspace, size_t workspace_bytes, void* stream) {
+    vqseg::ProtoArgs a;
+    if (int rc = proto_args(a, bf16, x, proto, labels, keep, conf, m, c, k, variant, scale, margin, easy_margin)) return rc;
+    if (!workspace || !g_loss || !gx) return bad("proto_loss: null pointer");
+    if (workspace_bytes < vqseg_proto_loss_workspace_bytes(m, c, k)) return vqseg_set_error(VQSEG_ENOSPC, "proto_loss: workspace too small");
+    float* gpp = gproto ? reinterpret_cast<float*>(static_cast<char*>(workspace) + (size_t)vqseg::proto_blocks(m) * sizeof(double)) : nullptr;
+    hipError_t e = vqseg::launch_proto_backward(a, g_loss, gx, gpp, gproto, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "proto_bwd_kernel");
 }
 
 }  // extern "C"

@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ... import nnf
 from ...utils.seg_tools import onehot_1d
 from ...vector_quantizer.vq_img import kmeans
 
@@ -69,16 +70,23 @@ class ReliablePrototypeLoss(_PrototypeBase):
 
     @torch.autocast("cuda", enabled=False)
     def forward(self, x, gt, percent, entropy):
-        x = x.float()
         gt = gt.unsqueeze(1) if gt.dim() == 3 else gt
         if gt.shape != x.shape:
             gt = F.interpolate(gt.float(), x.shape[-2:], mode="nearest").long()
+        if not self.initted and self.init == "kmeans" and self.training:
+            self._kmeans_init(_rows(x.float()))
+        proto = F.normalize(self.embedding.weight.data, p=2, dim=-1)
+        if nnf.proto_loss_supported(x, self.num_classes):
+            # HIP path: one fused pass forward, one backward (vqseg_proto_loss_*), bf16 or fp32 features as they are
+            with torch.no_grad():
+                thresh = torch.quantile(entropy.detach().flatten().double(), percent / 100.0)   # == np.percentile (linear)
+                keep = torch.le(entropy, thresh.to(entropy.dtype))
+            return nnf.proto_loss(x, proto, _rows(gt), keep=keep, variant=1, scale=self.scale, margin=self.margin,
+                                  easy_margin=self.easy_margin)
+        x = x.float()
         rows = _rows(x)
         labels = _rows(gt)
         onehot = onehot_1d(labels, self.num_classes)
-        if not self.initted and self.init == "kmeans" and self.training:
-            self._kmeans_init(rows)
-        proto = F.normalize(self.embedding.weight.data, p=2, dim=-1)
         rows = F.normalize(rows, p=2, dim=-1)
         cosine = F.linear(rows, proto)
         phi = self._phi(cosine)
@@ -99,6 +107,7 @@ class ReliablePrototypeLossv2(_PrototypeBase):
 
     @torch.autocast("cuda", enabled=False)
     def forward(self, x, gt, th):
+        x_in = x
         x = x.float()
         conf = None
         if gt.dim() == 4:
@@ -111,11 +120,14 @@ class ReliablePrototypeLossv2(_PrototypeBase):
         gt = gt.unsqueeze(1) if gt.dim() == 3 else gt
         if gt.shape[-2:] != x.shape[-2:]:
             gt = F.interpolate(gt.float(), x.shape[-2:], mode="nearest").long()
-        rows = _rows(x)
         labels = _rows(gt)[:, 0]
         if not self.initted and self.init == "kmeans" and self.training:
-            self._kmeans_init(rows)
+            self._kmeans_init(_rows(x.float()))
         self.embedding.weight.data = F.normalize(self.embedding.weight.data, p=2, dim=-1)   # prototype.py:844
+        if nnf.proto_loss_supported(x_in, self.num_classes):
+            return nnf.proto_loss(x_in, self.embedding.weight, labels, conf=conf, variant=2, scale=self.scale, margin=self.margin,
+                                  easy_margin=self.easy_margin).float()
+        rows = _rows(x)
         rows = F.normalize(rows, p=2, dim=-1)
         cosine = F.linear(rows, self.embedding.weight)
         phi = self._phi(cosine)

@@ -98,7 +98,7 @@ class VQRePTUnet1x1(_VQRePTUnet1x1Base):
             with torch.no_grad():
                 prob = torch.softmax(output.float().permute(0, 2, 3, 1).reshape(-1, output.shape[1]), dim=1)
                 entropy = -torch.sum(prob * torch.log(prob + 1e-10), dim=1)
-            prototype_loss = self.prototype_loss(decoder_out.float(), gt, percent=percent, entropy=entropy)
+            prototype_loss = self.prototype_loss(decoder_out, gt, percent=percent, entropy=entropy)
         output = self.upsampling(output)
         if code_usage_loss:
             return output, loss, self._usage_to_host(usage, output), torch.stack(usage).sum()[None] / len(self.codebook)
@@ -110,7 +110,7 @@ class VQRePTUnet1x1v2(_VQRePTUnet1x1Base):
 
     def forward(self, x, gt=None, code_usage_loss=False, th=None):
         decoder_out, output, loss, usage = self._trunk(x)
-        prototype_loss = self.prototype_loss(decoder_out.float(), gt, th) if self.training else None
+        prototype_loss = self.prototype_loss(decoder_out, gt, th) if self.training else None
         output = self.upsampling(output)
         if code_usage_loss:
             return output, loss, self._usage_to_host(usage, output), torch.stack(usage).sum()[None] / len(self.codebook)

@@ -437,3 +437,57 @@ def cast_act(x, dtype):
     if {x.dtype, dtype} != {torch.float32, torch.bfloat16}:
         return x.to(dtype)
     return _Cast.apply(x, dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# Reliable prototype losses (models/modules/prototype.py): fused forward / backward over the decoder features
+# ------------------------------------------------------------------------------------------------
+class _ProtoLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, proto, labels, keep, conf, variant, scale, margin, easy_margin):
+        xr = _rows(x)
+        n, h, w, c = xr.shape
+        m, k = n * h * w, proto.shape[0]
+        L = lib()
+        proto = proto.detach().float().contiguous()
+        labels = labels.reshape(-1).long().contiguous()
+        keep = keep.reshape(-1).to(torch.uint8).contiguous() if keep is not None else None
+        conf = conf.reshape(-1).float().contiguous() if conf is not None else None
+        nbytes = L.vqseg_proto_loss_workspace_bytes(m, c, k)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=xr.device)
+        loss = torch.empty((), dtype=torch.float64, device=xr.device)
+        with torch.cuda.device(xr.device):
+            _check(L.vqseg_proto_loss_forward_f(_is_bf16(xr), xr.data_ptr(), proto.data_ptr(), labels.data_ptr(), _p(keep), _p(conf),
+                                                m, c, k, variant, float(scale), float(margin), int(easy_margin), ws.data_ptr(), nbytes,
+                                                loss.data_ptr(), _stream()), "vqseg_proto_loss_forward_f")
+        ctx.save_for_backward(xr, proto, labels, keep, conf)
+        ctx.cfg = (m, c, k, variant, float(scale), float(margin), int(easy_margin))
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        xr, proto, labels, keep, conf = ctx.saved_tensors
+        m, c, k, variant, scale, margin, easy = ctx.cfg
+        L = lib()
+        g32 = g.detach().float().reshape(1).contiguous()
+        gx = torch.empty_like(xr)
+        gproto = torch.empty_like(proto) if ctx.needs_input_grad[1] else None
+        nbytes = L.vqseg_proto_loss_workspace_bytes(m, c, k)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=xr.device)
+        with torch.cuda.device(xr.device):
+            _check(L.vqseg_proto_loss_backward_f(_is_bf16(xr), xr.data_ptr(), proto.data_ptr(), labels.data_ptr(), _p(keep), _p(conf),
+                                                 m, c, k, variant, scale, margin, easy, g32.data_ptr(), gx.data_ptr(), _p(gproto),
+                                                 ws.data_ptr(), nbytes, _stream()), "vqseg_proto_loss_backward_f")
+        return _nchw(gx), gproto, None, None, None, None, None, None, None
+
+
+def proto_loss_supported(x, num_classes: int) -> bool:
+    return x.is_cuda and x.dim() == 4 and x.shape[1] % 8 == 0 and x.shape[1] <= 64 and num_classes <= 4 and \
+        x.dtype in (torch.float32, torch.bfloat16)
+
+
+def proto_loss(x, proto, labels, keep=None, conf=None, variant=1, scale=1.0, margin=0.0, easy_margin=True):
+    """-mean( log( exp(S) / (sum_c exp(z_c) + 1e-7) + 1e-7 ) * w ) of the reliable prototype losses (float64 scalar);
+    x (N, C, H, W) decoder features, proto (K, C) L2-normalised, labels / keep / conf per pixel in (n, h, w) order."""
+    return _ProtoLoss.apply(x, proto, labels, keep, conf, variant, scale, margin, easy_margin)
+
