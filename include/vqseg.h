@@ -235,6 +235,18 @@ int vqseg_proto_loss_backward_f(int bf16, const void* x, const float* proto, con
                                 int variant, float scale, float margin, int easy_margin, const float* g_loss,
                                 void* gx, float* gproto, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Soft Dice sums of loss/dice_loss.py:5-37 (softmax form, 2..4 classes; ignored pixels: zero logits, class-0 target):
+ *   inter[b][c] = sum_px p_c 1[t == c],  sets[b][c] = sum_px (p_c + 1[t == c]);  the scalar formula on these (B x C)
+ * sums stays with the host.  logits element (b, c, px) at b*stride_b + c*stride_c + px*stride_px (NCHW or NHWC);
+ * backward writes d loss / d logits in the same layout from d loss / d inter, d loss / d sets. */
+size_t vqseg_dice_workspace_bytes(int b, int c, int64_t hw);
+int vqseg_dice_sums_forward_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px,
+                              const int64_t* target, int b, int c, int64_t hw, int64_t ignore_index,
+                              void* workspace, size_t workspace_bytes, float* inter, float* sets, void* stream);
+int vqseg_dice_sums_backward_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px,
+                               const int64_t* target, int b, int c, int64_t hw, int64_t ignore_index,
+                               const float* g_inter, const float* g_sets, float* g_logits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,3 +64,34 @@ def test_proto_loss_matches_tensor_ops(variant, margin, scale, easy, dtype):
             assert ge_ref is not None and ge_hip is not None and rel(ge_hip, ge_ref) < 1e-4
         else:
             assert ge_ref is None and ge_hip is None
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc", "cat"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_dice_loss_matches_tensor_ops(layout, weighted):
+    """Fused Dice sums (vqseg_dice_sums_*) against the tensor-op formulation (loss/dice_loss.py), ignore_index = 255."""
+    from vq_seg_amd import nnf
+    from vq_seg_amd.loss.dice_loss import dice_loss
+    b, c, h, w = 4, 3, 33, 47
+    x = (synth.uniform(11, (b, c, h, w), -3, 3)).to(dev())
+    if layout == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    elif layout == "cat":
+        x = torch.cat([x[:2].contiguous(memory_format=torch.channels_last), x[2:]], dim=0)
+    t = (synth.uniform(12, (b, h, w), 0, 1) * 3).long().clamp_(0, 2).to(dev())
+    t[synth.uniform(13, (b, h, w), 0, 1).to(dev()) > 0.8] = 255
+    wgt = torch.tensor([0.2, 0.5, 0.3]) if weighted else None
+    res = []
+    for fused in (False, True):
+        saved = nnf.dice_sums_supported
+        if not fused:
+            nnf.dice_sums_supported = lambda *_a, **_k: False
+        try:
+            xx = x.clone().requires_grad_(True)
+            loss = dice_loss(xx, t, 3, weight=wgt, ignore_index=255)
+            (loss * 2.5).backward()
+            res.append((loss.detach(), xx.grad))
+        finally:
+            nnf.dice_sums_supported = saved
+    assert abs(res[0][0].item() - res[1][0].item()) < 2e-6
+    assert rel(res[1][1], res[0][1]) < 2e-4

@@ -24,4 +24,18 @@ hipError_t launch_proto_forward(const ProtoArgs& a, double* partial, double* los
 hipError_t launch_proto_backward(const ProtoArgs& a, const float* g_loss, void* gx, float* gproto_partial, float* gproto,
                                  hipStream_t st);
 
+// ---- soft Dice sums (loss/dice_loss.py:5-37): inter[b][c] = sum_px p_c 1[t == c],  sets[b][c] = sum_px (p_c + 1[t == c])
+struct DiceArgs {
+    const float* logits;         // element (b, c, px) at b * sb + c * sc + px * sp
+    long sb, sc, sp;
+    const long long* target;     // [B][HW]
+    int B, C;
+    long HW;
+    long long ignore_index;
+};
+constexpr int DICE_PX_PER_BLOCK = 4096;
+long dice_blocks(long HW);
+hipError_t launch_dice_forward(const DiceArgs& a, double* partial, float* inter, float* sets, hipStream_t st);
+hipError_t launch_dice_backward(const DiceArgs& a, const float* g_inter, const float* g_sets, float* g_logits, hipStream_t st);
+
 }  // namespace vqseg

@@ -294,4 +294,120 @@ hipError_t launch_proto_backward(const ProtoArgs& a, const float* g_loss, void* 
     return hipGetLastError();
 }
 
+// =====================================================================================================
+// Soft Dice sums.  Reference quirks kept (loss/dice_loss.py:12-18): ignored pixels get ZERO logits (softmax 1/C)
+// and become class-0 targets.  One thread walks pixels with stride 256; block sums in double, fixed-order folds.
+// =====================================================================================================
+namespace {
+constexpr int DMAXC = 4;
+
+__device__ __forceinline__ void dice_pixel(const DiceArgs& a, int b, long px, float (&p)[DMAXC], int& tgt, bool& keep) {
+    const long long t = a.target[(long)b * a.HW + px];
+    keep = t != a.ignore_index;
+    tgt = keep ? (int)t : 0;
+    float z[DMAXC], mx = -__builtin_inff();
+#pragma unroll
+    for (int c = 0; c < DMAXC; ++c)
+        if (c < a.C) {
+            z[c] = keep ? a.logits[(long)b * a.sb + c * a.sc + px * a.sp] : 0.0f;
+            mx = fmaxf(mx, z[c]);
+        }
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < DMAXC; ++c)
+        if (c < a.C) {
+            p[c] = expf(z[c] - mx);
+            sum += p[c];
+        }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int c = 0; c < DMAXC; ++c)
+        if (c < a.C) p[c] *= inv;
+}
+
+__global__ __launch_bounds__(256) void dice_fwd_kernel(const DiceArgs a, double* __restrict__ partial) {
+    __shared__ double red[256];
+    const int b = blockIdx.y;
+    const long p0 = (long)blockIdx.x * DICE_PX_PER_BLOCK;
+    double inter[DMAXC] = {0, 0, 0, 0}, sets[DMAXC] = {0, 0, 0, 0};
+    for (long px = p0 + threadIdx.x; px < p0 + DICE_PX_PER_BLOCK && px < a.HW; px += 256) {
+        float p[DMAXC];
+        int tgt;
+        bool keep;
+        dice_pixel(a, b, px, p, tgt, keep);
+#pragma unroll
+        for (int c = 0; c < DMAXC; ++c)
+            if (c < a.C) {
+                const float oh = c == tgt ? 1.0f : 0.0f;
+                inter[c] += (double)(p[c] * oh);
+                sets[c] += (double)(p[c] + oh);
+            }
+    }
+    double* out = partial + ((long)b * gridDim.x + blockIdx.x) * 2 * a.C;
+    for (int q = 0; q < 2 * a.C; ++q) {
+        red[threadIdx.x] = q < a.C ? inter[q] : sets[q - a.C];
+        __syncthreads();
+        for (int m = 128; m >= 1; m >>= 1) {
+            if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[q] = red[0];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void dice_final_kernel(const double* __restrict__ partial, long n_blocks, int C,
+                                                        float* __restrict__ inter, float* __restrict__ sets) {
+    const int b = blockIdx.x, q = threadIdx.x;
+    if (q >= 2 * C) return;
+    double s = 0.0;
+    for (long i = 0; i < n_blocks; ++i) s += partial[((long)b * n_blocks + i) * 2 * C + q];
+    if (q < C) inter[b * C + q] = (float)s;
+    else sets[b * C + q - C] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const DiceArgs a, const float* __restrict__ g_inter,
+                                                       const float* __restrict__ g_sets, float* __restrict__ g_logits) {
+    const int b = blockIdx.y;
+    const long p0 = (long)blockIdx.x * DICE_PX_PER_BLOCK;
+    float gi[DMAXC], gs[DMAXC];
+#pragma unroll
+    for (int c = 0; c < DMAXC; ++c)
+        if (c < a.C) {
+            gi[c] = g_inter[b * a.C + c];
+            gs[c] = g_sets[b * a.C + c];
+        }
+    for (long px = p0 + threadIdx.x; px < p0 + DICE_PX_PER_BLOCK && px < a.HW; px += 256) {
+        float p[DMAXC];
+        int tgt;
+        bool keep;
+        dice_pixel(a, b, px, p, tgt, keep);
+        float dp[DMAXC], dotp = 0.0f;
+#pragma unroll
+        for (int c = 0; c < DMAXC; ++c)
+            if (c < a.C) {
+                dp[c] = gs[c] + (c == tgt ? gi[c] : 0.0f);
+                dotp = __builtin_fmaf(dp[c], p[c], dotp);
+            }
+#pragma unroll
+        for (int c = 0; c < DMAXC; ++c)
+            if (c < a.C) g_logits[(long)b * a.sb + c * a.sc + px * a.sp] = keep ? p[c] * (dp[c] - dotp) : 0.0f;   // logits * keep
+    }
+}
+}  // namespace
+
+long dice_blocks(long HW) { return (HW + DICE_PX_PER_BLOCK - 1) / DICE_PX_PER_BLOCK; }
+
+hipError_t launch_dice_forward(const DiceArgs& a, double* partial, float* inter, float* sets, hipStream_t st) {
+    const long nb = dice_blocks(a.HW);
+    hipLaunchKernelGGL(dice_fwd_kernel, dim3((unsigned)nb, (unsigned)a.B), dim3(256), 0, st, a, partial);
+    hipLaunchKernelGGL(dice_final_kernel, dim3((unsigned)a.B), dim3(64), 0, st, partial, nb, a.C, inter, sets);
+    return hipGetLastError();
+}
+
+hipError_t launch_dice_backward(const DiceArgs& a, const float* g_inter, const float* g_sets, float* g_logits, hipStream_t st) {
+    hipLaunchKernelGGL(dice_bwd_kernel, dim3((unsigned)dice_blocks(a.HW), (unsigned)a.B), dim3(256), 0, st, a, g_inter, g_sets, g_logits);
+    return hipGetLastError();
+}
+
 }  // namespace vqseg

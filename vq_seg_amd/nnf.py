@@ -491,3 +491,48 @@ def proto_loss(x, proto, labels, keep=None, conf=None, variant=1, scale=1.0, mar
     x (N, C, H, W) decoder features, proto (K, C) L2-normalised, labels / keep / conf per pixel in (n, h, w) order."""
     return _ProtoLoss.apply(x, proto, labels, keep, conf, variant, scale, margin, easy_margin)
 
+
+# ------------------------------------------------------------------------------------------------
+# Soft Dice sums (loss/dice_loss.py): inter / sets per (image, class) in one pass, closed-form backward
+# ------------------------------------------------------------------------------------------------
+class _DiceSums(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, ignore_index):
+        b, c, h, w = pred.shape
+        sb, sc, sh, sw = pred.stride()
+        if sh != w * sw:                                   # pixels must be linear in memory (NCHW and NHWC both are)
+            pred = pred.contiguous()
+            sb, sc, sh, sw = pred.stride()
+        tgt = target.reshape(b, h * w).long().contiguous()
+        L = lib()
+        nbytes = L.vqseg_dice_workspace_bytes(b, c, h * w)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=pred.device)
+        out = torch.empty(2, b, c, dtype=torch.float32, device=pred.device)
+        ign = -(1 << 62) if ignore_index is None else int(ignore_index)
+        with torch.cuda.device(pred.device):
+            _check(L.vqseg_dice_sums_forward_f(pred.data_ptr(), sb, sc, sw, tgt.data_ptr(), b, c, h * w, ign, ws.data_ptr(), nbytes,
+                                               out[0].data_ptr(), out[1].data_ptr(), _stream()), "vqseg_dice_sums_forward_f")
+        ctx.save_for_backward(pred, tgt)
+        ctx.cfg = (b, c, h * w, ign, (sb, sc, sw))
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_inter, g_sets):
+        pred, tgt = ctx.saved_tensors
+        b, c, hw, ign, (sb, sc, sw) = ctx.cfg
+        g = torch.empty_strided(pred.shape, pred.stride(), dtype=torch.float32, device=pred.device)
+        gi, gs = g_inter.float().contiguous(), g_sets.float().contiguous()
+        with torch.cuda.device(pred.device):
+            _check(lib().vqseg_dice_sums_backward_f(pred.data_ptr(), sb, sc, sw, tgt.data_ptr(), b, c, hw, ign, gi.data_ptr(), gs.data_ptr(),
+                                                    g.data_ptr(), _stream()), "vqseg_dice_sums_backward_f")
+        return g, None, None
+
+
+def dice_sums_supported(pred, num_classes: int) -> bool:
+    return pred.is_cuda and pred.dim() == 4 and pred.dtype == torch.float32 and 2 <= num_classes <= 4 and pred.shape[1] == num_classes
+
+
+def dice_sums(pred, target, ignore_index):
+    """(inter, sets), each (B, C) float32: sum over pixels of softmax * onehot and of softmax + onehot (dice_loss.py:24-26)."""
+    return _DiceSums.apply(pred, target, ignore_index)
+
