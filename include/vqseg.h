@@ -100,6 +100,18 @@ int vqseg_vq_backward_f32(const float* grad_quant, const float* grad_loss, const
                           const float* quant, int64_t n_rows, int channels,
                           float commitment_weight, float* grad_x, void* stream);
 
+/* The same layer on bf16 activations (the trainer's autocast mode): x and quant are bf16 rows, every bf16 value is an
+ * exact float and all arithmetic (distances, argmin, straight-through value, commitment) is the fp32 arithmetic of the
+ * f32 entry points, so the indices are identical to those of the up-cast rows; quant is rounded to bf16 on store.
+ * Backward re-reads e = codebook[idx] in fp32 (the bf16 quant would cost the commitment gradient its accuracy):
+ *   grad_x = grad_quant + (2 w grad_loss / (n c)) (x - e). */
+int vqseg_vq_forward_bf16(const void* x, const float* codebook, const void* prepared, int64_t n_rows, int channels,
+                          int n_codes, int training, float commitment_weight, void* quant, int64_t* idx, float* loss,
+                          float* dead_pct, float* dmin, void* workspace, size_t workspace_bytes, void* stream);
+int vqseg_vq_backward_bf16(const void* grad_quant, const float* grad_loss, const void* x, const int64_t* idx,
+                           const float* codebook, int64_t n_rows, int channels, float commitment_weight,
+                           void* grad_x, void* stream);
+
 /* ---------------------------------------------------------------------------------- *
  * k-means codebook initialisation, Lloyd iterations GIVEN the initial means.
  * Replaces kmeans() (vq_img.py:29-63, euclidean branch) after its RNG draw (:10-17,

@@ -173,3 +173,30 @@ def test_half_and_bf16_inputs_are_cast_to_fp32():
         from oracle import torch_ref
         _, ref_idx, _, _ = torch_ref.vq_forward(xh, W, training=False)
         assert torch.equal(idx.cpu(), ref_idx)
+    # under autocast the bf16 rows are consumed as they are (same indices) and the output is bf16 for the bf16 decoder
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        q, idx2, _, _ = vq(x.to(torch.bfloat16).to(dev()))
+    assert q.dtype == torch.bfloat16 and torch.equal(idx2.cpu(), ref_idx)
+
+
+@pytest.mark.parametrize("shape", [(4096, 64, 96), (3000, 512, 512), (777, 2048, 33)])
+def test_bf16_rows_give_the_same_layer(shape):
+    """bf16 activations (autocast mode): every bf16 value is an exact float, so the layer on bf16 rows must equal the
+    fp32 layer on the up-cast rows -- identical indices, histogram and (to fp32 summation order) loss; quant is the
+    bf16 rounding of the fp32 straight-through value; backward re-reads the fp32 codebook row."""
+    from vq_seg_amd import _hip
+    n, c, k = shape
+    dev = torch.device("cuda:0")
+    rows = synth.relu_features(n + c, (n, c)).to(dev).bfloat16()
+    cb = synth.relu_features(k + 5, (k, c)).to(dev)
+    q32, i32, l32, d32 = _hip.vq_forward(rows.float(), cb, True, 0.25)
+    q16, i16, l16, d16 = _hip.vq_forward(rows, cb, True, 0.25)
+    assert q16.dtype == torch.bfloat16
+    assert torch.equal(i16, i32) and torch.equal(d16, d32)
+    assert torch.equal(q16, q32.bfloat16())
+    assert abs(l16.item() - l32.item()) <= 1e-6 * abs(l32.item())
+    g = synth.uniform(9, (n, c), -1, 1).to(dev).bfloat16()
+    gl = torch.tensor([0.7], device=dev)
+    gx32 = _hip.vq_backward(g.float(), gl, rows.float(), cb[i32], 0.25)       # exact e = codebook[idx]
+    gx16 = _hip.vq_backward_bf16(g, gl, rows, i16, cb, 0.25)
+    assert torch.equal(gx16, gx32.bfloat16())

@@ -27,6 +27,9 @@ SYMBOLS = {
     "vqseg_vq_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "vqseg_vq_forward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vqseg_vq_forward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vqseg_vq_backward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "vqseg_vq_assign_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_size_t, c_void_p]),
     "vqseg_vq_prepared_bytes": (c_size_t, [c_int, c_int]),
@@ -143,7 +146,8 @@ def vq_forward(rows: torch.Tensor, codebook: torch.Tensor, training: bool, commi
     L = lib()
     n, c = rows.shape
     k = codebook.shape[0]
-    xp, wp = _dev(rows, torch.float32, "rows"), _dev(codebook, torch.float32, "codebook")
+    bf16 = rows.dtype == torch.bfloat16                      # bf16 activations: same fp32 arithmetic, bf16 quant
+    xp, wp = _dev(rows, rows.dtype if bf16 else torch.float32, "rows"), _dev(codebook, torch.float32, "codebook")
     dev = rows.device
     quant = torch.empty_like(rows)
     idx = torch.empty(n, dtype=torch.int64, device=dev)
@@ -152,10 +156,11 @@ def vq_forward(rows: torch.Tensor, codebook: torch.Tensor, training: bool, commi
     nbytes = L.vqseg_vq_workspace_bytes(n, c, k)
     ws = _workspace(nbytes, dev)
     with torch.cuda.device(dev):
-        rc = L.vqseg_vq_forward_f32(xp, wp, prepared.data_ptr() if prepared is not None else None, n, c, k,
-                                    int(bool(training)), float(commitment_weight), quant.data_ptr(),
-                                    idx.data_ptr(), scal.data_ptr(), scal.data_ptr() + 4,
-                                    dmin.data_ptr() if want_dmin else None, ws.data_ptr(), nbytes, _stream())
+        fwd = L.vqseg_vq_forward_bf16 if bf16 else L.vqseg_vq_forward_f32
+        rc = fwd(xp, wp, prepared.data_ptr() if prepared is not None else None, n, c, k,
+                 int(bool(training)), float(commitment_weight), quant.data_ptr(),
+                 idx.data_ptr(), scal.data_ptr(), scal.data_ptr() + 4,
+                 dmin.data_ptr() if want_dmin else None, ws.data_ptr(), nbytes, _stream())
     _check(rc, "vqseg_vq_forward_f32")
     out = (quant, idx, scal[0:1], scal[1])
     return out + (dmin,) if want_dmin else out
@@ -166,7 +171,8 @@ def vq_assign(rows: torch.Tensor, codebook: torch.Tensor, want_dmin: bool = Fals
     L = lib()
     n, c = rows.shape
     k = codebook.shape[0]
-    xp, wp = _dev(rows, torch.float32, "rows"), _dev(codebook, torch.float32, "codebook")
+    bf16 = rows.dtype == torch.bfloat16                      # bf16 activations: same fp32 arithmetic, bf16 quant
+    xp, wp = _dev(rows, rows.dtype if bf16 else torch.float32, "rows"), _dev(codebook, torch.float32, "codebook")
     dev = rows.device
     idx = torch.empty(n, dtype=torch.int64, device=dev)
     dmin = torch.empty(n, dtype=torch.float32, device=dev) if want_dmin else None
@@ -191,6 +197,22 @@ def vq_backward(grad_quant: torch.Tensor, grad_loss: Optional[torch.Tensor], row
         rc = L.vqseg_vq_backward_f32(gq, gl, _dev(rows, torch.float32, "rows"), _dev(quant, torch.float32, "quant"),
                                      n, c, float(commitment_weight), gx.data_ptr(), _stream())
     _check(rc, "vqseg_vq_backward_f32")
+    return gx
+
+
+def vq_backward_bf16(grad_quant: torch.Tensor, grad_loss: Optional[torch.Tensor], rows: torch.Tensor, idx: torch.Tensor,
+                     codebook: torch.Tensor, commitment_weight: float) -> torch.Tensor:
+    """bf16 activations: grad_x = grad_quant + (2 w grad_loss / (N C)) (x - codebook[idx]), e re-read in fp32."""
+    L = lib()
+    n, c = rows.shape
+    gq = _dev(grad_quant, torch.bfloat16, "grad_quant")
+    gl = _dev(grad_loss, torch.float32, "grad_loss") if grad_loss is not None else None
+    gx = torch.empty_like(rows)
+    with torch.cuda.device(rows.device):
+        rc = L.vqseg_vq_backward_bf16(gq, gl, _dev(rows, torch.bfloat16, "rows"), _dev(idx, torch.int64, "idx"),
+                                      _dev(codebook, torch.float32, "codebook"), n, c, float(commitment_weight), gx.data_ptr(),
+                                      _stream())
+    _check(rc, "vqseg_vq_backward_bf16")
     return gx
 
 

@@ -39,12 +39,14 @@ KmPlan km_plan(int64_t N, int C, int K);
 
 size_t prepared_bytes(int C, int K);
 hipError_t launch_prepare(const float* W, int K, int C, void* prepared, hipStream_t st);
-hipError_t launch_assign(const float* x, int64_t N, int C, int K, const void* prepared, const VqPlan& p, char* ws,
+hipError_t launch_assign(const void* x, int x_bf16, int64_t N, int C, int K, const void* prepared, const VqPlan& p, char* ws,
                          int64_t* idx, float* dmin, hipStream_t st);
-hipError_t launch_gather(const float* x, const float* W, const int64_t* idx, int64_t N, int C, int K, int training,
-                         float cw, const VqPlan& p, char* ws, float* quant, float* loss, float* dead, hipStream_t st);
+hipError_t launch_gather(const void* x, int bf16, const float* W, const int64_t* idx, int64_t N, int C, int K, int training,
+                         float cw, const VqPlan& p, char* ws, void* quant, float* loss, float* dead, hipStream_t st);
 hipError_t launch_backward(const float* gq, const float* gloss, const float* x, const float* q, int64_t N, int C,
                            float cw, float* gx, hipStream_t st);
+hipError_t launch_backward_idx(const void* gq, const float* gloss, const void* x, const int64_t* idx, const float* W, int64_t N,
+                               int C, float cw, void* gx, hipStream_t st);
 hipError_t launch_km_accumulate(const float* samples, const float* means, int64_t N, int C, int K, const KmPlan& p,
                                 char* ws, float* sums, int64_t* counts64, hipStream_t st);
 hipError_t launch_km_finalize(const float* sums, const int64_t* counts64, float* means, int C, int K, hipStream_t st);

@@ -34,6 +34,7 @@ namespace vqseg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------
 // codebook preparation ("prepared codebook" blob, valid until the codebook changes):
@@ -105,8 +106,9 @@ __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int T>
-__global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const float* __restrict__ x,
+// TX: storage type of the pixel rows (float, or __bf16 -- every bf16 value is an exact float, the arithmetic is the same)
+template <int T, typename TX = float>
+__global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const TX* __restrict__ x,
                                                                const float* __restrict__ E4,
                                                                const float* __restrict__ enorm, long N,
                                                                int C, int Cp, int Kp,
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const float* __re
     const long row0 = (long)blockIdx.x * ROWS_PER_WG + wave * ROWS_PER_WAVE;
     long row = row0 + r;
     if (row > N - 1) row = N - 1;                               // clamp: loads stay in bounds
-    const float* xrow = x + row * (long)C + 4 * h;
+    const TX* xrow = x + row * (long)C + 4 * h;
 
     f32x16 acc[T];
 #pragma unroll
@@ -156,7 +158,15 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const float* __re
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             const int col = stage * BK + 8 * j + 4 * h;
-            a[j] = (col < C) ? *reinterpret_cast<const f32x4*>(xrow + stage * BK + 8 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (col >= C) {
+                a[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else if constexpr (sizeof(TX) == 4) {
+                a[j] = *reinterpret_cast<const f32x4*>(xrow + stage * BK + 8 * j);
+            } else {
+                const u32x2 v = *reinterpret_cast<const u32x2*>(xrow + stage * BK + 8 * j);       // 4 bf16
+                a[j] = f32x4{__builtin_bit_cast(float, v[0] << 16), __builtin_bit_cast(float, v[0] & 0xFFFF0000u),
+                             __builtin_bit_cast(float, v[1] << 16), __builtin_bit_cast(float, v[1] & 0xFFFF0000u)};
+            }
         }
     };
 
@@ -313,9 +323,35 @@ __global__ __launch_bounds__(256) void vq_unpack_keys(const unsigned long long* 
 constexpr int GATHER_BLOCKS_MAX = 2048;
 constexpr int GATHER_ROWS_PER_BLOCK = 16;   // 4 waves x 4 rows in flight
 
-__global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict__ x, const float* __restrict__ W,
+template <typename TA>
+__device__ __forceinline__ f32x4 ld4(const TA* p, long v) {                 // elements 4v .. 4v+3 as floats
+    if constexpr (sizeof(TA) == 4) {
+        return reinterpret_cast<const f32x4*>(p)[v];
+    } else {
+        const u32x2 r = reinterpret_cast<const u32x2*>(p)[v];
+        return f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xFFFF0000u),
+                     __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xFFFF0000u)};
+    }
+}
+template <typename TA>
+__device__ __forceinline__ void st4(TA* p, long v, const f32x4& q) {
+    if constexpr (sizeof(TA) == 4) {
+        reinterpret_cast<f32x4*>(p)[v] = q;
+    } else {
+        u32x2 r;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const __bf16 lo = (__bf16)q[2 * e], hi = (__bf16)q[2 * e + 1];
+            r[e] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+        }
+        reinterpret_cast<u32x2*>(p)[v] = r;
+    }
+}
+
+template <typename TA>
+__global__ __launch_bounds__(256) void vq_gather_kernel(const TA* __restrict__ x, const float* __restrict__ W,
                                                         const long long* __restrict__ idx, long N, int C,
-                                                        int training, float* __restrict__ quant,
+                                                        int training, TA* __restrict__ quant,
                                                         int* __restrict__ hist, float* __restrict__ partial) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4 = C >> 2;
@@ -334,13 +370,13 @@ __global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict_
             for (int j = 0; j < RG; ++j) {
                 if (row0 + j < N) {
                     e[j] = reinterpret_cast<const f32x4*>(W + k[j] * (long)C)[v];
-                    if (training) xv[j] = reinterpret_cast<const f32x4*>(x + (row0 + j) * (long)C)[v];
+                    if (training) xv[j] = ld4<TA>(x + (row0 + j) * (long)C, v);
                 }
             }
 #pragma unroll
             for (int j = 0; j < RG; ++j) {
                 if (row0 + j < N) {
-                    f32x4* qr = reinterpret_cast<f32x4*>(quant + (row0 + j) * (long)C);
+                    TA* qr = quant + (row0 + j) * (long)C;
                     if (training) {
                         f32x4 q;
 #pragma unroll
@@ -349,9 +385,9 @@ __global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict_
                             const float dlt = q[i] - xv[j][i];
                             sq = __builtin_fmaf(dlt, dlt, sq);
                         }
-                        qr[v] = q;
+                        st4<TA>(qr, v, q);
                     } else {
-                        qr[v] = e[j];
+                        st4<TA>(qr, v, e[j]);
                     }
                 }
             }
@@ -406,6 +442,27 @@ __global__ __launch_bounds__(256) void vq_backward_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf(k, xv[j] - qv[j], g[j]);
         reinterpret_cast<f32x4*>(gx)[i] = o;
+    }
+}
+
+// bf16 activations: the quantised rows are not kept for backward (their bf16 image would cost the commitment gradient
+// its accuracy); the code index is, and e = W[idx] is re-read in fp32:  gx = g + k (x - e)
+__global__ __launch_bounds__(256) void vq_backward_idx_kernel(const __bf16* __restrict__ gq, const float* __restrict__ gloss,
+                                                              const __bf16* __restrict__ x, const long long* __restrict__ idx,
+                                                              const float* __restrict__ W, long N, int C, float coef,
+                                                              __bf16* __restrict__ gx) {
+    const float k = gloss ? gloss[0] * coef : 0.0f;
+    const int c4 = C >> 2;
+    const long n4 = N * c4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long row = i / c4;
+        const int v = (int)(i - row * c4);
+        const f32x4 g = ld4<__bf16>(gq, i), xv = ld4<__bf16>(x, i);
+        const f32x4 e = reinterpret_cast<const f32x4*>(W + idx[row] * (long)C)[v];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf(k, xv[j] - e[j], g[j]);
+        st4<__bf16>(gx, i, o);
     }
 }
 
@@ -653,16 +710,16 @@ int profile_collect(int max_records, int64_t* n, int* c, int* k, float* ms) {
     return out;
 }
 
-template <int T>
-static void launch_assign_t(const float* x, const float* E4, const float* en, int64_t N, int C, int Kp,
+template <int T, typename TX>
+static void launch_assign_t(const TX* x, const float* E4, const float* en, int64_t N, int C, int Kp,
                             unsigned long long* keys, hipStream_t st) {
     static_assert((size_t)WAVES * 32 * 33 * sizeof(unsigned long long) <= (2 * STAGE_FLOATS + 256) * sizeof(float), "key scratch aliases the B stages");
     const size_t lds = (size_t)(2 * STAGE_FLOATS + 256 + WAVES * 32) * sizeof(float);
     const dim3 grid((unsigned)((N + ROWS_PER_WG - 1) / ROWS_PER_WG), (unsigned)(Kp / (32 * T)));
-    hipLaunchKernelGGL(vq_assign_f32_kernel<T>, grid, dim3(256), lds, st, x, E4, en, (long)N, C, C, Kp, keys);
+    hipLaunchKernelGGL((vq_assign_f32_kernel<T, TX>), grid, dim3(256), lds, st, x, E4, en, (long)N, C, C, Kp, keys);
 }
 
-hipError_t launch_assign(const float* x, int64_t N, int C, int K, const void* prepared, const VqPlan& p, char* ws,
+hipError_t launch_assign(const void* x, int x_bf16, int64_t N, int C, int K, const void* prepared, const VqPlan& p, char* ws,
                          int64_t* idx, float* dmin, hipStream_t st) {
     const float* E4 = reinterpret_cast<const float*>(prepared);
     const float* en = E4 + (size_t)C * p.Kp;
@@ -675,12 +732,16 @@ hipError_t launch_assign(const float* x, int64_t N, int C, int K, const void* pr
         g_prof.shape.push_back({N, C, K});
         (void)hipEventRecord(g_prof.ev[2 * slot], st);
     }
+#define VQ_ASSIGN(T_)                                                                             \
+    if (x_bf16) launch_assign_t<T_, __bf16>(static_cast<const __bf16*>(x), E4, en, N, C, p.Kp, keys, st); \
+    else launch_assign_t<T_, float>(static_cast<const float*>(x), E4, en, N, C, p.Kp, keys, st)
     switch (p.T) {
-        case 8: launch_assign_t<8>(x, E4, en, N, C, p.Kp, keys, st); break;
-        case 4: launch_assign_t<4>(x, E4, en, N, C, p.Kp, keys, st); break;
-        case 2: launch_assign_t<2>(x, E4, en, N, C, p.Kp, keys, st); break;
-        default: launch_assign_t<1>(x, E4, en, N, C, p.Kp, keys, st); break;
+        case 8: VQ_ASSIGN(8); break;
+        case 4: VQ_ASSIGN(4); break;
+        case 2: VQ_ASSIGN(2); break;
+        default: VQ_ASSIGN(1); break;
     }
+#undef VQ_ASSIGN
     if (rec) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
     long blocks = (N + 255) / 256;
     if (blocks > 2048) blocks = 2048;
@@ -689,14 +750,18 @@ hipError_t launch_assign(const float* x, int64_t N, int C, int K, const void* pr
     return hipGetLastError();
 }
 
-hipError_t launch_gather(const float* x, const float* W, const int64_t* idx, int64_t N, int C, int K, int training,
-                         float cw, const VqPlan& p, char* ws, float* quant, float* loss, float* dead, hipStream_t st) {
+hipError_t launch_gather(const void* x, int bf16, const float* W, const int64_t* idx, int64_t N, int C, int K, int training,
+                         float cw, const VqPlan& p, char* ws, void* quant, float* loss, float* dead, hipStream_t st) {
     int* hist = reinterpret_cast<int*>(ws + p.off_hist);
     float* partial = reinterpret_cast<float*>(ws + p.off_partial);
     hipError_t e = hipMemsetAsync(hist, 0, (size_t)p.Kp * sizeof(int), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(vq_gather_kernel, dim3(p.gather_blocks), dim3(256), 0, st, x, W,
-                       reinterpret_cast<const long long*>(idx), (long)N, C, training, quant, hist, partial);
+    if (bf16)
+        hipLaunchKernelGGL(vq_gather_kernel<__bf16>, dim3(p.gather_blocks), dim3(256), 0, st, static_cast<const __bf16*>(x), W,
+                           reinterpret_cast<const long long*>(idx), (long)N, C, training, static_cast<__bf16*>(quant), hist, partial);
+    else
+        hipLaunchKernelGGL(vq_gather_kernel<float>, dim3(p.gather_blocks), dim3(256), 0, st, static_cast<const float*>(x), W,
+                           reinterpret_cast<const long long*>(idx), (long)N, C, training, static_cast<float*>(quant), hist, partial);
     hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, partial, p.gather_blocks, hist, K, training, cw,
                        (double)N * (double)C, loss, dead);
     return hipGetLastError();
@@ -741,12 +806,25 @@ KmPlan km_plan(int64_t N, int C, int K) {
     return p;
 }
 
+hipError_t launch_backward_idx(const void* gq, const float* gloss, const void* x, const int64_t* idx, const float* W, int64_t N,
+                               int C, float cw, void* gx, hipStream_t st) {
+    const long n4 = (long)N * C / 4;
+    const float coef = (float)((double)cw * 2.0 / ((double)N * (double)C));
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(vq_backward_idx_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const __bf16*>(gq), gloss,
+                       static_cast<const __bf16*>(x), reinterpret_cast<const long long*>(idx), W, (long)N, C, coef,
+                       static_cast<__bf16*>(gx));
+    return hipGetLastError();
+}
+
 hipError_t launch_km_accumulate(const float* samples, const float* means, int64_t N, int C, int K, const KmPlan& p,
                                 char* ws, float* sums, int64_t* counts64, hipStream_t st) {
     hipError_t e = launch_prepare(means, K, C, ws + p.vq.off_prepared, st);
     if (e != hipSuccess) return e;
     int64_t* idx = reinterpret_cast<int64_t*>(ws + p.off_idx);
-    e = launch_assign(samples, N, C, K, ws + p.vq.off_prepared, p.vq, ws, idx, nullptr, st);
+    e = launch_assign(samples, 0, N, C, K, ws + p.vq.off_prepared, p.vq, ws, idx, nullptr, st);
     if (e != hipSuccess) return e;
     int* counts = reinterpret_cast<int*>(ws + p.off_counts);
     int* offsets = reinterpret_cast<int*>(ws + p.off_offsets);

@@ -86,8 +86,8 @@ int vqseg_vq_prepare_f32(const float* codebook, int c, int k, void* prepared, si
     return 0;
 }
 
-int vqseg_vq_assign_f32(const float* x, const float* codebook, const void* prepared, int64_t n, int c, int k,
-                        int64_t* idx, float* dmin, void* ws, size_t ws_bytes, void* stream) {
+static int vq_assign_any(const void* x, int x_bf16, const float* codebook, const void* prepared, int64_t n, int c, int k,
+                         int64_t* idx, float* dmin, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_shape(n, c, k)) return rc;
     if (!x || !idx || !ws || (!codebook && !prepared)) return fail(VQSEG_EINVAL, "null pointer argument");
     if (!aligned16(x) || !aligned16(ws) || !aligned16(prepared) || !aligned16(codebook))
@@ -101,21 +101,50 @@ int vqseg_vq_assign_f32(const float* x, const float* codebook, const void* prepa
         if (e != hipSuccess) return hip_fail(e, "vq codebook prepare");
         prepared = w + p.off_prepared;
     }
-    hipError_t e = vqseg::launch_assign(x, n, c, k, prepared, p, w, idx, dmin, st);
+    hipError_t e = vqseg::launch_assign(x, x_bf16, n, c, k, prepared, p, w, idx, dmin, st);
     if (e != hipSuccess) return hip_fail(e, "vq_assign_f32_kernel");
+    return 0;
+}
+
+int vqseg_vq_assign_f32(const float* x, const float* codebook, const void* prepared, int64_t n, int c, int k,
+                        int64_t* idx, float* dmin, void* ws, size_t ws_bytes, void* stream) {
+    return vq_assign_any(x, 0, codebook, prepared, n, c, k, idx, dmin, ws, ws_bytes, stream);
+}
+
+static int vq_forward_any(const void* x, int bf16, const float* codebook, const void* prepared, int64_t n, int c, int k,
+                          int training, float cw, void* quant, int64_t* idx, float* loss, float* dead_pct, float* dmin,
+                          void* ws, size_t ws_bytes, void* stream) {
+    if (!quant || !loss || !dead_pct || !codebook) return fail(VQSEG_EINVAL, "null pointer argument");
+    if (!aligned16(quant)) return fail(VQSEG_EINVAL, "quant must be 16-byte aligned");
+    if (int rc = vq_assign_any(x, bf16, codebook, prepared, n, c, k, idx, dmin, ws, ws_bytes, stream)) return rc;
+    const vqseg::VqPlan p = vqseg::vq_plan(n, c, k);
+    hipError_t e = vqseg::launch_gather(x, bf16, codebook, idx, n, c, k, training, cw, p, static_cast<char*>(ws), quant, loss,
+                                        dead_pct, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "vq_gather_kernel");
     return 0;
 }
 
 int vqseg_vq_forward_f32(const float* x, const float* codebook, const void* prepared, int64_t n, int c, int k,
                          int training, float cw, float* quant, int64_t* idx, float* loss, float* dead_pct, float* dmin,
                          void* ws, size_t ws_bytes, void* stream) {
-    if (!quant || !loss || !dead_pct || !codebook) return fail(VQSEG_EINVAL, "null pointer argument");
-    if (!aligned16(quant)) return fail(VQSEG_EINVAL, "quant must be 16-byte aligned");
-    if (int rc = vqseg_vq_assign_f32(x, codebook, prepared, n, c, k, idx, dmin, ws, ws_bytes, stream)) return rc;
-    const vqseg::VqPlan p = vqseg::vq_plan(n, c, k);
-    hipError_t e = vqseg::launch_gather(x, codebook, idx, n, c, k, training, cw, p, static_cast<char*>(ws), quant, loss,
-                                        dead_pct, static_cast<hipStream_t>(stream));
-    if (e != hipSuccess) return hip_fail(e, "vq_gather_kernel");
+    return vq_forward_any(x, 0, codebook, prepared, n, c, k, training, cw, quant, idx, loss, dead_pct, dmin, ws, ws_bytes, stream);
+}
+
+int vqseg_vq_forward_bf16(const void* x, const float* codebook, const void* prepared, int64_t n, int c, int k,
+                          int training, float cw, void* quant, int64_t* idx, float* loss, float* dead_pct, float* dmin,
+                          void* ws, size_t ws_bytes, void* stream) {
+    if (c % 8) return fail(VQSEG_EINVAL, "bf16 rows need channels %% 8 == 0");
+    return vq_forward_any(x, 1, codebook, prepared, n, c, k, training, cw, quant, idx, loss, dead_pct, dmin, ws, ws_bytes, stream);
+}
+
+int vqseg_vq_backward_bf16(const void* gq, const float* gloss, const void* x, const int64_t* idx, const float* codebook,
+                           int64_t n, int c, float cw, void* gx, void* stream) {
+    if (int rc = check_shape(n, c, 1)) return rc;
+    if (!gq || !x || !idx || !codebook || !gx) return fail(VQSEG_EINVAL, "null pointer argument");
+    if (c % 8) return fail(VQSEG_EINVAL, "bf16 rows need channels %% 8 == 0");
+    if (!aligned16(gq) || !aligned16(x) || !aligned16(codebook) || !aligned16(gx)) return fail(VQSEG_EINVAL, "tensors must be 16-byte aligned");
+    hipError_t e = vqseg::launch_backward_idx(gq, gloss, x, idx, codebook, n, c, cw, gx, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "vq_backward_idx_kernel");
     return 0;
 }
 

@@ -25,8 +25,12 @@ class _VQFunction(torch.autograd.Function):
         quant, idx, loss, dead = _hip.vq_forward(rows, codebook, training, commitment_weight, prepared=prepared)
         ctx.commitment_weight = float(commitment_weight)
         ctx.training = bool(training)
+        ctx.bf16 = rows.dtype == torch.bfloat16
         if training:
-            ctx.save_for_backward(rows, quant)
+            if ctx.bf16:
+                ctx.save_for_backward(rows, idx, codebook)   # the code index, not the (bf16-rounded) quantised rows
+            else:
+                ctx.save_for_backward(rows, quant)
         ctx.mark_non_differentiable(idx, dead)
         return quant, idx, loss, dead
 
@@ -34,20 +38,26 @@ class _VQFunction(torch.autograd.Function):
     def backward(ctx, g_quant, _g_idx, g_loss, _g_dead):
         if not ctx.training:
             return None, None, None, None, None             # eval: quant is a pure gather (constant in x)
+        gl = g_loss.contiguous() if (g_loss is not None and ctx.commitment_weight > 0) else None
+        if ctx.bf16:
+            rows, idx, codebook = ctx.saved_tensors
+            g_quant = torch.zeros_like(rows) if g_quant is None else g_quant.to(torch.bfloat16).contiguous()
+            return _hip.vq_backward_bf16(g_quant, gl, rows, idx, codebook, ctx.commitment_weight), None, None, None, None
         rows, quant = ctx.saved_tensors
         if g_quant is None:
             g_quant = torch.zeros_like(rows)
         g_quant = g_quant.contiguous()
-        gl = g_loss.contiguous() if (g_loss is not None and ctx.commitment_weight > 0) else None
         gx = _hip.vq_backward(g_quant, gl, rows, quant, ctx.commitment_weight)
         return gx, None, None, None, None                   # the codebook receives no gradient (vq_img.py:236-239)
 
 
 def _rows_of(x: torch.Tensor):
-    """(B, C, H, W) any float -> contiguous fp32 (B*H*W, C) rows (free for channels_last input)."""
-    from .. import nnf
+    """(B, C, H, W) -> contiguous (B*H*W, C) rows (free for channels_last input).  Under torch.autocast bf16 activations
+    stay bf16 (the kernels up-cast on load: x.float() of vq_img.py:229 without the pass over memory, and the quantised
+    output is bf16 -- what the autocast decoder would cast it to anyway); everything else becomes fp32."""
     b, c, h, w = x.shape
-    x = nnf.cast_act(x, torch.float32) if x.dtype == torch.bfloat16 else x.to(torch.float32)
+    if not (x.dtype == torch.bfloat16 and x.is_cuda and c % 8 == 0 and torch.is_autocast_enabled()):
+        x = x.to(torch.float32)                             # outside autocast the layer returns fp32 like the reference
     rows = x.permute(0, 2, 3, 1)                            # vq_img.py:229,232
     if not rows.is_contiguous():
         rows = rows.contiguous()
@@ -142,12 +152,12 @@ class VectorQuantizer(nn.Module):
                                           num_codebook=num_codebook)
 
     def forward(self, x: torch.Tensor):
-        """x (B, C, H, W) -> (quantize (B, C, H, W) f32, embed_index (B, H, W) i64, loss (1,), code_usage ())."""
+        """x (B, C, H, W) -> (quantize (B, C, H, W) f32 -- bf16 for bf16 input --, embed_index (B, H, W) i64, loss (1,), code_usage ())."""
         b, c, h, w = x.shape
         rows = _rows_of(x)
         cb = self.codebook
-        if cb.kmeans_init and self.training:
-            cb._kmeans_init(rows.detach())                                   # vq_img.py:165-166
+        if cb.kmeans_init and self.training and not cb.initted:
+            cb._kmeans_init(rows.detach().float())                           # vq_img.py:165-166
         quant, idx, loss, dead = _VQFunction.apply(rows, cb.embedding.weight.detach(), self.training,
                                                    float(self.commitment_weight), cb.prepared())
         quantize = quant.reshape(b, h, w, c).permute(0, 3, 1, 2)             # vq_img.py:242 (channels_last view)
