@@ -720,23 +720,31 @@ constexpr int HEAD_ROWS = 1024;
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const T* __restrict__ x, const float* __restrict__ g, long M, int Cin,
                                                               int Cout, float* __restrict__ partial) {
-    // block -> HEAD_ROWS rows; thread -> (o, c) pairs over a row slice; partial[blk][Cout*Cin]
-    const int pairs = Cin * Cout;
+    // block -> HEAD_ROWS rows; thread -> (row slot, input channel c): one x load (coalesced along c) feeds Cout <= 4
+    // accumulators; the 256 / Cin row slots are folded through LDS in slot order; partial[blk][Cout * Cin]
+    __shared__ float sh[4][256];
+    const int slots = 256 / Cin > 0 ? 256 / Cin : 1;
+    const int c = threadIdx.x % Cin, sl = threadIdx.x / Cin;
     const long row0 = (long)blockIdx.x * HEAD_ROWS;
-    __shared__ float sh[256];
-    const int slices = 256 / pairs > 0 ? 256 / pairs : 1;
-    const int pr = threadIdx.x % pairs, sl = threadIdx.x / pairs;
-    float acc = 0.0f;
-    if (sl < slices) {
-        const int o = pr / Cin, c = pr % Cin;
-        for (long m = row0 + sl; m < row0 + HEAD_ROWS && m < M; m += slices) acc = __builtin_fmaf(g[m * Cout + o], ld(x, m * Cin + c), acc);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sl < slots) {
+        long end = row0 + HEAD_ROWS;
+        if (end > M) end = M;
+        for (long m = row0 + sl; m < end; m += slots) {
+            const float xv = ld(x, m * Cin + c);
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (o < Cout) acc[o] = __builtin_fmaf(g[m * Cout + o], xv, acc[o]);
+        }
     }
-    sh[threadIdx.x] = acc;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) sh[o][threadIdx.x] = acc[o];
     __syncthreads();
-    if (threadIdx.x < pairs) {
+    if ((int)threadIdx.x < Cin * Cout) {
+        const int o = threadIdx.x / Cin, cc = threadIdx.x % Cin;
         float s = 0.0f;
-        for (int l = 0; l < slices; ++l) s += sh[l * pairs + threadIdx.x];
-        partial[(long)blockIdx.x * pairs + threadIdx.x] = s;
+        for (int l = 0; l < slots; ++l) s += sh[o][l * Cin + cc];
+        partial[(long)blockIdx.x * Cin * Cout + threadIdx.x] = s;
     }
 }
 
