@@ -426,3 +426,33 @@ def test_grad_sink_accumulates_in_place():
     assert sorted(fired) == sorted(id(q) for q in list(conv2.parameters()) + list(bn2.parameters()))
     for a_, b_ in zip(list(conv.parameters()) + list(bn.parameters()), list(conv2.parameters()) + list(bn2.parameters())):
         assert rel(b_.grad - 0.5, a_.grad) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["precise", "fast"])
+def test_bottleneck_grad_link_is_exact(mode):
+    """Identity-shortcut bottleneck: folding the shortcut's gradient into conv1's data-gradient epilogue (nnf.GradLink)
+    must give bit-identical gradients to autograd's separate add (same roundings in the same order)."""
+    from vq_seg_amd import nnf
+    from vq_seg_amd.models.encoders.resnet import Bottleneck
+    torch.manual_seed(1)
+    blk = Bottleneck(256, 64).to(dev())
+    blk.train()
+    dt = torch.float32 if mode == "precise" else torch.bfloat16
+    x0 = cl(synth.uniform(3, (2, 256, 16, 16), -1, 1)).to(dt)
+    g = cl(synth.uniform(4, (2, 256, 16, 16), -1, 1)).to(dt)
+
+    def run(use_link):
+        saved = nnf.GradLink
+        if not use_link:
+            nnf.GradLink = lambda: None
+        try:
+            for p_ in blk.parameters():
+                p_.grad = None
+            x = x0.clone().requires_grad_(True)
+            blk(x).backward(g)
+            return [x.grad.clone()] + [p_.grad.clone() for p_ in blk.parameters()]
+        finally:
+            nnf.GradLink = saved
+
+    a, b = run(True), run(False)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))

@@ -33,5 +33,7 @@ def test_two_streams_change_nothing(recipe, amp):
     la, ca = _run(False, recipe, amp)
     lb, cb = _run(True, recipe, amp)
     assert all(l == l and abs(l) < 1e6 for l in la)           # finite
-    assert la == lb, (la, lb)
+    # the loss VALUE passes through ATen's cross-entropy forward (v2 recipe), whose atomics make its last bit vary from
+    # run to run; every gradient kernel is deterministic, so the updated parameters must agree bit for bit
+    assert all(abs(u - v) <= 1e-6 * abs(u) for u, v in zip(la, lb)), (la, lb)
     assert torch.equal(ca, cb)

@@ -9,6 +9,7 @@ zero-padded, q13), six feature maps returned.  state_dict keys equal torchvision
 """
 from __future__ import annotations
 
+import torch
 from torch import nn
 
 from ... import nnf
@@ -53,11 +54,14 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         idt = x
+        link = None
         if self.downsample is not None:
             idt = nnf.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
-        y = nnf.conv_bn_act(x, self.conv1, self.bn1)
+        elif torch.is_grad_enabled() and x.requires_grad:
+            link = nnf.GradLink()              # identity shortcut: conv1's data gradient absorbs the shortcut's gradient
+        y = nnf.conv_bn_act(x, self.conv1, self.bn1, link_in=link)
         y = nnf.conv_bn_act(y, self.conv2, self.bn2)
-        return nnf.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=idt)
+        return nnf.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=idt, link_out=link)
 
 
 resnet_encoders = {

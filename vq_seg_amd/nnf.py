@@ -96,6 +96,28 @@ def _out_size(h, k, s, p):
 # (`accumulate` flag of the C entry points) and autograd gets None for that parameter -- one tiny add kernel per
 # parameter and backward pass less.  The callback (if any) is told, as a post-accumulate-grad hook would be.
 # ------------------------------------------------------------------------------------------------
+class GradLink:
+    """Carries the gradient of a block's identity branch from the backward of its LAST conv (`link_out`: where the
+    residual add happened) to the backward of its FIRST conv (`link_in`), whose data-gradient kernel adds it in its
+    epilogue -- instead of autograd materialising both gradients of the block input and adding them in a separate
+    pass.  Valid when both convolutions read the same tensor (identity shortcut)."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+
+_UNIT_AFFINE = {}
+
+
+def _unit_affine(dev, c):
+    key = (str(dev), c)
+    if key not in _UNIT_AFFINE:
+        _UNIT_AFFINE[key] = (torch.ones(c, dtype=torch.float32, device=dev), torch.zeros(c, dtype=torch.float32, device=dev))
+        torch.cuda.current_stream(dev).synchronize()       # once per (device, width): other streams may read them next
+    return _UNIT_AFFINE[key]
+
+
 def _sink_ready(p) -> bool:
     g = getattr(p, "grad", None)
     return hasattr(p, "_vq_grad_sink") and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.is_cuda
@@ -123,7 +145,8 @@ def _sink_done(p) -> None:
 # ------------------------------------------------------------------------------------------------
 class _ConvBNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, x2, residual, weight, gamma, beta, bn, stride, pad, reflect, relu, patches_of, fuse_eval=False):
+    def forward(ctx, x, x2, residual, weight, gamma, beta, bn, stride, pad, reflect, relu, patches_of, fuse_eval=False,
+                link_in=None, link_out=None):
         """x (N,C1,H,W) [+ x2 (N,C2,H,W)] -> out (N,Cout,Ho,Wo).  `patches_of` = (kh, kw, cin, stride, pad, reflect,
         H, W) when x is an im2col patch matrix of the stem (then the convolution itself is 1x1)."""
         xr = _rows(x)
@@ -181,6 +204,7 @@ class _ConvBNAct(torch.autograd.Function):
                                       out.data_ptr(), _stream()), "vqseg_bn_apply_f")
         ctx.save_for_backward(xr, x2r, y, out, coef, weight, gamma)
         ctx.params = (weight, gamma, beta)                                  # the Parameter objects (see grad sinks)
+        ctx.links = (link_in, link_out)
         ctx.cfg = (stride, pad, bool(reflect), bool(relu), training, residual is not None, patches_of, (n, h, w, c1, cin, cout,
                                                                                                          kh, kw, ho, wo))
         return _nchw(out)
@@ -214,6 +238,9 @@ class _ConvBNAct(torch.autograd.Function):
                                          _stream()), "vqseg_bn_backward_f")
         if sink_bn:
             _sink_done(p_g), _sink_done(p_b)
+        link_in, link_out = ctx.links
+        if link_out is not None and has_res:
+            link_out.g = g_res                                              # picked up by the block's first conv (GradLink)
         # ---- weight gradient
         gw = p_w.grad if sink_w else torch.empty(weight.shape, dtype=torch.float32, device=dev)
         if patches_of:
@@ -242,7 +269,22 @@ class _ConvBNAct(torch.autograd.Function):
             hp, wp = (h + 2 * pad, w + 2 * pad) if reflect else (h, w)         # reflect: gradient of the padded input first
             dpad = (kh - 1) if reflect else (kh - 1 - pad)
 
+            extra = link_in.g if link_in is not None else None          # residual-branch gradient of the same block input
+            if link_in is not None:
+                link_in.g = None
+
             def dgrad(c_lo, c_cnt):
+                nonlocal extra
+                if extra is not None and not reflect and stride == 1 and x2r is None and extra.shape == (n, hp, wp, c_cnt):
+                    # the data gradient and the residual-branch gradient meet in the convolution's epilogue (one add pass less)
+                    one, zero = _unit_affine(dev, c_cnt)
+                    gp = torch.empty((n, hp, wp, c_cnt), dtype=g_y.dtype, device=dev)
+                    with torch.cuda.device(dev):
+                        _check(L.vqseg_conv2d_affine_f(g_y.data_ptr(), None, cout, t_hi.data_ptr(), _p(t_lo), one.data_ptr(),
+                                                       zero.data_ptr(), extra.data_ptr(), 0, gp.data_ptr(), n, ho, wo, cout, c_cnt,
+                                                       kh, kw, 1, dpad, 0, hp, wp, int(precise), _stream()), "vqseg_conv2d_affine_f")
+                    extra = None
+                    return gp
                 gp = _conv_raw(g_y, None, cout, t_hi, t_lo, (n, hp, wp, c_cnt), None, n, ho, wo, cout, c_cnt, kh, kw, 1, dpad, False,
                                stride, hp, wp, w_offset_elems=c_lo * taps * ((cout + 31) // 32 * 32))
                 if not reflect:
@@ -256,11 +298,16 @@ class _ConvBNAct(torch.autograd.Function):
                 return gxx
 
             if need1:
-                gx = _nchw(dgrad(0, c1))
+                g1 = dgrad(0, c1)
+                if extra is not None:                                       # link not fusable here: plain add
+                    g1 = g1 + extra
+                    extra = None
+                gx = _nchw(g1)
             if need2 and x2r is not None:
                 gx2 = _nchw(dgrad(c1, cin - c1))
-        return (gx, gx2, (_nchw(g_res) if has_res else None), None if sink_w else gw, None if sink_bn else dgb[0],
-                None if sink_bn else dgb[1], None, None, None, None, None, None, None)
+        g_res_out = _nchw(g_res) if (has_res and link_out is None) else None
+        return (gx, gx2, g_res_out, None if sink_w else gw, None if sink_bn else dgb[0],
+                None if sink_bn else dgb[1], None, None, None, None, None, None, None, None, None)
 
 
 def _stem_weights(weight, precise, kp):
@@ -281,7 +328,7 @@ def _stem_weights(weight, precise, kp):
     return cache[k]
 
 
-def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None):
+def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None, link_in=None, link_out=None):
     """Conv2d (no bias; zero or reflect padding) -> BatchNorm2d -> [+ residual] -> [ReLU] on the HIP kernels.
     `x2`: second input whose channels follow x's (the decoder's concat).  `training` is ignored: the
     BatchNorm module's own mode decides (nn.BatchNorm2d semantics)."""
@@ -292,7 +339,8 @@ def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None):
     pad = conv.padding[0]
     _sink_use(conv.weight, bn.weight, bn.bias)
     return _ConvBNAct.apply(x, x2, residual, conv.weight, bn.weight, bn.bias, bn, conv.stride[0], pad,
-                            conv.padding_mode == "reflect" and pad > 0, relu, None, not bn.training and not torch.is_grad_enabled())
+                            conv.padding_mode == "reflect" and pad > 0, relu, None, not bn.training and not torch.is_grad_enabled(),
+                            link_in, link_out)
 
 
 def stem_conv_bn_act(x, conv, bn):
