@@ -196,7 +196,8 @@ int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, 
  *               recomputed as fma(y, fwd_scale, fwd_shift) > 0, the forward's own expression (one tensor read less). */
 int vqseg_bn_finalize_f(float* partial, int64_t m_rows, int c, const float* gamma, const float* beta,
                         float* run_mean, float* run_var, float momentum, float eps, int training,
-                        float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+                        float* scale, float* shift, float* save_mean, float* save_invstd,
+                        int64_t* num_batches_tracked /* nullable: += 1 in training mode */, void* stream);
 int vqseg_bn_apply_f(int bf16, const void* y, const void* res, const float* scale, const float* shift,
                      int64_t m_rows, int c, int relu, void* out, void* stream);
 size_t vqseg_bn_backward_workspace_floats(int64_t m_rows, int c);

@@ -51,7 +51,7 @@ SYMBOLS = {
     "vqseg_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int] * 9),
     "vqseg_conv2d_wgrad_f": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 17 + [c_void_p, c_size_t, c_void_p, c_void_p]),
     "vqseg_bn_finalize_f": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
-                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqseg_bn_apply_f": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "vqseg_bn_backward_workspace_floats": (c_size_t, [c_int64, c_int]),
     "vqseg_bn_backward_f": (c_int, [c_int] + [c_void_p] * 8 + [c_int64, c_int, c_int, c_int, c_int] + [c_void_p] * 6),

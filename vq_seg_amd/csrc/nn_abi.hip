@@ -126,14 +126,15 @@ int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, 
 
 int vqseg_bn_finalize_f(float* partial, int64_t m_rows, int c, const float* gamma, const float* beta, float* run_mean,
                         float* run_var, float momentum, float eps, int training, float* scale, float* shift, float* save_mean,
-                        float* save_invstd, void* stream) {
+                        float* save_invstd, int64_t* num_batches_tracked, void* stream) {
     if (!gamma || !beta || !scale || !shift || !save_mean || !save_invstd || c <= 0 || m_rows <= 0) return bad("bn_finalize: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e;
     if (training) {
         if (!partial) return bad("bn_finalize: training mode needs the conv epilogue partials");
         e = vqseg::launch_bn_finalize(partial, (m_rows + conv_rows_per_slot(c) - 1) / conv_rows_per_slot(c), conv_rows_per_slot(c), m_rows, c, gamma, beta,
-                                      run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd, st);
+                                      run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd,
+                                      reinterpret_cast<long long*>(num_batches_tracked), st);
     } else {
         if (!run_mean || !run_var) return bad("bn_finalize: eval mode needs running statistics");
         e = vqseg::launch_bn_eval_coeffs(c, gamma, beta, run_mean, run_var, eps, scale, shift, save_mean, save_invstd, st);

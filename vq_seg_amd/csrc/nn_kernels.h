@@ -8,7 +8,7 @@ namespace vqseg {
 
 hipError_t launch_bn_finalize(float* partial, long n_slots, int rows_per_slot, long M, int C, const float* gamma,
                               const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
-                              float* shift, float* save_mean, float* save_invstd, hipStream_t st);
+                              float* shift, float* save_mean, float* save_invstd, long long* num_batches_tracked, hipStream_t st);
 hipError_t launch_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var,
                                  float eps, float* scale, float* shift, float* save_mean, float* save_invstd, hipStream_t st);
 hipError_t launch_bn_apply(int bf16, const void* y, const void* res, const float* scale, const float* shift, long M, int C,

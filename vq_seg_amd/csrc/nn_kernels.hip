@@ -130,8 +130,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           const float* __restrict__ beta, float* __restrict__ run_mean,
                                                           float* __restrict__ run_var, float momentum, float eps,
                                                           float* __restrict__ scale, float* __restrict__ shift,
-                                                          float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+                                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                          long long* __restrict__ num_batches_tracked) {
     __shared__ PowerSums lds[256];
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;   // nn.BatchNorm2d bookkeeping
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const PowerSums r = fold_slots(partial, 0, n_slots, slots_per_group, slots_per_group > 1, rows_per_slot, M, C, c, lds);
     if ((threadIdx.x >> 6) == 0 && c < C) {
@@ -933,7 +935,7 @@ static inline unsigned grid_for(long work, int per_block = 256, long cap = 8192)
 
 hipError_t launch_bn_finalize(float* partial, long n_slots, int rows_per_slot, long M, int C, const float* gamma,
                               const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
-                              float* shift, float* save_mean, float* save_invstd, hipStream_t st_) {
+                              float* shift, float* save_mean, float* save_invstd, long long* num_batches_tracked, hipStream_t st_) {
     long spg = 1;                                           // slots per group of level 1
     if (n_slots > 128) {
         spg = (n_slots + 127) / 128;
@@ -943,7 +945,7 @@ hipError_t launch_bn_finalize(float* partial, long n_slots, int rows_per_slot, l
                            rows_per_slot, M, C);
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st_, partial, n_slots, spg, rows_per_slot, M, C, gamma,
-                       beta, run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd);
+                       beta, run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd, num_batches_tracked);
     return hipGetLastError();
 }
 

@@ -180,7 +180,7 @@ class _ConvBNAct(torch.autograd.Function):
                 _check(L.vqseg_bn_finalize_f(None, m, cout, _dev(gamma, torch.float32, "bn.weight"),
                                              _dev(beta, torch.float32, "bn.bias"), _p(bn.running_mean), _p(bn.running_var),
                                              float(bn.momentum), float(bn.eps), 0, coef[0].data_ptr(), coef[1].data_ptr(),
-                                             coef[2].data_ptr(), coef[3].data_ptr(), _stream()), "vqseg_bn_finalize_f")
+                                             coef[2].data_ptr(), coef[3].data_ptr(), None, _stream()), "vqseg_bn_finalize_f")
                 _check(L.vqseg_conv2d_affine_f(xr.data_ptr(), _p(x2r), c1, w_hi.data_ptr(), _p(w_lo), coef[0].data_ptr(),
                                                coef[1].data_ptr(), _p(rr), int(relu), out.data_ptr(), n, h, w, cin, cout, kh, kw,
                                                stride, pad, int(reflect), ho, wo, int(precise), _stream()), "vqseg_conv2d_affine_f")
@@ -192,10 +192,9 @@ class _ConvBNAct(torch.autograd.Function):
             _check(L.vqseg_bn_finalize_f(_p(stat), m, cout, _dev(gamma, torch.float32, "bn.weight"),
                                          _dev(beta, torch.float32, "bn.bias"), _p(bn.running_mean), _p(bn.running_var),
                                          float(bn.momentum), float(bn.eps), int(training), coef[0].data_ptr(),
-                                         coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), _stream()),
+                                         coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
+                                         _p(bn.num_batches_tracked) if training else None, _stream()),   # += 1 in the kernel
                    "vqseg_bn_finalize_f")
-            if training and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
             rr = _rows(residual) if residual is not None else None
             if rr is not None and rr.dtype != y.dtype:
                 raise _hip.HipLibraryError("residual dtype differs from the activation dtype")
