@@ -4,7 +4,7 @@ FETCH_SIZE is in KiB and reports HALF of the bytes of wide coalesced reads on gf
 in KiB and exact -> x 1024.  GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy fraction =
 SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs).
 usage: python tools/summarize_pmc.py gpurun_out/pmc_r1 profiles/r01"""
-import csv, json, os, sys
+import csv, json, os, re, sys
 from collections import defaultdict
 
 src, dst = sys.argv[1], sys.argv[2]
@@ -12,7 +12,8 @@ K = 512                                                      # bench.py's codebo
 acc = defaultdict(lambda: defaultdict(list))
 for name in ("fetch", "write", "mfma"):
     for r in csv.DictReader(open(os.path.join(src, name + ".csv"))):
-        t = int(r["Kernel_Name"].split("<")[1].split(">")[0])
+        mt = re.search(r"vq_assign_f32_kernel(?:<(\d+)|ILi(\d+)E)", r["Kernel_Name"])   # demangled or mangled (bf16 rows) name
+        t = int(mt.group(1) or mt.group(2))
         wgs = int(r["Grid_Size"]) // 256
         n_rows = wgs * 128 // (K // (32 * t))
         key = f"N{n_rows}_T{t}"
