@@ -35,6 +35,7 @@ namespace vqseg {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------
 // codebook preparation ("prepared codebook" blob, valid until the codebook changes):
@@ -106,6 +107,9 @@ __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+template <typename TX> struct RawFrag { typedef f32x4 type; };
+template <> struct RawFrag<__bf16> { typedef u32x2 type; };
+
 // TX: storage type of the pixel rows (float, or __bf16 -- every bf16 value is an exact float, the arithmetic is the same)
 template <int T, typename TX = float>
 __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const TX* __restrict__ x,
@@ -154,18 +158,17 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const TX* __restr
             glds16(src, dst + piece * 256);
         }
     };
-    auto load_a = [&](int stage, f32x4 (&a)[JB]) {
+    // bf16 rows stay RAW (8 bytes = 4 bf16 per block) until their stage becomes current (widen_a): converting at the
+    // load would put the wait for the global load in front of the current stage's MFMAs
+    using RawA = typename RawFrag<TX>::type;
+    auto load_a = [&](int stage, RawA (&a)[JB]) {
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             const int col = stage * BK + 8 * j + 4 * h;
             if (col >= C) {
-                a[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            } else if constexpr (sizeof(TX) == 4) {
-                a[j] = *reinterpret_cast<const f32x4*>(xrow + stage * BK + 8 * j);
+                a[j] = RawA{};
             } else {
-                const u32x2 v = *reinterpret_cast<const u32x2*>(xrow + stage * BK + 8 * j);       // 4 bf16
-                a[j] = f32x4{__builtin_bit_cast(float, v[0] << 16), __builtin_bit_cast(float, v[0] & 0xFFFF0000u),
-                             __builtin_bit_cast(float, v[1] << 16), __builtin_bit_cast(float, v[1] & 0xFFFF0000u)};
+                a[j] = *reinterpret_cast<const RawA*>(xrow + stage * BK + 8 * j);
             }
         }
     };
@@ -175,12 +178,26 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const TX* __restr
     //   MFMAs that consume them, so by the time the stage's last block starts every fragment of the stage is in
     //   registers: the barrier sits right there, the freed buffer is refilled for stage s+2, and the first block of
     //   stage s+1 is fetched under the last block's MFMAs.
-    f32x4 a_cur[JB], a_nxt[JB];
+    f32x4 a_cur[JB];
+    RawA a_nxt[JB];
     fill(0, 0);
     if (n_stage > 1) fill(1, 1);
-    load_a(0, a_cur);
+    auto widen_a = [&](f32x4 (&dst)[JB], const RawA (&src)[JB]) {
 #pragma unroll
-    for (int j = 0; j < JB; ++j) a_nxt[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < JB; ++j) {
+            if constexpr (sizeof(TX) == 4) {
+                dst[j] = src[j];
+            } else {
+                const unsigned lo = src[j][0], hi = src[j][1];
+                dst[j] = f32x4{__builtin_bit_cast(float, lo << 16), __builtin_bit_cast(float, lo & 0xFFFF0000u),
+                               __builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xFFFF0000u)};
+            }
+        }
+    };
+    load_a(0, a_nxt);
+    widen_a(a_cur, a_nxt);
+#pragma unroll
+    for (int j = 0; j < JB; ++j) a_nxt[j] = RawA{};
     __syncthreads();                                           // drains vmcnt, then barrier
 
     // B fragment of lane (r, h) for block j, tile t: Bs[buf][2j + h][32 t + r][0..3]
@@ -227,8 +244,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const TX* __restr
         mfma_block(JB - 1);
 #pragma unroll
         for (int t = 0; t < T; ++t) b_cur[t] = b_nxt[t];
-#pragma unroll
-        for (int j = 0; j < JB; ++j) a_cur[j] = a_nxt[j];
+        widen_a(a_cur, a_nxt);
     }
 
     // ---- epilogue: distances -> (min, code) per row over this workgroup's codes
