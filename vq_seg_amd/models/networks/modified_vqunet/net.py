@@ -56,14 +56,19 @@ class _VQRePTUnet1x1Base(nn.Module):
         self.device = None
         self.upsampling = _Upsampling(upsampling) if upsampling > 1 else nn.Identity()
 
-    # -- shared trunk: encoder -> VQ on the configured levels -> decoder -> 1x1 head
-    def _trunk(self, x):
+    # -- shared trunk in three phases: encoder -> VQ on the configured levels -> decoder + 1x1 head.  forward() runs them
+    # back to back; trainer.CPSTrainer drives the phases of its two networks separately so that the distance kernels of
+    # the VQ phase have the GPU to themselves while everything else of the two networks overlaps on two streams.
+    def encode(self, x):
         if self.device is None:
             self.device = x.device
         feats = self.encoder(_to_device_layout(x))[1:]
         if len(feats) != len(self.codebook):
             raise NotImplementedError
-        loss = torch.zeros(1, device=x.device)
+        return feats
+
+    def quantize(self, feats):
+        loss = torch.zeros(1, device=feats[0].device)
         usage = []
         for i, vq in enumerate(self.codebook):
             quantize, _idx, commitment, dead = vq(feats[i])
@@ -72,15 +77,36 @@ class _VQRePTUnet1x1Base(nn.Module):
                 loss = loss + commitment
             if dead is not None:
                 usage.append(dead.detach())
-        loss = loss / len(feats)
-        decoder_out = self.decoder(*feats)
-        return decoder_out, self.segmentation_head(decoder_out), loss, usage
+        return feats, loss / len(feats), usage
 
-    @staticmethod
-    def _usage_to_host(usage, like):
+    def decode(self, feats):
+        decoder_out = self.decoder(*feats)
+        return decoder_out, self.segmentation_head(decoder_out)
+
+    def _trunk(self, x):
+        feats, loss, usage = self.quantize(self.encode(x))
+        decoder_out, logits = self.decode(feats)
+        return decoder_out, logits, loss, usage
+
+    # `async_code_usage = True` (set by trainer.CPSTrainer): the code-usage vector is copied to PINNED host memory without
+    # blocking the host -- the returned CPU tensor is valid once the stream has been synchronised.  The default keeps the
+    # reference's semantics (a CPU tensor that is valid on return), at the price of one host-device sync per forward, which
+    # stalls the host's kernel queue (and keeps the two networks of a CPS pair from overlapping).
+    async_code_usage = False
+
+    def _usage_to_host(self, usage, like):
         if not usage:
             return torch.tensor([])
-        return torch.stack(usage).cpu()                               # the one device->host copy of forward
+        stacked = torch.stack(usage)
+        if not (self.async_code_usage and stacked.is_cuda):
+            return stacked.cpu()                                      # the one device->host copy of forward
+        ring = self.__dict__.setdefault("_usage_ring", [])            # a few pinned buffers, reused round-robin
+        if len(ring) < 8:
+            ring.append(torch.empty(stacked.shape, dtype=stacked.dtype, pin_memory=True))
+        buf = ring[self.__dict__.setdefault("_usage_i", 0) % len(ring)]
+        self.__dict__["_usage_i"] += 1
+        buf.copy_(stacked, non_blocking=True)
+        return buf
 
     @torch.no_grad()
     def pseudo_label(self, x):
@@ -92,7 +118,10 @@ class VQRePTUnet1x1(_VQRePTUnet1x1Base):
     _proto_cls = ReliablePrototypeLoss
 
     def forward(self, x, gt=None, code_usage_loss=False, percent=None):
-        decoder_out, output, loss, usage = self._trunk(x)
+        return self.finish(*self.quantize(self.encode(x)), gt=gt, code_usage_loss=code_usage_loss, percent=percent)
+
+    def finish(self, feats, loss, usage, gt=None, code_usage_loss=False, percent=None):
+        decoder_out, output = self.decode(feats)
         prototype_loss = None
         if self.training:
             with torch.no_grad():
@@ -109,7 +138,10 @@ class VQRePTUnet1x1v2(_VQRePTUnet1x1Base):
     _proto_cls = ReliablePrototypeLossv2
 
     def forward(self, x, gt=None, code_usage_loss=False, th=None):
-        decoder_out, output, loss, usage = self._trunk(x)
+        return self.finish(*self.quantize(self.encode(x)), gt=gt, code_usage_loss=code_usage_loss, th=th)
+
+    def finish(self, feats, loss, usage, gt=None, code_usage_loss=False, th=None):
+        decoder_out, output = self.decode(feats)
         prototype_loss = self.prototype_loss(decoder_out, gt, th) if self.training else None
         output = self.upsampling(output)
         if code_usage_loss:
