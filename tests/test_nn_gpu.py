@@ -183,6 +183,9 @@ PATCH_CASES = [
     (2, 64, 0, 128, 8, 32, False), (1, 128, 64, 256, 16, 64, True), (3, 64, 0, 128, 16, 16, True), (2, 192, 0, 128, 32, 48, False),
     (1, 64, 64, 384, 16, 32, False), (2, 128, 0, 256, 16, 32, False),
     (2, 64, 0, 64, 8, 32, True), (1, 128, 64, 32, 16, 32, False), (2, 64, 0, 32, 16, 16, True), (2, 128, 0, 64, 32, 32, False),
+    # 32-channel chunks (channel counts that are not multiples of 64)
+    (2, 32, 0, 32, 16, 32, False), (1, 96, 0, 128, 16, 16, True), (2, 32, 0, 64, 8, 32, True), (1, 32, 32, 128, 16, 32, False),
+    (2, 160, 0, 32, 8, 32, False),
 ]
 
 

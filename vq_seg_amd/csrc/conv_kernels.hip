@@ -637,17 +637,24 @@ struct TileRows {                                           // tile row -> outpu
     }
 };
 
-template <int BN, int NBW, bool UNROLL_TAPS>
+// CK: input channels per chunk (64, or 32 for layers whose channel count is not a multiple of 64: rows of 64 bytes,
+// four 16-byte chunks swizzled by (row >> 2) & 3, two K steps per tap)
+template <int BN, int NBW, bool UNROLL_TAPS, int CK = 64>
 __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     constexpr int TBM = 256, NW = 8;
     constexpr int NT = BN >= 128 ? 2 : 1;                  // 32-channel tiles per wave
     constexpr int WN = BN / (32 * NT), WM = NW / WN;       // wave grid; wave tile (MT*32) px x (NT*32) co
     constexpr int MT = TBM / (WM * 32);                    // BN 256/128/64/32 -> MT 4/2/2/1 (64/32-row BN stat slots)
-    constexpr int PATCH_BYTES = 48 * 1024;                 // 6 DMA instructions (8 rows x 128 B) per wave
-    constexpr int W_ROWS = BN >= 64 ? BN : 64;             // weight rows staged per tap (rows >= Cout: zero page)
-    constexpr int W_BYTES = W_ROWS * 128;
+    constexpr int ROWB = CK * 2;                           // bytes per LDS row (one pixel / one output channel)
+    constexpr int RPI = 1024 / ROWB;                       // rows per 1 KB DMA instruction
+    constexpr int KS = CK / 16;                            // MFMA K steps per tap
+    constexpr int PI = (344 + RPI * NW - 1) / (RPI * NW);  // patch DMA instructions per wave and chunk (6 or 3)
+    constexpr int PATCH_BYTES = PI * NW * 1024;
+    constexpr int W_ROWS = (BN * ROWB >= NW * 1024) ? BN : NW * 1024 / ROWB;   // weight rows staged per tap (rows >= Cout: zero page)
+    constexpr int W_BYTES = W_ROWS * ROWB;
     constexpr int WI = W_BYTES / 1024 / NW;                // weight DMA instructions per wave and tap
-    static_assert(W_BYTES % (1024 * NW) == 0, "weight tile must split evenly over the waves");
+    static_assert(W_BYTES % (1024 * NW) == 0 && (CK == 64 || CK == 32), "weight tile must split evenly over the waves");
+    auto swz = [](int row) { return CK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const patch0 = smem;
@@ -670,13 +677,13 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     const int oh0 = tyi * TH, ow0 = txi * TW;
     const int co0 = blockIdx.y * BN;
 
-    const int slot = lane & 7;
+    const int slot = lane & (ROWB / 16 - 1), lrow = lane / (ROWB / 16);     // 16-byte slot and row of this lane in a DMA instruction
     // ---- this lane's weight rows
     int b_chunk[WI];
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-        const int row = 8 * (wave * WI + i) + (lane >> 3);
-        b_chunk[i] = slot ^ ((row >> 1) & 7);
+        const int row = RPI * (wave * WI + i) + lrow;
+        b_chunk[i] = slot ^ swz(row);
     }
     // ---- MFMA A rows: tile row -> patch pixel (tap (0, 0))
     int a_pp[MT];
@@ -695,15 +702,15 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
     const int cin_p = (p.Cin + 31) / 32 * 32;
-    const int n_chunks = p.Cin / 64;
+    const int n_chunks = p.Cin / CK;
     const int n_stage = n_chunks * 9;
     const long w_row = 9L * cin_p;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
-    // patch rows: instruction i (0..5) of this wave covers patch pixels 8 * (wave + NW * i) .. + 7.  The row's input
-    // pixel is recomputed per instruction (a handful of VALU ops per tap) rather than kept in 18 registers.
+    // patch rows: instruction i (0..PI-1) of this wave covers patch pixels RPI * (wave + NW * i) .. + RPI - 1.  The row's
+    // input pixel is recomputed per instruction (a handful of VALU ops per tap) rather than kept in 18 registers.
     auto issue_patch = [&](int chunk, int i) {
-        const int pp = 8 * (wave + NW * i) + (lane >> 3);
+        const int pp = RPI * (wave + NW * i) + lrow;
         const int pr = pp / PW, pc = pp - pr * PW;
         int ih = oh0 - 1 + pr, iw = ow0 - 1 + pc;
         bool ok = pr < PH;
@@ -713,21 +720,21 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
         }
         ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
         const long pix = ((long)n * p.H + ih) * p.W + iw;
-        const int ci0 = chunk * 64;
+        const int ci0 = chunk * CK;
         const bool second = ci0 >= p.C1;
         const char* src = reinterpret_cast<const char*>(second ? p.x2 : p.x);
         const int csrc = second ? (p.Cin - p.C1) : p.C1;
         const int cbase = second ? (ci0 - p.C1) : ci0;
-        const long off = pix * csrc + cbase + ((slot ^ ((pp >> 1) & 7)) << 3);
+        const long off = pix * csrc + cbase + ((slot ^ swz(pp)) << 3);
         glds16(ok ? src + off * 2 : zero, patch0 + (chunk & 1) * PATCH_BYTES + (wave + NW * i) * 1024);
     };
     auto issue_weights = [&](int chunk, int tap, int wslot) {
         char* Bs = wring + wslot * W_BYTES;
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
-            const int row = 8 * (wave * WI + i) + (lane >> 3);
+            const int row = RPI * (wave * WI + i) + lrow;
             const int co = co0 + row;
-            const unsigned short* wp = p.w_hi + (long)co * w_row + (long)tap * cin_p + chunk * 64 + b_chunk[i] * 8;
+            const unsigned short* wp = p.w_hi + (long)co * w_row + (long)tap * cin_p + chunk * CK + b_chunk[i] * 8;
             glds16(co < p.Cout ? reinterpret_cast<const char*>(wp) : zero, Bs + (wave * WI + i) * 1024);
         }
     };
@@ -735,17 +742,17 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
         const char* Ps = patch0 + (chunk & 1) * PATCH_BYTES;
         const char* Bs = wring + wslot * W_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < KS; ++kk) {
             bf16x8 af[MT], bfr[NT];
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int pp = a_pp[a] + tapoff;
-                af[a] = *reinterpret_cast<const bf16x8*>(Ps + pp * 128 + (((kk * 2 + h) ^ ((pp >> 1) & 7)) << 4));
+                af[a] = *reinterpret_cast<const bf16x8*>(Ps + pp * ROWB + (((kk * 2 + h) ^ swz(pp)) << 4));
             }
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
                 const int row = (wn * NT + b) * 32 + r;
-                bfr[b] = *reinterpret_cast<const bf16x8*>(Bs + row * 128 + (((kk * 2 + h) ^ ((row >> 1) & 7)) << 4));
+                bfr[b] = *reinterpret_cast<const bf16x8*>(Bs + row * ROWB + (((kk * 2 + h) ^ swz(row)) << 4));
             }
 #pragma unroll
             for (int a = 0; a < MT; ++a)
@@ -757,12 +764,12 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
 
     // ---- prologue: whole patch of chunk 0, weights of the first NBW - 1 stages
 #pragma unroll
-    for (int i = 0; i < 6; ++i) issue_patch(0, i);
+    for (int i = 0; i < PI; ++i) issue_patch(0, i);
 #pragma unroll
     for (int s = 0; s < NBW - 1; ++s)
         if (s < n_stage) issue_weights(s / 9, s % 9, s);
 
-    // stage = (chunk, tap).  Issue order inside a stage: [patch piece of chunk + 1 (taps 0..5)] [weights of stage
+    // stage = (chunk, tap).  Issue order inside a stage: [patch piece of chunk + 1 (taps 0..PI-1)] [weights of stage
     // s + NBW - 1].  At the top of stage s the DMA instructions younger than the weights of stage s are those of the
     // NBW - 2 later weight stages plus the patch pieces issued with them; vmcnt completes in order.
     int wslot = 0;
@@ -774,7 +781,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
             // younger instructions still allowed in flight
             if (NBW == 3) {
                 const bool w1 = s + 1 < n_stage;            // weights of stage s + 1 were issued in stage s - 1
-                const bool pz = tap >= 1 && tap - 1 < 6 && more;   // ... after a patch piece
+                const bool pz = tap >= 1 && tap - 1 < PI && more;  // ... after a patch piece
                 if (w1 && pz) __builtin_amdgcn_s_waitcnt(((WI + 1) & 0xF) | 0x0F70);
                 else if (w1) __builtin_amdgcn_s_waitcnt((WI & 0xF) | 0x0F70);
                 else __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -782,7 +789,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);
             }
             __builtin_amdgcn_s_barrier();
-            if (tap < 6 && more) issue_patch(chunk + 1, tap);
+            if (tap < PI && more) issue_patch(chunk + 1, tap);
             {
                 const int s2 = s + NBW - 1;
                 if (s2 < n_stage) {
@@ -833,21 +840,24 @@ int conv_set_option(const char* key, int value) {
 
 static bool conv3x3_patch_ok(const ConvArgs& a) {
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.up != 1 || a.Ho != a.H || a.Wo != a.W) return false;
-    if (a.Cin % 64 || (a.C1 != a.Cin && a.C1 % 64) || (a.Cout % 128 && a.Cout != 64 && a.Cout != 32)) return false;
+    const int ck = a.Cin % 64 == 0 && (a.C1 == a.Cin || a.C1 % 64 == 0) ? 64 : 32;
+    if (a.Cin % ck || (a.C1 != a.Cin && a.C1 % ck) || (a.Cout % 128 && a.Cout != 64 && a.Cout != 32)) return false;
     const int tw = (a.W % 32 == 0) ? 32 : 16, th = 256 / tw;
     if (a.W % tw || a.H % th) return false;
     const int bn = a.Cout % 128 == 0 ? 128 : a.Cout;
     return (long)a.N * (a.H / th) * (a.W / tw) * (a.Cout / bn) >= g_patch_min_wgs;   // at least one workgroup per CU
 }
 
-template <int BN, int NBW, bool UNROLL_TAPS>
+template <int BN, int NBW, bool UNROLL_TAPS, int CK = 64>
 static void launch_patch_t(const ConvArgs& a, hipStream_t st) {
-    size_t lds = 2 * 48 * 1024 + (size_t)NBW * (BN >= 64 ? BN : 64) * 128;
+    constexpr int ROWB = CK * 2, RPI = 1024 / ROWB, PI = (344 + RPI * 8 - 1) / (RPI * 8);
+    constexpr int W_ROWS = (BN * ROWB >= 8 * 1024) ? BN : 8 * 1024 / ROWB;
+    size_t lds = 2 * (size_t)PI * 8 * 1024 + (size_t)NBW * W_ROWS * ROWB;
     const size_t out_tile = (size_t)256 * (BN + 8) * 2;
     if (out_tile > lds) lds = out_tile;
     const int tw = (a.W % 32 == 0) ? 32 : 16, th = 256 / tw;
     dim3 grid((unsigned)((long)a.N * (a.H / th) * (a.W / tw)), (unsigned)(a.Cout / BN));
-    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK>), grid, dim3(512), lds, st, a);
 }
 
 // ------------------------------------------------------------------------------------
@@ -903,6 +913,10 @@ hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
         if (bn == 128) launch_t<128, true, 32>(a, st);
         else if (bn == 64) launch_t<64, true, 32>(a, st);
         else launch_t<32, true, 32>(a, st);
+    } else if (!k64 && conv3x3_patch_ok(a)) {                // 32-channel chunks (the last decoder level and its gradients)
+        if (a.Cout == 64) launch_patch_t<64, 3, true, 32>(a, st);
+        else if (a.Cout == 32) launch_patch_t<32, 3, true, 32>(a, st);
+        else launch_patch_t<128, 3, true, 32>(a, st);
     } else if (k64 && conv3x3_patch_ok(a)) {
         const int tw = (a.W % 32 == 0) ? 32 : 16, th = 256 / tw;
         const long tiles = (long)a.N * (a.H / th) * (a.W / tw);
