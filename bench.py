@@ -56,7 +56,7 @@ def cpu_baseline():
     torch.set_num_threads(cores)
     sd = synth.synth_state_dict(golden_io.layout("vqreptunet1x1"), 77)
     ks = (0, 0, K_CODES, K_CODES, K_CODES)
-    CS, NB, REPS = SIZE, 2, 2                           # bounded sample: 2 full 512x512 images, 2 timed repeats after a warm-up
+    CS, NB, REPS = SIZE, 4, 3                           # bounded sample (~15 s): 4 full 512x512 images, 3 timed repeats after a warm-up
     x, gt = synth.uniform(1, (NB, 3, CS, CS)), synth.blob_labels(2, NB, CS, cell=32)
 
     def run_eval():

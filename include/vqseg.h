@@ -119,7 +119,7 @@ int vqseg_vq_backward_bf16(const void* grad_quant, const float* grad_loss, const
  * argmin of cdist) -> per-cluster counts -> per-cluster sums -> divide -> clusters with no
  * member keep their mean.  The sums are deterministic but not in scatter_add_'s single running order:
  * member lists are in row order, cut into segments of 128 members, four interleaved partial sums per
- * segment, segments added in order (fp32; agreement with the CPU order is at rounding level, asserted
+ * segment, a cluster's segments folded as four interleaved chains in fixed order (fp32; agreement with the CPU order is at rounding level, asserted
  * at 1e-5 in tests/test_vq_gpu.py).
  *
  *   samples [N, C] f32, means [K, C] f32 in/out, bins [K] i64 out (last iteration).

@@ -609,12 +609,17 @@ __global__ __launch_bounds__(256) void km_segsum_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void km_sums_kernel(const float* __restrict__ partial, int C, const int* __restrict__ segoff,
                                                       float* __restrict__ sums) {
+    // block = (cluster, 64-channel group); 4 thread rows stride the cluster's segments, folded in row order
+    __shared__ float sh[4][64];
     const int k = blockIdx.x;
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= C) return;
+    const int lane = threadIdx.x & 63, rowl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
     float s = 0.0f;
-    for (int g = segoff[k]; g < segoff[k + 1]; ++g) s += partial[(size_t)g * C + c];
-    sums[(size_t)k * C + c] = s;
+    if (c < C)
+        for (int g = segoff[k] + rowl; g < segoff[k + 1]; g += 4) s += partial[(size_t)g * C + c];
+    sh[rowl][lane] = s;
+    __syncthreads();
+    if (rowl == 0 && c < C) sums[(size_t)k * C + c] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
 }
 
 __global__ __launch_bounds__(256) void km_counts64_kernel(const int* __restrict__ counts, int K, long long* __restrict__ out) {
@@ -854,7 +859,7 @@ hipError_t launch_km_accumulate(const float* samples, const float* means, int64_
     hipLaunchKernelGGL(km_lists_kernel, dim3(p.row_blocks), dim3(64), (size_t)K * sizeof(int), st, idx64, (long)N, K, hist, members);
     hipLaunchKernelGGL(km_segsum_kernel, dim3(p.max_segments, (C + 63) / 64), dim3(256), 0, st, samples, C, K, offsets, segoff, members,
                        partial);
-    hipLaunchKernelGGL(km_sums_kernel, dim3(K, (C + 255) / 256), dim3(256), 0, st, partial, C, segoff, sums);
+    hipLaunchKernelGGL(km_sums_kernel, dim3(K, (C + 63) / 64), dim3(256), 0, st, partial, C, segoff, sums);
     hipLaunchKernelGGL(km_counts64_kernel, dim3((K + 255) / 256), dim3(256), 0, st, counts, K,
                        reinterpret_cast<long long*>(counts64));
     return hipGetLastError();
