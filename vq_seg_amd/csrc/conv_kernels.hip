@@ -778,15 +778,23 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
 #pragma unroll UNROLL_TAPS ? 9 : 1
         for (int tap = 0; tap < 9; ++tap) {
             const int s = chunk * 9 + tap;
-            // younger instructions still allowed in flight
-            if (NBW == 3) {
-                const bool w1 = s + 1 < n_stage;            // weights of stage s + 1 were issued in stage s - 1
-                const bool pz = tap >= 1 && tap - 1 < PI && more;  // ... after a patch piece
-                if (w1 && pz) __builtin_amdgcn_s_waitcnt(((WI + 1) & 0xF) | 0x0F70);
-                else if (w1) __builtin_amdgcn_s_waitcnt((WI & 0xF) | 0x0F70);
-                else __builtin_amdgcn_s_waitcnt(0x0F70);
-            } else {
-                __builtin_amdgcn_s_waitcnt(0x0F70);
+            // DMA instructions younger than the weights of stage s (issued in stages s-NBW+2 .. s-1: the weights of
+            // stages s+1 .. s+NBW-2 and the patch pieces that went with them) may still be in flight
+            int young = 0;
+#pragma unroll
+            for (int d = 1; d <= NBW - 2; ++d) {
+                if (s + d < n_stage) young += WI;
+                const int t = s - d;                                   // stage that issued them
+                if (t >= 0) {
+                    const int tt = t % 9, tc = t / 9;
+                    if (tt < PI && tc + 1 < n_chunks) young += 1;
+                }
+            }
+            switch (young) {
+#define VM_CASE(N_) case N_: __builtin_amdgcn_s_waitcnt(((N_) & 0xF) | 0x0F70); break;
+                VM_CASE(1) VM_CASE(2) VM_CASE(3) VM_CASE(4) VM_CASE(5) VM_CASE(6) VM_CASE(7) VM_CASE(8) VM_CASE(9) VM_CASE(10)
+#undef VM_CASE
+                default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
             }
             __builtin_amdgcn_s_barrier();
             if (tap < PI && more) issue_patch(chunk + 1, tap);
@@ -827,7 +835,7 @@ int conv_set_option(const char* key, int value) {
     }
     if (key && !strcmp(key, "conv3x3_patch_unroll")) {
         const int prev = g_patch_unroll;
-        g_patch_unroll = value ? 1 : 0;
+        g_patch_unroll = value;
         return prev;
     }
     if (key && !strcmp(key, "conv3x3_patch_wide_tile")) {
@@ -925,6 +933,8 @@ hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
         else if (a.Cout == 32) launch_patch_t<32, 3, true>(a, st);
         else if (a.Cout % 256 == 0 && g_patch_wide && tiles * (a.Cout / 256) >= g_patch_min_wgs)
             launch_patch_t<256, 2, false>(a, st);
+        else if (g_patch_unroll == 2)
+            launch_patch_t<128, 4, true>(a, st);
         else if (g_patch_unroll)
             launch_patch_t<128, 3, true>(a, st);
         else
