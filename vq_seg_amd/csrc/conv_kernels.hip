@@ -797,8 +797,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
                 default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
             }
             __builtin_amdgcn_s_barrier();
-            if (tap < PI && more) issue_patch(chunk + 1, tap);
-            {
+            auto issue_next = [&]() {
+                if (tap < PI && more) issue_patch(chunk + 1, tap);
                 const int s2 = s + NBW - 1;
                 if (s2 < n_stage) {
                     const int c2 = tap + NBW - 1 >= 9 ? chunk + 1 : chunk, t2 = tap + NBW - 1 >= 9 ? tap + NBW - 1 - 9 : tap + NBW - 1;
@@ -806,8 +806,12 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
                     if (ws2 >= NBW) ws2 -= NBW;
                     issue_weights(c2, t2, ws2);
                 }
-            }
+            };
+            // NBW == 4: the slot being refilled was last read a whole stage ago, so the DMA issue can follow this stage's
+            // MFMAs (which then start right behind the barrier) instead of preceding them
+            if (NBW < 4) issue_next();
             compute(chunk, (tap / 3) * PW + tap % 3, wslot);
+            if (NBW >= 4) issue_next();
             wslot = wslot == NBW - 1 ? 0 : wslot + 1;
         }
     }
