@@ -221,3 +221,25 @@ def test_kmeans_prototype_init_and_model_first_train_forward():
     (out[0].mean() + out[1].sum() + out[3]).backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     assert (out[2] < 100).all()                                   # k-means codes are in use
+
+
+def test_evaluation_loop_on_hip_model():
+    """evaluate.test_loop with the HIP model (eval-mode fused epilogues) == Measurement on that model's own logits."""
+    import numpy as np
+    from vq_seg_amd.evaluate import test_loop
+    from vq_seg_amd.measurement import Measurement
+    fx = golden_io.load("model_v1")
+    model = build(fx.meta["name"], fx.meta["margin"], fx.meta["scale"], fx.meta["model_seed"])
+    x, gt, _ = cases.model_inputs()
+    tgt = torch.nn.functional.interpolate(gt[:, None].float(), scale_factor=1.5, mode="nearest")[:, 0].long()
+    batches = [(x, tgt), (x.flip(0), tgt.flip(0))]
+    got = test_loop(model, batches, 3, device=dev())
+    meas = Measurement(3)
+    miou = 0.0
+    model.eval()
+    with torch.no_grad():
+        for img, t in batches:
+            pred = F.interpolate(model(img.to(dev()))[0].float(), t.shape[-2:], mode="bilinear").cpu().numpy()
+            miou += meas(pred, t.numpy())[1]
+    assert abs(got["test_miou"] - miou / 2) < 1e-9 and 0.0 <= got["test_acc"] <= 1.0
+    assert len(got["test_ious"]) == 3 and all(np.isfinite(got["test_ious"]))

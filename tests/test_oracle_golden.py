@@ -218,3 +218,38 @@ def test_plain_unet():
         ref = fx["grad/" + key]
         got = golden_io.probe(p[key].grad)
         assert (got - ref).abs().max().item() <= 2e-3 * (ref.abs().max().item() + 1e-12), key
+
+
+def test_evaluation_loop_matches_measurement_on_numpy():
+    """vq_seg_amd.evaluate.test_loop (device-side confusion counts) against Measurement.measure on the resized logits,
+    batch by batch, as the reference's test_detailviz.py:107-123 does."""
+    import numpy as np
+    import torch.nn.functional as F
+    from vq_seg_amd.evaluate import test_loop
+    from vq_seg_amd.measurement import Measurement
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.c = torch.nn.Conv2d(3, 3, 3, padding=1)
+
+        def forward(self, x):
+            return self.c(x), None, None, None
+
+    model = Tiny()
+    batches = [(synth.uniform(i, (2, 3, 24, 20), 0, 1), (synth.uniform(50 + i, (2, 31, 27), 0, 1) * 3).long().clamp_(0, 2)) for i in range(3)]
+    got = test_loop(model, batches, 3)
+    meas = Measurement(3)
+    acc = miou = prec = rec = f1 = 0.0
+    ious = np.zeros(3)
+    with torch.no_grad():
+        for img, tgt in batches:
+            pred = F.interpolate(model(img)[0], tgt.shape[-2:], mode="bilinear").numpy()
+            a, m, i, p, r, f = meas(pred, tgt.numpy())
+            acc, miou, prec, rec, f1, ious = acc + a, miou + m, prec + p, rec + r, f1 + f, ious + np.array(i)
+    n = len(batches)
+    assert abs(got["test_acc"] - acc / n) < 1e-12 and abs(got["test_miou"] - miou / n) < 1e-12
+    assert abs(got["test_precision"] - prec / n) < 1e-12 and abs(got["test_recall"] - rec / n) < 1e-12
+    assert abs(got["test_f1score"] - f1 / n) < 1e-12
+    assert np.allclose(got["test_ious"], np.round(ious / n, 5))
