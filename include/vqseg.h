@@ -260,6 +260,13 @@ int vqseg_dice_sums_backward_f(const float* logits, int64_t stride_b, int64_t st
                                const int64_t* target, int b, int c, int64_t hw, int64_t ignore_index,
                                const float* g_inter, const float* g_sets, float* g_logits, void* stream);
 
+/* Pseudo-label statistics in one pass over the logits (layout as for the Dice sums): per pixel the arg-max class (i64),
+ * the entropy -sum p log(p + 1e-10) and the top probability of softmax(logits); any output may be NULL.  Replaces
+ * softmax -> argmax / log / mul / sum / max of make_regularized_pseudo_label (deprecated/train_with_test_pt_pseudo_entropy_reg.py:30-39),
+ * score_mask (train_vqreptunet1x1v2.py:43-46) and the entropy map of VQRePTUnet1x1.forward (net.py:1199-1201). */
+int vqseg_softmax_stats_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px, int b, int c,
+                          int64_t hw, int64_t* label, float* entropy, float* top, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,3 +95,17 @@ def test_dice_loss_matches_tensor_ops(layout, weighted):
             nnf.dice_sums_supported = saved
     assert abs(res[0][0].item() - res[1][0].item()) < 2e-6
     assert rel(res[1][1], res[0][1]) < 2e-4
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_softmax_stats_matches_tensor_ops(layout):
+    """vqseg_softmax_stats_f: arg-max label, entropy and top probability of softmax(logits) in one pass."""
+    from vq_seg_amd import nnf
+    x = (synth.uniform(21, (3, 3, 37, 29), -6, 6)).to(dev())
+    if layout == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    label, ent, top = nnf.softmax_stats(x, want_top=True)
+    prob = torch.softmax(x, dim=1)
+    assert torch.equal(label, prob.argmax(dim=1))
+    assert rel(ent, -(prob * torch.log(prob + 1e-10)).sum(dim=1)) < 1e-5
+    assert rel(top, prob.max(dim=1)[0]) < 1e-6

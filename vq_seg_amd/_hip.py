@@ -71,6 +71,7 @@ SYMBOLS = {
                                           c_void_p, c_void_p, c_void_p]),
     "vqseg_dice_sums_backward_f": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p,
                                            c_void_p, c_void_p, c_void_p]),
+    "vqseg_softmax_stats_f": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqseg_im2col_f": (c_int, [c_int, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p]),
     "vqseg_reflect_fold_f": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vqseg_cast_f": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p]),

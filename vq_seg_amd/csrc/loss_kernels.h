@@ -33,6 +33,8 @@ struct DiceArgs {
     long HW;
     long long ignore_index;
 };
+// per pixel: argmax label, entropy -sum p log(p + 1e-10), top probability of softmax(logits)   (any output nullable)
+hipError_t launch_softmax_stats(const DiceArgs& a, long long* label, float* entropy, float* top, hipStream_t st);
 constexpr int DICE_PX_PER_BLOCK = 4096;
 long dice_blocks(long HW);
 hipError_t launch_dice_forward(const DiceArgs& a, double* partial, float* inter, float* sets, hipStream_t st);

@@ -396,6 +396,52 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const DiceArgs a, const f
 }
 }  // namespace
 
+namespace {
+// Pseudo-label statistics of the CPS trainers (deprecated/train_with_test_pt_pseudo_entropy_reg.py:30-39 softmax -> argmax,
+// entropy; train_vqreptunet1x1v2.py:43-46 softmax -> max) and of VQRePTUnet1x1.forward's entropy map (net.py:1199-1201)
+__global__ __launch_bounds__(256) void softmax_stats_kernel(const DiceArgs a, long long* __restrict__ label,
+                                                            float* __restrict__ entropy, float* __restrict__ top) {
+    const int b = blockIdx.y;
+    const long px = (long)blockIdx.x * 256 + threadIdx.x;
+    if (px >= a.HW) return;
+    float z[DMAXC], mx = -__builtin_inff();
+    int arg = 0;
+#pragma unroll
+    for (int c = 0; c < DMAXC; ++c)
+        if (c < a.C) {
+            z[c] = a.logits[(long)b * a.sb + c * a.sc + px * a.sp];
+            if (z[c] > mx) {                                    // first maximum, as torch.argmax
+                mx = z[c];
+                arg = c;
+            }
+        }
+    float sum = 0.0f, p[DMAXC];
+#pragma unroll
+    for (int c = 0; c < DMAXC; ++c)
+        if (c < a.C) {
+            p[c] = expf(z[c] - mx);
+            sum += p[c];
+        }
+    const float inv = 1.0f / sum;
+    float ent = 0.0f;
+#pragma unroll
+    for (int c = 0; c < DMAXC; ++c)
+        if (c < a.C) {
+            const float q = p[c] * inv;
+            ent -= q * logf(q + 1e-10f);
+        }
+    const long o = (long)b * a.HW + px;
+    if (label) label[o] = arg;
+    if (entropy) entropy[o] = ent;
+    if (top) top[o] = inv;                                      // exp(0) / sum: the probability of the arg-max class
+}
+}  // namespace
+
+hipError_t launch_softmax_stats(const DiceArgs& a, long long* label, float* entropy, float* top, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_stats_kernel, dim3((unsigned)((a.HW + 255) / 256), (unsigned)a.B), dim3(256), 0, st, a, label, entropy, top);
+    return hipGetLastError();
+}
+
 long dice_blocks(long HW) { return (HW + DICE_PX_PER_BLOCK - 1) / DICE_PX_PER_BLOCK; }
 
 hipError_t launch_dice_forward(const DiceArgs& a, double* partial, float* inter, float* sets, hipStream_t st) {

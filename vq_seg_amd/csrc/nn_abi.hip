@@ -297,4 +297,13 @@ int vqseg_dice_sums_backward_f(const float* logits, int64_t stride_b, int64_t st
     return e == hipSuccess ? 0 : hipfail(e, "dice_bwd_kernel");
 }
 
+int vqseg_softmax_stats_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px, int b, int c, int64_t hw,
+                          int64_t* label, float* entropy, float* top, void* stream) {
+    if (!logits || b <= 0 || hw <= 0 || c < 2 || c > 4) return bad("softmax_stats: bad argument (2..4 classes)");
+    vqseg::DiceArgs a;
+    a.logits = logits; a.sb = stride_b; a.sc = stride_c; a.sp = stride_px; a.target = nullptr; a.B = b; a.C = c; a.HW = hw; a.ignore_index = 0;
+    hipError_t e = vqseg::launch_softmax_stats(a, reinterpret_cast<long long*>(label), entropy, top, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "softmax_stats_kernel");
+}
+
 }  // extern "C"

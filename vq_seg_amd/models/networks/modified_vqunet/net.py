@@ -125,8 +125,11 @@ class VQRePTUnet1x1(_VQRePTUnet1x1Base):
         prototype_loss = None
         if self.training:
             with torch.no_grad():
-                prob = torch.softmax(output.float().permute(0, 2, 3, 1).reshape(-1, output.shape[1]), dim=1)
-                entropy = -torch.sum(prob * torch.log(prob + 1e-10), dim=1)
+                if nnf.softmax_stats_supported(output):
+                    entropy = nnf.softmax_stats(output, want_label=False)[1].reshape(-1)     # (b, h, w) order, one HIP pass
+                else:
+                    prob = torch.softmax(output.float().permute(0, 2, 3, 1).reshape(-1, output.shape[1]), dim=1)
+                    entropy = -torch.sum(prob * torch.log(prob + 1e-10), dim=1)
             prototype_loss = self.prototype_loss(decoder_out, gt, percent=percent, entropy=entropy)
         output = self.upsampling(output)
         if code_usage_loss:

@@ -583,3 +583,28 @@ def dice_sums(pred, target, ignore_index):
     """(inter, sets), each (B, C) float32: sum over pixels of softmax * onehot and of softmax + onehot (dice_loss.py:24-26)."""
     return _DiceSums.apply(pred, target, ignore_index)
 
+
+def softmax_stats(logits, want_label=True, want_entropy=True, want_top=False):
+    """(label (B, H, W) i64, entropy (B, H, W) f32, top-probability (B, H, W) f32) of softmax(logits, dim=1) in one HIP pass
+    (None for outputs not wanted).  No gradient flows (the callers detach / use them as masks and targets)."""
+    x = logits.detach()
+    if x.dtype != torch.float32:
+        x = x.float()
+    b, c, h, w = x.shape
+    sb, sc, sh, sw = x.stride()
+    if sh != w * sw:
+        x = x.contiguous()
+        sb, sc, sh, sw = x.stride()
+    dev = x.device
+    label = torch.empty((b, h, w), dtype=torch.int64, device=dev) if want_label else None
+    ent = torch.empty((b, h, w), dtype=torch.float32, device=dev) if want_entropy else None
+    top = torch.empty((b, h, w), dtype=torch.float32, device=dev) if want_top else None
+    with torch.cuda.device(dev):
+        _check(lib().vqseg_softmax_stats_f(x.data_ptr(), sb, sc, sw, b, c, h * w, _p(label), _p(ent), _p(top), _stream()),
+               "vqseg_softmax_stats_f")
+    return label, ent, top
+
+
+def softmax_stats_supported(logits) -> bool:
+    return logits.is_cuda and logits.dim() == 4 and 2 <= logits.shape[1] <= 4
+

@@ -21,6 +21,7 @@ from torch import nn
 from . import dist as vdist
 from .loss import make_loss
 from .measurement import confusion_matrix_device, miou_device
+from . import nnf
 from .models import init_weight
 from .models.networks import make_model
 from .utils.lr_schedulers import CosineAnnealingLR
@@ -158,9 +159,12 @@ class CPSConfig:
 def regularized_pseudo_label(raw: torch.Tensor, percent: float) -> torch.Tensor:
     """make_regularized_pseudo_label (deprecated/train_with_test_pt_pseudo_entropy_reg.py:30-39) with
     the percentile taken on the device (torch.quantile == np.percentile, linear interpolation)."""
-    prob = torch.softmax(raw.float(), dim=1)
-    label = torch.argmax(prob, dim=1)
-    entropy = -torch.sum(prob * torch.log(prob + 1e-10), dim=1)
+    if nnf.softmax_stats_supported(raw):
+        label, entropy, _ = nnf.softmax_stats(raw)          # one HIP pass (vqseg_softmax_stats_f)
+    else:
+        prob = torch.softmax(raw.float(), dim=1)
+        label = torch.argmax(prob, dim=1)
+        entropy = -torch.sum(prob * torch.log(prob + 1e-10), dim=1)
     flat = entropy.detach().flatten()
     if flat.numel() > (1 << 24):                      # torch.quantile's input limit: exact k-th value instead
         k = percent / 100.0 * (flat.numel() - 1)
@@ -174,7 +178,10 @@ def regularized_pseudo_label(raw: torch.Tensor, percent: float) -> torch.Tensor:
 
 def score_mask(pred: torch.Tensor, pseudo: torch.Tensor, th: float = 0.7) -> torch.Tensor:
     """train_vqreptunet1x1v2.py:43-46."""
-    top = torch.softmax(pred.float(), dim=1).max(dim=1)[0]
+    if nnf.softmax_stats_supported(pred):
+        top = nnf.softmax_stats(pred, want_label=False, want_entropy=False, want_top=True)[2]
+    else:
+        top = torch.softmax(pred.float(), dim=1).max(dim=1)[0]
     return torch.where(top > th, pseudo, torch.full_like(pseudo, 255))
 
 
