@@ -1,4 +1,4 @@
-"""Conditioning of the whole-model fixture: how far a tiny input perturbation moves logits and gradients on the CPU oracle.\n   usage: python tools/conditioning.py <size> <eps>"""
+"""Conditioning of the whole-model fixture: how far a tiny input perturbation moves logits and gradients on the CPU oracle.\n   usage: python tests/diagnostics/conditioning.py <size> <eps>"""
 import sys; sys.path.insert(0,'/root/repo')
 import torch
 from oracle import torch_ref as R

@@ -1,7 +1,7 @@
 """Debug: run the oracle's functional model with torch ops ON THE GPU and compare grads with golden."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import torch_ref as R
 from tests import cases, golden_io, synth
 dev = torch.device(sys.argv[1] if len(sys.argv) > 1 else "cuda:0")

@@ -90,7 +90,7 @@ def test_whole_model_matches_reference_golden(version):
     total.backward()
     named = dict(model.named_parameters())
     # Tolerance: a 1e-6 perturbation of the INPUT moves these gradients by up to 5e-3 of their scale on the CPU
-    # oracle itself (53 convs + train-mode BN over as few as 8 samples at the 2x2 levels; tools/conditioning.py), and
+    # oracle itself (53 convs + train-mode BN over as few as 8 samples at the 2x2 levels; tests/diagnostics/conditioning.py), and
     # a change of the last float bit of the BatchNorm statistics (a different but equally exact merge order) moves
     # them by 1e-2.  Cross-device agreement is therefore asserted at 5e-2 (L2) here; the per-operator gradient
     # checks in test_nn_gpu.py carry the tight bar (2e-4 of scale in fp32).
