@@ -183,7 +183,10 @@ def main():
         chk = torch.stack([p.detach().double().sum() for m in trainer.models for p in m.parameters()]).cpu()
         gathered = [torch.zeros_like(chk) for _ in range(world)]
         dist.all_gather(gathered, chk)
-        assert all(torch.equal(g, gathered[0]) for g in gathered), "ranks diverged"
+        if not all(torch.equal(g, gathered[0]) for g in gathered):
+            names = [f"model{i}.{k}" for i, m in enumerate(trainer.models) for k, _ in m.named_parameters()]
+            bad = [names[j] for j in range(len(names)) if any(g[j] != gathered[0][j] for g in gathered)]
+            raise AssertionError(f"ranks diverged in {len(bad)} of {len(names)} parameters, e.g. {bad[:6]} ... {bad[-3:]}")
         note(f"rank {rank}: parameter checksums identical on all {world} ranks")
 
     if rank == 0:

@@ -45,6 +45,7 @@ def _job(rank, world):
         buckets.zero()
         net(_inputs(rank)).square().sum().backward()
         launched_in_backward = list(buckets._launched)
+        assert all(c == 0 for c in buckets._pending), "every parameter must report exactly once (sink or hook, not both)"
         buckets.finish()
     return [p.grad.detach().cpu().clone() for p in net.parameters()], launched_in_backward
 

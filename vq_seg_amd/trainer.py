@@ -62,6 +62,7 @@ class GradBuckets:
         self._pending = list(self._sizes)
         self._launched = [False] * len(groups)
         self._handles = []
+        self._reported = set()
         for p in self.params:
             # the HIP weight-gradient kernels add straight into the bucket views (nnf grad sinks) and report here;
             # parameters whose gradient still comes from autograd (VQ-free torch ops) report through the hook
@@ -77,12 +78,18 @@ class GradBuckets:
         self._pending = list(self._sizes)
         self._launched = [False] * len(self.buckets)
         self._handles = []
+        self._reported = set()
 
     def _launch(self, bi):
         self._launched[bi] = True
         self._handles.append(dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, async_op=True))
 
     def _on_grad(self, p):
+        # A sunk parameter reports through its sink (last contribution) AND, later, through the post-accumulate hook
+        # (autograd runs AccumulateGrad for it with an undefined gradient): count every parameter once per step.
+        if id(p) in self._reported:
+            return
+        self._reported.add(id(p))
         bi = self.owner[id(p)]
         self._pending[bi] -= 1
         if self._pending[bi] == 0 and not self._launched[bi]:
