@@ -42,6 +42,10 @@ const char* vqseg_kernel_name(const char* entry_point);
 /* Dispatch tunables (tests use them to reach every kernel with small shapes).  Keys:
  *   "conv3x3_patch_min_workgroups"  minimum grid of the patch-reuse 3x3 kernel before the generic implicit-GEMM
  *                                   kernel is preferred (default 256 = one workgroup per CU)
+ *   "conv3x3_patch_unroll", "conv3x3_patch_wide_tile"   variants of that kernel (tap loop unrolled; 256-channel tile)
+ *   "conv_short_k_small_tile", "conv_short_k_single_buffer"   K loops of up to that many 64-channel stages take the
+ *                                   128x128 tile at 4 waves/SIMD, double- resp. single-buffered (defaults 1 and 8)
+ * The environment variable VQSEG_OPTS="key=value,..." applies options when the Python binding loads the library.
  * Returns the previous value, or VQSEG_EINVAL for an unknown key / negative value.  Not thread safe. */
 int vqseg_set_option(const char* key, int value);
 

@@ -459,3 +459,30 @@ def test_bottleneck_grad_link_is_exact(mode):
 
     a, b = run(True), run(False)
     assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+def test_short_k_dispatch_variants_agree():
+    """1x1 layers with a short K loop may take the single-buffered 128x128 tile (conv_short_k_single_buffer) or the 4-waves/SIMD
+    double-buffered one (conv_short_k_small_tile): same accumulation order, so the outputs must be bit-identical to the default."""
+    from vq_seg_amd import _hip
+    L = _hip.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    n, h, w = 2, 24, 20
+    for cin, cout in ((64, 256), (128, 512), (256, 128), (512, 256)):
+        x = synth.uniform(cin + cout, (n, h, w, cin), -1, 1).bfloat16().to(dev())
+        wt = (synth.uniform(cin, (cout, cin, 1, 1), -1, 1) * (2.0 / cin) ** 0.5).to(dev())
+        hi = torch.empty(L.vqseg_conv_packed_elems(cout, cin, 1, 1, 0), dtype=torch.int16, device=dev())
+        assert L.vqseg_conv_pack_weights_f32(wt.data_ptr(), cout, cin, 1, 1, 0, hi.data_ptr(), None, st) == 0
+        outs = []
+        for opts in ({}, {"conv_short_k_single_buffer": 8, "conv_short_k_small_tile": 0}, {"conv_short_k_small_tile": 8}):
+            prev = {k: L.vqseg_set_option(k.encode(), v) for k, v in opts.items()}
+            y = torch.full((n, h, w, cout), float("nan"), dtype=torch.bfloat16, device=dev())
+            rc = L.vqseg_conv2d_f(x.data_ptr(), None, cin, hi.data_ptr(), None, y.data_ptr(), None, n, h, w, cin, cout, 1, 1, 1, 0, 0, 1, h, w, 0, st)
+            for k, v in prev.items():
+                L.vqseg_set_option(k.encode(), v)
+            assert rc == 0, L.vqseg_last_error()
+            outs.append(y)
+        torch.cuda.synchronize()
+        ref = (x.float().reshape(-1, cin) @ wt.reshape(cout, cin).bfloat16().float().t()).reshape(n, h, w, cout)
+        assert rel(outs[0].float(), ref) < 2 ** -7
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -5,9 +5,6 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vq_seg_amd import _hip
 L = _hip.lib()
-for kv in filter(None, os.environ.get('VQSEG_OPTS', '').split(',')):
-    k_, v_ = kv.split('=')
-    assert L.vqseg_set_option(k_.encode(), int(v_)) >= 0, k_
 dev = torch.device("cuda:0")
 B = 32
 # name, cin, cout, hw_in, k, stride, pad

@@ -4,9 +4,6 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torch import nn
 from vq_seg_amd import nnf, _hip
-for kv in filter(None, os.environ.get('VQSEG_OPTS', '').split(',')):      # e.g. VQSEG_OPTS=conv3x3_patch_wide_tile=0
-    k, v = kv.split('=')
-    assert _hip.lib().vqseg_set_option(k.encode(), int(v)) >= 0, k
 
 def timeit(fn, iters=10, warm=2):
     for _ in range(warm): fn()

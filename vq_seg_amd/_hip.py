@@ -98,6 +98,10 @@ def lib() -> ctypes.CDLL:
             fn.restype, fn.argtypes = res, args
         if handle.vqseg_abi_version() != 1:
             raise HipLibraryError("libvqseg_hip.so ABI version mismatch")
+        for kv in filter(None, os.environ.get("VQSEG_OPTS", "").split(",")):     # dispatch tunables for A/B runs: "key=value,..."
+            key, _, val = kv.partition("=")
+            if handle.vqseg_set_option(key.strip().encode(), int(val)) < 0:
+                raise HipLibraryError(f"VQSEG_OPTS: unknown option {key!r}")
         _lib = handle
     return _lib
 

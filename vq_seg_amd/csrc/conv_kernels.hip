@@ -586,6 +586,17 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
         else if (stages >= 1 && NBUF >= 3) __builtin_amdgcn_s_waitcnt((G & 0xF) | ((G >> 4) << 14) | 0x0F70);
         else __builtin_amdgcn_s_waitcnt(0x0F70);
     };
+    if constexpr (NBUF == 1) {
+        // one stage buffer: no overlap inside the workgroup -- the point is its small footprint (several workgroups per
+        // CU cover each other's loads and epilogues), for layers whose whole K loop is a few stages
+        for (int s = 0; s < n_stage; ++s) {
+            stage(s, 0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();
+            compute(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i)
         if (i < n_stage) stage(i, i);
@@ -598,6 +609,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
         compute(slot_c);
         slot_c = slot_c == NBUF - 1 ? 0 : slot_c + 1;
         slot_i = slot_i == NBUF - 1 ? 0 : slot_i + 1;
+    }
     }
     __syncthreads();                                       // all MFMAs done: LDS is free for the output tile
     conv_epilogue<TBM, BN, false, MT, NTT, NT, NW * 64>(acc, p, smem, M, m0, co0, wm, wn, r, h, tid);
@@ -823,7 +835,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
 
 static int g_patch_min_wgs = 256;
 static int g_patch_wide = 0;                                // 1: take the 256-channel tile where it fills the chip (measured 3-5 % slower than the unrolled 128 tile)
-static int g_short_k_small = 2;                             // K loops of up to this many stages take the 128x128 tile at 4 waves/SIMD
+static int g_short_k_small = 1;                             // K loops of up to this many stages take the 128x128 tile at 4 waves/SIMD
+static int g_short_k_single = 8;                            // K loops of up to this many stages: single-buffered 128x128 tile, 4 workgroups/CU
 static int g_patch_unroll = 1;                              // 128-channel tile: tap loop unrolled
 
 int conv_set_option(const char* key, int value) {
@@ -835,6 +848,11 @@ int conv_set_option(const char* key, int value) {
     if (key && !strcmp(key, "conv_short_k_small_tile")) {
         const int prev = g_short_k_small;
         g_short_k_small = value;
+        return prev;
+    }
+    if (key && !strcmp(key, "conv_short_k_single_buffer")) {
+        const int prev = g_short_k_single;
+        g_short_k_single = value;
         return prev;
     }
     if (key && !strcmp(key, "conv3x3_patch_unroll")) {
@@ -950,7 +968,8 @@ hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
         const long t256 = ((M + 255) / 256) * ((a.Cout + 255) / 256), t256x128 = ((M + 255) / 256) * ((a.Cout + 127) / 128);
         (void)t256;
         const int n_stage = a.KH * a.KW * (a.Cin / 64);
-        if (n_stage <= g_short_k_small && bn == 128) launch_glds_t<128, 128, 4, 2, 4>(a, st);   // epilogue-bound: more, independent workgroups per CU
+        if (n_stage <= g_short_k_small && bn == 128) launch_glds_t<128, 128, 4, 2, 4>(a, st);
+        else if (n_stage <= g_short_k_single && bn == 128) launch_glds_t<128, 128, 4, 1, 4>(a, st);   // epilogue-bound: more, independent workgroups per CU
         else if (a.Cout % 128 == 0 && t256x128 >= 512) launch_glds_t<256, 128, 8, 3>(a, st);
         else if (bn == 128) launch_glds_t<128, 128, 4, 2>(a, st);
         else if (bn == 64) launch_glds_t<128, 64, 4, 3>(a, st);
