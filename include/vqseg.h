@@ -271,6 +271,14 @@ int vqseg_dice_sums_backward_f(const float* logits, int64_t stride_b, int64_t st
 int vqseg_softmax_stats_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px, int b, int c,
                           int64_t hw, int64_t* label, float* entropy, float* top, void* stream);
 
+/* Exact order statistics of n floats by radix select: out2[0] = the k-th smallest (0-based), out2[1] = the (k+1)-th
+ * (clamped to the last).  The two values bracket the virtual index of np.percentile in make_regularized_pseudo_label
+ * (deprecated/train_with_test_pt_pseudo_entropy_reg.py:35); the host interpolates.  Replaces the full device sort of
+ * torch.quantile (and its 2^24-element input limit).  0 <= k < n < 2^32. */
+size_t vqseg_order_stats_workspace_bytes(void);
+int vqseg_order_stats_f(const float* x, int64_t n, int64_t k, void* workspace, size_t workspace_bytes, float* out2,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

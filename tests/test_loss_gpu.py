@@ -109,3 +109,58 @@ def test_softmax_stats_matches_tensor_ops(layout):
     assert torch.equal(label, prob.argmax(dim=1))
     assert rel(ent, -(prob * torch.log(prob + 1e-10)).sum(dim=1)) < 1e-5
     assert rel(top, prob.max(dim=1)[0]) < 1e-6
+
+
+@pytest.mark.parametrize("n,percent", [(1, 80.0), (2, 50.0), (7, 100.0), (1001, 0.0), (4099, 83.7), (1 << 20, 80.0),
+                                       ((1 << 20) + 3, 99.99), (5_000_001, 92.5)])
+@pytest.mark.parametrize("kind", ["entropy", "ties", "signed"])
+def test_percentile_is_exact_radix_select(n, percent, kind):
+    """vqseg_order_stats_f: the two order statistics around np.percentile's virtual index are EXACT (equal to the sorted
+    array's entries, for clustered entropies, heavy ties, negative values and -0/+0), and the interpolated threshold masks
+    the same elements as np.percentile on the host (make_regularized_pseudo_label :35-38) except, at most, elements that
+    EQUAL one of the two statistics (rounding of the interpolation).  The numpy side is evaluated on the values widened to
+    double: on fp32 input numpy >= 2 also rounds the QUANTILE to fp32 (q / float32(100)), which moves the virtual index
+    by up to n * 2^-24 positions -- a property of the numpy version, not of the reference's algorithm."""
+    import numpy as np
+    from vq_seg_amd import _hip, nnf
+    g = torch.Generator().manual_seed(n + int(percent * 10))
+    if kind == "entropy":                               # softmax entropies of 3 classes: clustered near 0 and near log 3
+        p = torch.softmax(torch.randn(n, 3, generator=g) * 4, dim=1)
+        x = -(p * torch.log(p + 1e-10)).sum(1)
+    elif kind == "ties":
+        x = torch.randint(0, 5, (n,), generator=g).float() * 0.25
+    else:
+        x = torch.randn(n, generator=g)
+        x[::7] = 0.0
+        x[3::11] = -0.0
+    xs = np.sort(x.numpy())
+    virtual = percent / 100.0 * (n - 1)
+    k = min(int(virtual), n - 1)
+    xd = x.to(dev())
+    ws = torch.empty(_hip.lib().vqseg_order_stats_workspace_bytes(), dtype=torch.uint8, device=dev())
+    out = torch.empty(2, device=dev())
+    rc = _hip.lib().vqseg_order_stats_f(xd.data_ptr(), n, k, ws.data_ptr(), ws.numel(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    lo, hi = out.cpu().numpy()
+    assert lo == xs[k] and hi == xs[min(k + 1, n - 1)], (lo, hi, xs[k], xs[min(k + 1, n - 1)])
+    thresh = nnf.percentile(xd, percent)
+    ref = np.percentile(x.numpy().astype(np.float64), percent)
+    mask = (xd >= thresh).cpu().numpy()
+    ref_mask = x.numpy() >= ref
+    differ = mask != ref_mask
+    assert not (differ & (x.numpy() != lo) & (x.numpy() != hi)).any()
+    if kind == "entropy":
+        assert differ.sum() <= 2
+    assert abs(float(thresh) - float(ref)) <= 1e-6 * max(abs(float(ref)), 1e-3)          # fp32 lerp of exact neighbours
+
+
+def test_order_stats_rejects_bad_arguments():
+    from vq_seg_amd import _hip
+    L = _hip.lib()
+    x = torch.zeros(16, device=dev())
+    ws = torch.empty(L.vqseg_order_stats_workspace_bytes(), dtype=torch.uint8, device=dev())
+    out = torch.empty(2, device=dev())
+    assert L.vqseg_order_stats_f(x.data_ptr(), 16, 16, ws.data_ptr(), ws.numel(), out.data_ptr(), None) != 0      # k >= n
+    assert L.vqseg_order_stats_f(x.data_ptr(), 0, 0, ws.data_ptr(), ws.numel(), out.data_ptr(), None) != 0
+    assert L.vqseg_order_stats_f(x.data_ptr(), 16, 3, ws.data_ptr(), 8, out.data_ptr(), None) != 0                 # workspace
+    assert L.vqseg_order_stats_f(None, 16, 3, ws.data_ptr(), ws.numel(), out.data_ptr(), None) != 0

@@ -37,3 +37,28 @@ def test_two_streams_change_nothing(recipe, amp):
     # run to run; every gradient kernel is deterministic, so the updated parameters must agree bit for bit
     assert all(abs(u - v) <= 1e-6 * abs(u) for u, v in zip(la, lb)), (la, lb)
     assert torch.equal(ca, cb)
+
+
+def test_training_learns_the_synthetic_task():
+    """End to end: 80 CPS steps (v1 recipe, bf16 activations, two streams) on the synthetic crop/weed blobs must drive the
+    supervised loss down and the mean IoU of the labelled batch up -- every forward kernel, every backward kernel, the
+    bucketed gradients and the fused Adam step have to cooperate for that.  (CWFID itself cannot travel to the GPU box;
+    tools/learn_synthetic.py prints the whole curve.)"""
+    from vq_seg_amd.trainer import CPSConfig, CPSTrainer, SyntheticCropWeed
+    dev = torch.device("cuda:0")
+    model = {"name": "vqreptunet1x1", "params": {"encoder_name": "resnet50", "num_classes": 3, "depth": 5,
+                                                 "vq_cfg": {"num_embeddings": [0, 0, 64, 64, 64], "distance": "euclidean", "kmeans_init": True},
+                                                 "margin": 0.0, "scale": 1.0, "use_feature": False, "encoder_weights": None}}
+    torch.manual_seed(0)
+    tr = CPSTrainer(CPSConfig(model=model, recipe="v1", total_iters=200, amp_dtype=torch.bfloat16, learning_rate=1e-3), dev)
+    data = SyntheticCropWeed(128, 8, dev, seed=5)
+    first, last = [], []
+    for i in range(80):
+        (l_in, l_tg), ul_in = data.labelled(), data.unlabelled()
+        out = tr.step(l_in, l_tg, ul_in, epoch_frac=i / 80)
+        if i < 5 or i >= 75:
+            (first if i < 5 else last).append((out["sup_loss_1"].item(), out["miou"].item()))
+    sup0, miou0 = (sum(v) / len(v) for v in zip(*first))
+    sup1, miou1 = (sum(v) / len(v) for v in zip(*last))
+    assert sup1 < 0.8 * sup0, (sup0, sup1)
+    assert miou1 > miou0 + 0.2, (miou0, miou1)

@@ -35,6 +35,9 @@ struct DiceArgs {
 };
 // per pixel: argmax label, entropy -sum p log(p + 1e-10), top probability of softmax(logits)   (any output nullable)
 hipError_t launch_softmax_stats(const DiceArgs& a, long long* label, float* entropy, float* top, hipStream_t st);
+// out2[0], out2[1] = the k-th and (k+1)-th smallest (0-based; the second clamped to n-1) of x[0..n): exact radix select
+size_t order_stats_workspace_bytes();
+hipError_t launch_order_stats(const float* x, long n, long k, void* workspace, float* out2, hipStream_t st);
 constexpr int DICE_PX_PER_BLOCK = 4096;
 long dice_blocks(long HW);
 hipError_t launch_dice_forward(const DiceArgs& a, double* partial, float* inter, float* sets, hipStream_t st);

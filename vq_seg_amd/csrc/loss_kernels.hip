@@ -442,6 +442,161 @@ hipError_t launch_softmax_stats(const DiceArgs& a, long long* label, float* entr
     return hipGetLastError();
 }
 
+namespace {
+// ---- exact order statistics by radix select (the percentile of make_regularized_pseudo_label,
+// deprecated/train_with_test_pt_pseudo_entropy_reg.py:35: np.percentile needs the two order statistics around the virtual
+// index).  Three counting passes over the data (12 + 12 + 8 key bits); integer counts only, so the result does not depend
+// on the order the workgroups run in.  Two target ranks (k, k + 1) are narrowed together.
+constexpr int KTH_BINS = 4096;
+struct KthState {
+    unsigned prefix[2];
+    unsigned long long rank[2];
+};
+__device__ __forceinline__ unsigned order_key(float v) {        // unsigned order == float order (-0 < +0; NaNs at the ends)
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_value(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__device__ __forceinline__ void kth_count(unsigned* hist, bool hit, unsigned digit) {
+    // entropies cluster in a few exponent bins: when the whole wave hits one bin, one lane adds the population count
+    const unsigned long long m = __ballot(hit);
+    if (m == 0) return;
+    const int leader = __ffsll((long long)m) - 1;
+    const unsigned first = __shfl(digit, leader);
+    if (__ballot(hit && digit == first) == m) {
+        if ((int)__lane_id() == leader) atomicAdd(&hist[first], (unsigned)__popcll(m));
+    } else if (hit) {
+        atomicAdd(&hist[digit], 1u);
+    }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void kth_hist_kernel(const float* __restrict__ x, long n, const KthState* __restrict__ state,
+                                                       unsigned* __restrict__ hist) {
+    constexpr int SHIFT = PASS == 0 ? 20 : PASS == 1 ? 8 : 0;          // low end of this pass's digit
+    constexpr int BITS = PASS == 2 ? 8 : 12;
+    constexpr unsigned MASK = (1u << BITS) - 1;
+    __shared__ unsigned lh[2][KTH_BINS];
+    for (int i = threadIdx.x; i < 2 * KTH_BINS; i += 256) (&lh[0][0])[i] = 0;
+    unsigned p0 = 0, p1 = 0;
+    if (PASS > 0) { p0 = state->prefix[0]; p1 = state->prefix[1]; }
+    const bool two = PASS > 0 && p0 != p1;
+    __syncthreads();
+    const long n4 = n >> 2;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i <= n4; i += stride) {
+        float v[4] = {0, 0, 0, 0};
+        int cnt = 0;
+        if (i < n4) {
+            const float4 q = reinterpret_cast<const float4*>(x)[i];
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            cnt = 4;
+        } else if (i == n4) {                                                            // the ragged tail (n % 4 values)
+            cnt = (int)(n - n4 * 4);
+            for (int j = 0; j < cnt; ++j) v[j] = x[n4 * 4 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned key = order_key(v[j]);
+            const unsigned digit = (key >> SHIFT) & MASK;
+            const unsigned hi = PASS == 0 ? 0u : key >> (SHIFT + BITS);
+            kth_count(lh[0], j < cnt && hi == p0, digit);
+            if (two) kth_count(lh[1], j < cnt && hi == p1, digit);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * KTH_BINS; i += 256) {
+        const unsigned c = (&lh[0][0])[i];
+        if (c) atomicAdd(&hist[i], c);
+    }
+}
+
+// one workgroup: the bin holding each target rank becomes the next digit of its prefix; clears the histogram for the next pass
+template <int PASS>
+__global__ __launch_bounds__(256) void kth_scan_kernel(KthState* __restrict__ state, unsigned* __restrict__ hist, float* __restrict__ out) {
+    constexpr int BITS = PASS == 2 ? 8 : 12;
+    constexpr int NB = 1 << BITS, PER = KTH_BINS / 256;
+    __shared__ unsigned long long part[256];
+    __shared__ unsigned digit_s;
+    __shared__ unsigned long long before_s;
+    const int t = threadIdx.x;
+    const bool same = PASS == 0 || state->prefix[0] == state->prefix[1];
+    unsigned newp[2];
+    unsigned long long newr[2];
+    for (int w = 0; w < 2; ++w) {
+        const unsigned* h = hist + ((w == 1 && !same) ? KTH_BINS : 0);
+        const unsigned long long rank = state->rank[w];
+        unsigned c[PER];
+        unsigned long long s = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            c[j] = (t * PER + j < NB) ? h[t * PER + j] : 0u;
+            s += c[j];
+        }
+        part[t] = s;
+        __syncthreads();
+        if (t == 0) {
+            unsigned long long run = 0;
+            for (int i = 0; i < 256; ++i) {
+                const unsigned long long v = part[i];
+                part[i] = run;                                   // exclusive prefix
+                run += v;
+            }
+        }
+        __syncthreads();
+        unsigned long long run = part[t];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (rank >= run && rank < run + c[j]) {              // exactly one (thread, j) holds the rank (rank < n)
+                digit_s = (unsigned)(t * PER + j);
+                before_s = run;
+            }
+            run += c[j];
+        }
+        __syncthreads();
+        newp[w] = (PASS == 0 ? 0u : state->prefix[w] << BITS) | digit_s;
+        newr[w] = rank - before_s;
+        __syncthreads();
+    }
+    for (int i = t; i < 2 * KTH_BINS; i += 256) hist[i] = 0;
+    if (t == 0) {
+        for (int w = 0; w < 2; ++w) {
+            state->prefix[w] = newp[w];
+            state->rank[w] = newr[w];
+            if (PASS == 2) out[w] = key_value(newp[w]);
+        }
+    }
+}
+
+__global__ void kth_init_kernel(KthState* state, unsigned* hist, unsigned long long k0, unsigned long long k1) {
+    for (int i = threadIdx.x; i < 2 * KTH_BINS; i += blockDim.x) hist[i] = 0;
+    if (threadIdx.x == 0) {
+        state->prefix[0] = state->prefix[1] = 0;
+        state->rank[0] = k0;
+        state->rank[1] = k1;
+    }
+}
+}  // namespace
+
+size_t order_stats_workspace_bytes() { return 64 + sizeof(unsigned) * 2 * KTH_BINS; }
+
+hipError_t launch_order_stats(const float* x, long n, long k, void* workspace, float* out2, hipStream_t st) {
+    KthState* state = static_cast<KthState*>(workspace);
+    unsigned* hist = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + 64);
+    const long k1 = k + 1 < n ? k + 1 : n - 1;
+    long blocks = (n / 4 + 256 * 8 - 1) / (256 * 8);              // >= 8 float4 per thread
+    blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
+    hipLaunchKernelGGL(kth_init_kernel, dim3(1), dim3(256), 0, st, state, hist, (unsigned long long)k, (unsigned long long)k1);
+    hipLaunchKernelGGL(kth_hist_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, x, n, state, hist);
+    hipLaunchKernelGGL(kth_scan_kernel<0>, dim3(1), dim3(256), 0, st, state, hist, out2);
+    hipLaunchKernelGGL(kth_hist_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, n, state, hist);
+    hipLaunchKernelGGL(kth_scan_kernel<1>, dim3(1), dim3(256), 0, st, state, hist, out2);
+    hipLaunchKernelGGL(kth_hist_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, x, n, state, hist);
+    hipLaunchKernelGGL(kth_scan_kernel<2>, dim3(1), dim3(256), 0, st, state, hist, out2);
+    return hipGetLastError();
+}
+
 long dice_blocks(long HW) { return (HW + DICE_PX_PER_BLOCK - 1) / DICE_PX_PER_BLOCK; }
 
 hipError_t launch_dice_forward(const DiceArgs& a, double* partial, float* inter, float* sets, hipStream_t st) {

@@ -306,4 +306,15 @@ int vqseg_softmax_stats_f(const float* logits, int64_t stride_b, int64_t stride_
     return e == hipSuccess ? 0 : hipfail(e, "softmax_stats_kernel");
 }
 
+size_t vqseg_order_stats_workspace_bytes(void) { return vqseg::order_stats_workspace_bytes(); }
+
+int vqseg_order_stats_f(const float* x, int64_t n, int64_t k, void* workspace, size_t workspace_bytes, float* out2, void* stream) {
+    if (!x || !workspace || !out2) return bad("order_stats: null pointer");
+    if (n <= 0 || n >= (int64_t(1) << 32) || k < 0 || k >= n) return bad("order_stats: need 0 <= k < n < 2^32");
+    if (workspace_bytes < vqseg::order_stats_workspace_bytes()) return bad("order_stats: workspace too small");
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return bad("order_stats: x must be 16-byte aligned");
+    hipError_t e = vqseg::launch_order_stats(x, n, k, workspace, out2, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "kth_hist_kernel");
+}
+
 }  // extern "C"

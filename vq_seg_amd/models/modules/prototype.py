@@ -3,8 +3,8 @@
 Small (B*H/2*W/2 x 32) x (3 x 32) math kept as device-side PyTorch tensor ops; the
 k-means prototype initialisation reuses the HIP k-means of the VQ layer.  Differences from the
 reference, on purpose:
-  * v1 takes the entropy-percentile threshold with torch.quantile on the device instead of
-    numpy on the host (same linear-interpolation definition; removes a host sync, q11);
+  * v1 takes the entropy-percentile threshold on the device (nnf.percentile: exact radix select of the two
+    order statistics, np.percentile's linear interpolation) instead of numpy on the host (removes a host sync, q11);
   * v2 applies the margin out of place, so backward works in fp32 (the reference's in-place form
     raises, q10); forward values are identical.
 """
@@ -79,8 +79,7 @@ class ReliablePrototypeLoss(_PrototypeBase):
         if nnf.proto_loss_supported(x, self.num_classes):
             # HIP path: one fused pass forward, one backward (vqseg_proto_loss_*), bf16 or fp32 features as they are
             with torch.no_grad():
-                thresh = torch.quantile(entropy.detach().flatten().double(), percent / 100.0)   # == np.percentile (linear)
-                keep = torch.le(entropy, thresh.to(entropy.dtype))
+                keep = torch.le(entropy, nnf.percentile(entropy, percent))      # np.percentile by exact radix select
             return nnf.proto_loss(x, proto, _rows(gt), keep=keep, variant=1, scale=self.scale, margin=self.margin,
                                   easy_margin=self.easy_margin)
         x = x.float()

@@ -605,6 +605,26 @@ def softmax_stats(logits, want_label=True, want_entropy=True, want_top=False):
     return label, ent, top
 
 
+def percentile(values, percent: float):
+    """np.percentile(values, percent) (linear interpolation) as a 0-d device tensor, for any number of fp32 values below 2^32:
+    the two order statistics around the virtual index come from an exact radix select (vqseg_order_stats_f) instead of a
+    full sort, and the index is taken in double as numpy does (torch.quantile rounds it to fp32)."""
+    x = values.detach().reshape(-1)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.float().contiguous()
+    n = x.numel()
+    virtual = percent / 100.0 * (n - 1)
+    k = min(max(int(virtual), 0), n - 1)
+    ws = torch.empty(lib().vqseg_order_stats_workspace_bytes(), dtype=torch.uint8, device=x.device)
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().vqseg_order_stats_f(x.data_ptr(), n, k, ws.data_ptr(), ws.numel(), out.data_ptr(), _stream()), "vqseg_order_stats_f")
+    frac = virtual - k
+    if frac <= 0.0:
+        return out[0]
+    return torch.lerp(out[0], out[1], frac)
+
+
 def softmax_stats_supported(logits) -> bool:
     return logits.is_cuda and logits.dim() == 4 and 2 <= logits.shape[1] <= 4
 

@@ -63,6 +63,7 @@ class GradBuckets:
         self._launched = [False] * len(groups)
         self._handles = []
         self._reported = set()
+        self.producer_streams = []          # set by CPSTrainer: the side stream(s) the gradient kernels of these params run on
         for p in self.params:
             # the HIP weight-gradient kernels add straight into the bucket views (nnf grad sinks) and report here;
             # parameters whose gradient still comes from autograd (VQ-free torch ops) report through the hook
@@ -82,6 +83,14 @@ class GradBuckets:
 
     def _launch(self, bi):
         self._launched[bi] = True
+        # The collective orders itself after the CURRENT stream only.  The last gradient of a bucket may report from an
+        # autograd hook running on another stream than the one the HIP weight-gradient kernels wrote the rest of the bucket
+        # on, so order the current stream after everything those streams hold so far (all of this bucket's gradients).
+        if self.producer_streams and self.buckets[bi].is_cuda:
+            cur = torch.cuda.current_stream(self.buckets[bi].device)
+            for s in self.producer_streams:
+                if s != cur:
+                    cur.wait_stream(s)
         self._handles.append(dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, async_op=True))
 
     def _on_grad(self, p):
@@ -165,21 +174,17 @@ class CPSConfig:
 
 def regularized_pseudo_label(raw: torch.Tensor, percent: float) -> torch.Tensor:
     """make_regularized_pseudo_label (deprecated/train_with_test_pt_pseudo_entropy_reg.py:30-39) with
-    the percentile taken on the device (torch.quantile == np.percentile, linear interpolation)."""
+    the percentile taken on the device (np.percentile's linear interpolation between two order statistics)."""
     if nnf.softmax_stats_supported(raw):
         label, entropy, _ = nnf.softmax_stats(raw)          # one HIP pass (vqseg_softmax_stats_f)
     else:
         prob = torch.softmax(raw.float(), dim=1)
         label = torch.argmax(prob, dim=1)
         entropy = -torch.sum(prob * torch.log(prob + 1e-10), dim=1)
-    flat = entropy.detach().flatten()
-    if flat.numel() > (1 << 24):                      # torch.quantile's input limit: exact k-th value instead
-        k = percent / 100.0 * (flat.numel() - 1)
-        lo = torch.kthvalue(flat, int(k) + 1).values
-        hi = torch.kthvalue(flat, min(int(k) + 2, flat.numel())).values
-        thresh = lo + (hi - lo) * (k - int(k))
+    if entropy.is_cuda:
+        thresh = nnf.percentile(entropy, percent)         # exact radix select (vqseg_order_stats_f), no sort, no size limit
     else:
-        thresh = torch.quantile(flat, percent / 100.0)
+        thresh = torch.quantile(entropy.detach().flatten(), percent / 100.0)
     return torch.where(entropy >= thresh, torch.full_like(label, 255), label)
 
 
@@ -213,6 +218,8 @@ class CPSTrainer:
         import os as _os
         self._two_streams = device.type == "cuda" and cfg.two_streams and _os.environ.get("VQSEG_TWO_STREAMS", "1") == "1"
         self._streams = [torch.cuda.Stream(device) for _ in self.models] if self._two_streams else []
+        for b, s_ in zip(self.buckets, self._streams):
+            b.producer_streams = [s_]
         self._pending_sides = set()
         self.opts = [torch.optim.Adam(m.parameters(), lr=cfg.learning_rate, betas=(0.9, 0.999), fused=self.device.type == "cuda")
                      for m in self.models]
