@@ -142,6 +142,26 @@ int vqseg_kmeans_finalize_f32(const float* sums, const int64_t* counts, float* m
                               int channels, int n_codes, void* stream);
 
 
+/* ---------------------------------------------------------------------------------- *
+ * EXTENSION -- EMA codebook update (opt-in; BASELINE.json north_star names it, the reference does not have it:
+ * vq_img.py:72,83,140,151 accept and store `decay` / `eps` but the codebook is never written after the k-means init,
+ * SURVEY 0.1 / q6).  The rule is the published one of the module the reference descends from (vector-quantize-pytorch,
+ * EuclideanCodebook.forward: ema_inplace + laplace_smoothing); there is no reference output to pin it against, so its
+ * tests compare with a tensor-op restatement of that rule ("parity unpinned").
+ *   vqseg_vq_code_sums:      sums[k][c] = sum of the rows assigned to code k, counts[k] = how many -- from the idx a
+ *                            forward returned (no second distance pass); rows f32 or bf16; deterministic (the k-means
+ *                            member-list reduction).  workspace: vqseg_kmeans_workspace_bytes(n_rows, channels, n_codes).
+ *                            Data-parallel use: all-reduce sums and counts (RCCL) before the update.
+ *   vqseg_vq_ema_update_f32: cluster_size <- d cluster_size + (1-d) counts;  embed_avg <- d embed_avg + (1-d) sums;
+ *                            codebook <- embed_avg / ((cluster_size + eps) / (S + K eps) * S),  S = sum cluster_size.
+ *                            scratch: 1 float on the device.
+ * ---------------------------------------------------------------------------------- */
+int vqseg_vq_code_sums(int bf16, const void* x, const int64_t* idx, int64_t n_rows, int channels, int n_codes,
+                       float* sums, int64_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+int vqseg_vq_ema_update_f32(float* cluster_size, float* embed_avg, float* codebook, const float* sums,
+                            const int64_t* counts, int channels, int n_codes, float decay, float eps, float* scratch,
+                            void* stream);
+
 /* ================================================================================== *
  * Encoder / decoder blocks.  Tensors are NHWC rows; `precise` = 1: activations fp32, bf16x3
  * split MFMA (parity mode); 0: activations bf16 (fast mode).  `bf16` flags name the

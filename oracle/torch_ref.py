@@ -11,7 +11,8 @@ reference's own modules imported in the build container
 (`oracle/make_golden.py` -> `tests/golden/*.npz`, test: `tests/test_oracle_golden.py`).
 The one exception is the ResNet-50 body (`resnet_encoder`), whose arithmetic lives
 in torchvision 0.14.1 (absent here, un-vendored): that part is PARITY UNPINNED and
-follows the published torchvision Bottleneck (v1.5) semantics.
+follows the published torchvision Bottleneck (v1.5) semantics.  `vq_ema_update` restates
+an EXTENSION the reference does not have (opt-in EMA codebook update): PARITY UNPINNED too.
 
 Citations are into /root/reference (read-only), `file:line`.
 """
@@ -85,6 +86,23 @@ def kmeans_lloyd(samples: Tensor, means0: Tensor, iters: int) -> Tuple[Tensor, T
         fresh = sums / denom[:, None]                                        # :53
         means = torch.where(empty[:, None], means, fresh)                    # :58-61
     return means, bins
+
+
+def vq_ema_update(cluster_size: Tensor, embed_avg: Tensor, rows: Tensor, idx: Tensor, decay: float, eps: float):
+    """EXTENSION, PARITY UNPINNED: the reference has no EMA update (vq_img.py:72,83 store `decay` and never read it), so
+    there is nothing of the reference's to follow line by line.  This restates the published rule of the module the
+    reference's quantiser descends from (vector-quantize-pytorch, EuclideanCodebook.forward: one-hot counts and sums,
+    ema_inplace on both, laplace_smoothing of the counts) for the opt-in `ema_update=True` path.
+    Returns (new cluster_size, new embed_avg, new codebook)."""
+    k = cluster_size.shape[0]
+    onehot = F.one_hot(idx.reshape(-1), k).to(rows.dtype)
+    counts = onehot.sum(0)
+    sums = onehot.t() @ rows
+    cluster_size = cluster_size * decay + counts * (1 - decay)
+    embed_avg = embed_avg * decay + sums * (1 - decay)
+    total = cluster_size.sum()
+    smoothed = (cluster_size + eps) / (total + k * eps) * total
+    return cluster_size, embed_avg, embed_avg / smoothed[:, None]
 
 
 def vq_backward(x: Tensor, q_ste: Tensor, g_quant: Tensor, g_loss: Tensor, commitment_weight: float):

@@ -64,3 +64,39 @@ def test_sinks_and_buckets_average_over_ranks():
         for a, b in zip(grads, ref):
             assert ((a - b).abs().max() / (b.abs().max() + 1e-12)).item() < 1e-5
     assert all(torch.equal(a, b) for a, b in zip(out[0][0], out[1][0]))
+
+
+# ---- EXTENSION: EMA codebook update under data parallelism (per-code sums / counts all-reduced before the update) ----
+def _ema_inputs(rank, step):
+    return synth.relu_features(70 + 10 * step + rank, (2, 64, 12, 12)).cuda()
+
+
+def _ema_module():
+    from vq_seg_amd.vector_quantizer import VectorQuantizer
+    vq = VectorQuantizer(dim=64, num_embeddings=40, decay=0.9, eps=1e-5, ema_update=True).cuda()
+    W = synth.relu_features(10, (40, 64)).cuda()
+    with torch.no_grad():
+        vq.codebook.embedding.weight.copy_(W)
+        vq.codebook.embed_avg.copy_(W)
+        vq.codebook.cluster_size.fill_(1.0)
+    return vq.train()
+
+
+def _ema_job(rank, world):
+    torch.cuda.set_device(0)
+    vq = _ema_module()
+    for step in range(2):
+        vq(_ema_inputs(rank, step))
+    torch.cuda.synchronize()
+    return vq.codebook.embedding.weight.detach().cpu(), vq.codebook.cluster_size.cpu()
+
+
+def test_ema_codebook_stays_identical_across_ranks():
+    out = spawn(_ema_job)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    vq = _ema_module()                                       # one process on the union of the two ranks' batches
+    for step in range(2):
+        vq(torch.cat([_ema_inputs(0, step), _ema_inputs(1, step)], dim=0))
+    ref = vq.codebook.embedding.weight.detach().cpu()
+    assert ((out[0][0] - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    assert torch.allclose(out[0][1], vq.codebook.cluster_size.cpu(), rtol=1e-6)

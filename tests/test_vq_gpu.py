@@ -200,3 +200,109 @@ def test_bf16_rows_give_the_same_layer(shape):
     gx32 = _hip.vq_backward(g.float(), gl, rows.float(), cb[i32], 0.25)       # exact e = codebook[idx]
     gx16 = _hip.vq_backward_bf16(g, gl, rows, i16, cb, 0.25)
     assert torch.equal(gx16, gx32.bfloat16())
+
+
+def test_prepared_codebook_follows_kmeans_init_after_an_eval_forward():
+    """The CPS trainer's order: an EVAL forward first (pseudo labels; caches the kernel-side image of the N(0,1)
+    codebook), then the first TRAINING forward, whose k-means init rewrites the codebook -- the distances of that
+    forward must be taken against the new codebook, not the cached image of the old one."""
+    from vq_seg_amd import _hip
+    from vq_seg_amd.vector_quantizer import VectorQuantizer
+    torch.manual_seed(0)
+    vq = VectorQuantizer(dim=64, num_embeddings=48, kmeans_init=True).to(dev())
+    x = synth.relu_features(5, (2, 64, 16, 16)).to(dev())
+    vq.eval()
+    with torch.no_grad():
+        vq(x)
+    vq.train()
+    q, idx, loss, _ = vq(x)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, 64).contiguous()
+    W = vq.codebook.embedding.weight.detach()
+    assert torch.equal(idx.reshape(-1), _hip.vq_assign(rows, W))
+    vq.eval()
+    with torch.no_grad():
+        q2, idx2, _, _ = vq(x)
+    assert torch.equal(idx2, idx) and torch.equal(q2.permute(0, 2, 3, 1).reshape(-1, 64), W[idx.reshape(-1)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# EXTENSION: opt-in EMA codebook update (not in the reference; oracle.torch_ref.vq_ema_update restates the published rule)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,c,k", [(4096, 64, 96), (3001, 512, 512), (777, 2048, 33), (50, 8, 300)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_code_sums_match_one_hot_products(n, c, k, dtype):
+    from vq_seg_amd import _hip
+    rows = synth.relu_features(n + c, (n, c)).to(dev()).to(dtype)
+    idx = torch.randint(0, k, (n,), generator=torch.Generator().manual_seed(n)).to(dev())
+    if k > 8:
+        idx[idx == 3] = 4                                                    # an empty code
+    sums, counts = _hip.vq_code_sums(rows, idx, k)
+    assert torch.equal(counts, torch.bincount(idx, minlength=k))
+    ref = torch.zeros(k, c, dtype=torch.float64, device=dev()).index_add_(0, idx, rows.double())
+    close(sums, ref, rtol=1e-5, atol=1e-5)
+    assert k <= 8 or (sums[3] == 0).all()
+    again, _ = _hip.vq_code_sums(rows, idx, k)
+    assert torch.equal(again, sums)                                          # deterministic
+
+
+def test_ema_update_matches_published_rule():
+    from oracle import torch_ref
+    from vq_seg_amd import _hip
+    k, c, n = 96, 64, 5000
+    rows = synth.relu_features(1, (n, c))
+    idx = torch.randint(0, k - 5, (n,), generator=torch.Generator().manual_seed(2))   # the last 5 codes stay empty
+    cs = synth.uniform(3, (k,), 0.0, 50.0)
+    avg = synth.relu_features(4, (k, c)) * cs[:, None]
+    ref_cs, ref_avg, ref_cb = torch_ref.vq_ema_update(cs.double(), avg.double(), rows.double(), idx, 0.8, 1e-5)
+    d_cs, d_avg, cb = cs.to(dev()), avg.to(dev()), torch.zeros(k, c, device=dev())
+    sums, counts = _hip.vq_code_sums(rows.to(dev()), idx.to(dev()), k)
+    _hip.vq_ema_update(d_cs, d_avg, cb, sums, counts, 0.8, 1e-5)
+    close(d_cs, ref_cs, rtol=1e-6, atol=1e-6)
+    close(d_avg, ref_avg, rtol=1e-5, atol=1e-5)
+    close(cb, ref_cb, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_ema_module_updates_after_quantising_and_keeps_the_gradient(amp):
+    """ema_update=True: (1) forward quantises with the codebook as it was, THEN moves it; (2) backward still sees the
+    codebook that forward used (same input gradient as the frozen module); (3) eval forwards do not move it; (4) the
+    moving statistics are buffers (checkpointed) only when the extension is on; (5) off by default."""
+    from oracle import torch_ref
+    from vq_seg_amd.vector_quantizer import VectorQuantizer
+    W = synth.relu_features(10, (40, 64))
+    x = synth.relu_features(9, (2, 64, 12, 12)).to(dev())
+    g = synth.uniform(11, (2, 64, 12, 12), -1, 1).to(dev())
+
+    def run(ema):
+        vq = VectorQuantizer(dim=64, num_embeddings=40, decay=0.9, eps=1e-5, ema_update=ema).to(dev())
+        with torch.no_grad():
+            vq.codebook.embedding.weight.copy_(W)
+            if ema:
+                vq.codebook.embed_avg.copy_(W)
+                vq.codebook.cluster_size.fill_(1.0)
+        vq.train()
+        xr = (x.bfloat16() if amp else x).clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            q, idx, loss, _ = vq(xr)
+        ((q.float() * g).sum() + 0.5 * loss.sum()).backward()
+        return vq, q, idx, loss, xr.grad
+
+    frozen, q0, idx0, loss0, g0 = run(False)
+    assert "codebook.cluster_size" not in frozen.state_dict() and not frozen.codebook.ema_update
+    assert torch.equal(frozen.codebook.embedding.weight.detach().cpu(), W)
+    vq, q1, idx1, loss1, g1 = run(True)
+    assert torch.equal(idx1, idx0) and torch.equal(q1, q0) and torch.equal(loss1, loss0) and torch.equal(g1, g0)
+    assert {"codebook.cluster_size", "codebook.embed_avg"} <= set(vq.state_dict())
+    rows = (x.bfloat16().float() if amp else x).permute(0, 2, 3, 1).reshape(-1, 64).cpu()
+    ref_cs, ref_avg, ref_cb = torch_ref.vq_ema_update(torch.ones(40, dtype=torch.float64), W.double(), rows.double(),
+                                                      idx0.reshape(-1).cpu(), 0.9, 1e-5)
+    close(vq.codebook.cluster_size, ref_cs, rtol=1e-6, atol=1e-6)
+    close(vq.codebook.embedding.weight, ref_cb, rtol=1e-5, atol=1e-6)
+    w1 = vq.codebook.embedding.weight.detach().clone()
+    vq.eval()
+    with torch.no_grad():
+        q2, idx2, _, _ = vq(x)
+    assert torch.equal(vq.codebook.embedding.weight, w1)                     # eval: no update ...
+    rows_d = x.permute(0, 2, 3, 1).reshape(-1, 64).contiguous()
+    from vq_seg_amd import _hip
+    assert torch.equal(idx2.reshape(-1), _hip.vq_assign(rows_d, w1))         # ... and the NEW codebook is the one in use

@@ -42,6 +42,9 @@ SYMBOLS = {
     "vqseg_kmeans_accumulate_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                             c_size_t, c_void_p]),
     "vqseg_kmeans_finalize_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "vqseg_vq_code_sums": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vqseg_vq_ema_update_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p,
+                                        c_void_p]),
     "vqseg_conv_packed_elems": (c_size_t, [c_int] * 5),
     "vqseg_conv_pack_weights_f32": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
     "vqseg_conv_stat_slots": (c_int64, [c_int64, c_int]),
@@ -263,6 +266,42 @@ def kmeans_finalize(sums: torch.Tensor, counts: torch.Tensor, means: torch.Tenso
                                          _dev(means, torch.float32, "means"), c, k, _stream())
     _check(rc, "vqseg_kmeans_finalize_f32")
     return means
+
+
+def vq_code_sums(rows: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-code sums (K, C) f32 and counts (K,) i64 of rows (N, C) f32 / bf16 under the assignment idx (N,) i64."""
+    L = lib()
+    n, c = rows.shape
+    if rows.dtype not in (torch.float32, torch.bfloat16) or not rows.is_cuda or not rows.is_contiguous():
+        raise ValueError("vq_code_sums: rows must be contiguous f32 / bf16 on the GPU")
+    ip = _dev(idx, torch.int64, "idx")
+    if idx.numel() != n:
+        raise ValueError("vq_code_sums: one index per row")
+    sums = torch.empty(k, c, dtype=torch.float32, device=rows.device)
+    counts = torch.empty(k, dtype=torch.int64, device=rows.device)
+    nbytes = L.vqseg_kmeans_workspace_bytes(n, c, k)
+    ws = _workspace(nbytes, rows.device)
+    with torch.cuda.device(rows.device):
+        rc = L.vqseg_vq_code_sums(int(rows.dtype == torch.bfloat16), rows.data_ptr(), ip, n, c, k, sums.data_ptr(), counts.data_ptr(),
+                                  ws.data_ptr(), nbytes, _stream())
+    _check(rc, "vqseg_vq_code_sums")
+    return sums, counts
+
+
+def vq_ema_update(cluster_size: torch.Tensor, embed_avg: torch.Tensor, codebook: torch.Tensor, sums: torch.Tensor,
+                  counts: torch.Tensor, decay: float, eps: float) -> None:
+    """In place: moving counts / sums and the codebook they imply (include/vqseg.h: vqseg_vq_ema_update_f32)."""
+    L = lib()
+    k, c = codebook.shape
+    if cluster_size.shape != (k,) or embed_avg.shape != (k, c) or sums.shape != (k, c) or counts.shape != (k,):
+        raise ValueError("vq_ema_update: shapes must be (K,), (K, C), (K, C), (K, C), (K,)")
+    scratch = torch.empty(1, dtype=torch.float32, device=codebook.device)
+    with torch.cuda.device(codebook.device):
+        rc = L.vqseg_vq_ema_update_f32(_dev(cluster_size, torch.float32, "cluster_size"), _dev(embed_avg, torch.float32, "embed_avg"),
+                                       _dev(codebook, torch.float32, "codebook"), _dev(sums, torch.float32, "sums"),
+                                       _dev(counts, torch.int64, "counts"), c, k, float(decay), float(eps), scratch.data_ptr(),
+                                       _stream())
+    _check(rc, "vqseg_vq_ema_update_f32")
 
 
 def profile_begin(capacity: int = 4096) -> None:

@@ -49,6 +49,11 @@ hipError_t launch_backward_idx(const void* gq, const float* gloss, const void* x
                                int C, float cw, void* gx, hipStream_t st);
 hipError_t launch_km_accumulate(const float* samples, const float* means, int64_t N, int C, int K, const KmPlan& p,
                                 char* ws, float* sums, int64_t* counts64, hipStream_t st);
+// per-code sums / counts of rows already assigned (idx from a forward): the k-means accumulation without the distance pass
+hipError_t launch_code_sums(const void* x, int x_bf16, const int64_t* idx, int64_t N, int C, int K, const KmPlan& p, char* ws,
+                            float* sums, int64_t* counts64, hipStream_t st);
+hipError_t launch_ema_update(float* cluster_size, float* embed_avg, float* codebook, const float* sums, const int64_t* counts64,
+                             int K, int C, float decay, float eps, float* total, hipStream_t st);
 hipError_t launch_km_finalize(const float* sums, const int64_t* counts64, float* means, int C, int K, hipStream_t st);
 
 }  // namespace vqseg

@@ -581,7 +581,8 @@ __global__ __launch_bounds__(64) void km_lists_kernel(const long long* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void km_segsum_kernel(const float* __restrict__ samples, int C, int K,
+template <typename TS>
+__global__ __launch_bounds__(256) void km_segsum_kernel(const TS* __restrict__ samples, int C, int K,
                                                         const int* __restrict__ offsets, const int* __restrict__ segoff,
                                                         const int* __restrict__ members, float* __restrict__ partial) {
     const int seg = blockIdx.x;
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(256) void km_segsum_kernel(const float* __restrict_
     if (e > offsets[k + 1]) e = offsets[k + 1];
     float s = 0.0f;
     if (c < C)
-        for (int m = b + wave; m < e; m += 4) s += samples[(size_t)members[m] * C + c];
+        for (int m = b + wave; m < e; m += 4) s += (float)samples[(size_t)members[m] * C + c];
     __shared__ float sh[4][64];
     sh[wave][lane] = s;
     __syncthreads();
@@ -634,6 +635,43 @@ __global__ __launch_bounds__(256) void km_finalize_kernel(const float* __restric
     if (c >= C) return;
     const long long n = counts[k];
     if (n > 0) means[(size_t)k * C + c] = sums[(size_t)k * C + c] / (float)n;      // vq_img.py:53; :58-61 keep if empty
+}
+
+// ---- opt-in EMA codebook update (an EXTENSION: the reference keeps `decay`/`eps` but never updates the codebook).
+// The published rule the reference's module descends from (vector-quantize-pytorch EuclideanCodebook.forward):
+//   cluster_size <- d cluster_size + (1-d) counts;  embed_avg <- d embed_avg + (1-d) sums;
+//   codebook     <- embed_avg / ((cluster_size + eps) / (sum cluster_size + K eps) * sum cluster_size)
+__global__ __launch_bounds__(256) void ema_counts_kernel(float* __restrict__ cluster_size, const long long* __restrict__ counts, int K,
+                                                         float decay, float* __restrict__ total) {
+    // one workgroup: update the K moving counts and leave their sum (fixed tree order) in *total
+    __shared__ float sh[256];
+    float s = 0.0f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float v = __builtin_fmaf(cluster_size[k], decay, (1.0f - decay) * (float)counts[k]);
+        cluster_size[k] = v;
+        s += v;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = sh[0];
+}
+
+__global__ __launch_bounds__(256) void ema_embed_kernel(float* __restrict__ embed_avg, const float* __restrict__ sums,
+                                                        const float* __restrict__ cluster_size, const float* __restrict__ total,
+                                                        float* __restrict__ codebook, int K, int C, float decay, float eps) {
+    const int k = blockIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float n = *total;
+    const float smoothed = (cluster_size[k] + eps) / (n + (float)K * eps) * n;
+    const size_t o = (size_t)k * C + c;
+    const float avg = __builtin_fmaf(embed_avg[o], decay, (1.0f - decay) * sums[o]);
+    embed_avg[o] = avg;
+    codebook[o] = avg / smoothed;
 }
 
 // ------------------------------------------------------------------------------------
@@ -840,13 +878,9 @@ hipError_t launch_backward_idx(const void* gq, const float* gloss, const void* x
     return hipGetLastError();
 }
 
-hipError_t launch_km_accumulate(const float* samples, const float* means, int64_t N, int C, int K, const KmPlan& p,
-                                char* ws, float* sums, int64_t* counts64, hipStream_t st) {
-    hipError_t e = launch_prepare(means, K, C, ws + p.vq.off_prepared, st);
-    if (e != hipSuccess) return e;
-    int64_t* idx = reinterpret_cast<int64_t*>(ws + p.off_idx);
-    e = launch_assign(samples, 0, N, C, K, ws + p.vq.off_prepared, p.vq, ws, idx, nullptr, st);
-    if (e != hipSuccess) return e;
+template <typename TS>
+static hipError_t code_sums_from_idx(const TS* samples, const int64_t* idx, int64_t N, int C, int K, const KmPlan& p, char* ws,
+                                     float* sums, int64_t* counts64, hipStream_t st) {
     int* counts = reinterpret_cast<int*>(ws + p.off_counts);
     int* offsets = reinterpret_cast<int*>(ws + p.off_offsets);
     int* members = reinterpret_cast<int*>(ws + p.off_members);
@@ -857,11 +891,36 @@ hipError_t launch_km_accumulate(const float* samples, const float* means, int64_
     hipLaunchKernelGGL(km_hist_kernel, dim3(p.row_blocks), dim3(256), (size_t)K * sizeof(int), st, idx64, (long)N, K, hist);
     hipLaunchKernelGGL(km_scan_kernel, dim3(1), dim3(1024), 0, st, hist, p.row_blocks, K, counts, offsets, segoff);
     hipLaunchKernelGGL(km_lists_kernel, dim3(p.row_blocks), dim3(64), (size_t)K * sizeof(int), st, idx64, (long)N, K, hist, members);
-    hipLaunchKernelGGL(km_segsum_kernel, dim3(p.max_segments, (C + 63) / 64), dim3(256), 0, st, samples, C, K, offsets, segoff, members,
-                       partial);
+    hipLaunchKernelGGL(km_segsum_kernel<TS>, dim3(p.max_segments, (C + 63) / 64), dim3(256), 0, st, samples, C, K, offsets, segoff,
+                       members, partial);
     hipLaunchKernelGGL(km_sums_kernel, dim3(K, (C + 63) / 64), dim3(256), 0, st, partial, C, segoff, sums);
     hipLaunchKernelGGL(km_counts64_kernel, dim3((K + 255) / 256), dim3(256), 0, st, counts, K,
                        reinterpret_cast<long long*>(counts64));
+    return hipGetLastError();
+}
+
+hipError_t launch_km_accumulate(const float* samples, const float* means, int64_t N, int C, int K, const KmPlan& p,
+                                char* ws, float* sums, int64_t* counts64, hipStream_t st) {
+    hipError_t e = launch_prepare(means, K, C, ws + p.vq.off_prepared, st);
+    if (e != hipSuccess) return e;
+    int64_t* idx = reinterpret_cast<int64_t*>(ws + p.off_idx);
+    e = launch_assign(samples, 0, N, C, K, ws + p.vq.off_prepared, p.vq, ws, idx, nullptr, st);
+    if (e != hipSuccess) return e;
+    return code_sums_from_idx(samples, idx, N, C, K, p, ws, sums, counts64, st);
+}
+
+hipError_t launch_code_sums(const void* x, int x_bf16, const int64_t* idx, int64_t N, int C, int K, const KmPlan& p, char* ws,
+                            float* sums, int64_t* counts64, hipStream_t st) {
+    return x_bf16 ? code_sums_from_idx(static_cast<const __bf16*>(x), idx, N, C, K, p, ws, sums, counts64, st)
+                  : code_sums_from_idx(static_cast<const float*>(x), idx, N, C, K, p, ws, sums, counts64, st);
+}
+
+hipError_t launch_ema_update(float* cluster_size, float* embed_avg, float* codebook, const float* sums, const int64_t* counts64,
+                             int K, int C, float decay, float eps, float* total, hipStream_t st) {
+    hipLaunchKernelGGL(ema_counts_kernel, dim3(1), dim3(256), 0, st, cluster_size, reinterpret_cast<const long long*>(counts64), K,
+                       decay, total);
+    hipLaunchKernelGGL(ema_embed_kernel, dim3(K, (C + 255) / 256), dim3(256), 0, st, embed_avg, sums, cluster_size, total, codebook,
+                       K, C, decay, eps);
     return hipGetLastError();
 }
 

@@ -177,6 +177,30 @@ int vqseg_kmeans_accumulate_f32(const float* samples, const float* means, int64_
     return 0;
 }
 
+int vqseg_vq_code_sums(int bf16, const void* x, const int64_t* idx, int64_t n, int c, int k, float* sums, int64_t* counts, void* ws,
+                       size_t ws_bytes, void* stream) {
+    if (int rc = check_shape(n, c, k)) return rc;
+    if (!x || !idx || !sums || !counts || !ws) return fail(VQSEG_EINVAL, "null pointer argument");
+    if (!aligned16(ws)) return fail(VQSEG_EINVAL, "workspace must be 16-byte aligned");
+    const vqseg::KmPlan p = vqseg::km_plan(n, c, k);
+    if (ws_bytes < p.bytes) return fail(VQSEG_ENOSPC, "workspace %zu < %zu bytes", ws_bytes, p.bytes);
+    hipError_t e = vqseg::launch_code_sums(x, bf16 != 0, idx, n, c, k, p, static_cast<char*>(ws), sums, counts,
+                                           static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "code sums");
+    return 0;
+}
+
+int vqseg_vq_ema_update_f32(float* cluster_size, float* embed_avg, float* codebook, const float* sums, const int64_t* counts, int c,
+                            int k, float decay, float eps, float* scratch, void* stream) {
+    if (c <= 0 || k <= 0 || !cluster_size || !embed_avg || !codebook || !sums || !counts || !scratch)
+        return fail(VQSEG_EINVAL, "bad argument");
+    if (!(decay >= 0.0f && decay <= 1.0f) || !(eps >= 0.0f)) return fail(VQSEG_EINVAL, "need 0 <= decay <= 1, eps >= 0");
+    hipError_t e = vqseg::launch_ema_update(cluster_size, embed_avg, codebook, sums, counts, k, c, decay, eps, scratch,
+                                            static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "ema_embed_kernel");
+    return 0;
+}
+
 int vqseg_kmeans_finalize_f32(const float* sums, const int64_t* counts, float* means, int c, int k, void* stream) {
     if (c <= 0 || k <= 0 || !sums || !counts || !means) return fail(VQSEG_EINVAL, "bad argument");
     hipError_t e = vqseg::launch_km_finalize(sums, counts, means, c, k, static_cast<hipStream_t>(stream));

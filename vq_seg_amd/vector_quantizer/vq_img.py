@@ -7,6 +7,11 @@ the 4-tuple returned by forward (:228-244).  The arithmetic is NOT the reference
 sequence: distance + argmin + gather + straight-through + commitment + dead-code
 histogram run as fused kernels (vq_seg_amd/csrc/vq_kernels.hip), and backward is the
 analytic gradient instead of an autograd graph over cdist.
+
+Extension (opt-in, `ema_update=True`; default False = the reference's frozen codebook): the exponential-moving-average
+codebook update BASELINE.json's north_star names.  The reference stores `decay` / `eps` and never uses them (SURVEY 0.1);
+with the flag set they drive the published EMA rule (see include/vqseg.h, vqseg_vq_ema_update_f32) after every training
+forward, with the per-code sums / counts all-reduced over RCCL when torch.distributed runs more than one rank.
 """
 from __future__ import annotations
 
@@ -92,19 +97,24 @@ def kmeans(rows: torch.Tensor, num_clusters: int, num_iters: int, init_means: to
 
 
 class EuclideanCodebook(nn.Module):
-    def __init__(self, embedding_dim, num_embeddings, kmeans_init, kmeans_iters, decay, eps, num_codebook):
+    def __init__(self, embedding_dim, num_embeddings, kmeans_init, kmeans_iters, decay, eps, num_codebook, ema_update=False):
         super().__init__()
         self.kmeans_init = kmeans_init
         self.kmeans_iters = kmeans_iters
         self.initted = False
         self.num_codebook = num_codebook
-        self.decay = decay                                   # accepted, unused -- as in the reference
+        self.decay = decay                                   # unused unless ema_update -- as in the reference
+        self.eps = eps
+        self.ema_update = bool(ema_update)
         self.embedding = nn.Embedding(num_embeddings, embedding_dim)
         self.num_embeddings = num_embeddings
         self.embedding_dim = embedding_dim
         if not kmeans_init:
             self.embedding.weight.data.uniform_(-1 / num_embeddings, 1 / num_embeddings)   # vq_img.py:156-158
             self.initted = True
+        if self.ema_update:                                  # extension state; absent from state_dict() otherwise
+            self.register_buffer("cluster_size", torch.zeros(num_embeddings))
+            self.register_buffer("embed_avg", self.embedding.weight.detach().clone())
 
     def prepared(self) -> torch.Tensor:
         """Kernel-side image of the codebook (include/vqseg.h: vqseg_vq_prepare_f32), rebuilt only
@@ -120,9 +130,23 @@ class EuclideanCodebook(nn.Module):
     def _kmeans_init(self, rows: torch.Tensor):
         if self.initted:
             return
-        means, _ = kmeans(rows, self.num_embeddings, self.kmeans_iters)
-        self.embedding.weight.data.copy_(means)
+        means, bins = kmeans(rows, self.num_embeddings, self.kmeans_iters)
+        self.embedding.weight.copy_(means)                   # in place on the parameter itself: bumps its version counter,
+        self._prep_key = None                                # which (with this) retires the prepared image of the old codebook
+        if self.ema_update:
+            self.embed_avg.copy_(means)
+            self.cluster_size.copy_(bins.to(self.cluster_size.dtype))
         self.initted = True
+
+    @torch.no_grad()
+    def ema_step(self, rows: torch.Tensor, idx: torch.Tensor):
+        """Extension: one EMA update from the rows (N, C) of this forward and their code indices."""
+        sums, counts = _hip.vq_code_sums(rows, idx.reshape(-1), self.num_embeddings)
+        if _world_size() > 1:                                # every rank applies the same update to the same state
+            _all_reduce_sum(sums)
+            _all_reduce_sum(counts)
+        _hip.vq_ema_update(self.cluster_size, self.embed_avg, self.embedding.weight.detach(), sums, counts, self.decay, self.eps)
+        self._prep_key = None                                # the kernel wrote the weight behind autograd's back
 
     def forward(self, x: torch.Tensor):
         """x (B, HW, C) -> quantized (B, HW, C), embed_idx (B, HW), code_usage (dead-code %)."""
@@ -137,7 +161,7 @@ class EuclideanCodebook(nn.Module):
 
 class VectorQuantizer(nn.Module):
     def __init__(self, dim, num_embeddings, embedding_dim=None, decay=0.8, eps=1e-5, kmeans_init=False,
-                 kmeans_iters=10, distance="euclidean", commitment_weight=1, num_codebook=1):
+                 kmeans_iters=10, distance="euclidean", commitment_weight=1, num_codebook=1, ema_update=False):
         super().__init__()
         embedding_dim = embedding_dim if embedding_dim is not None else dim
         self.num_embeddings = num_embeddings
@@ -149,7 +173,7 @@ class VectorQuantizer(nn.Module):
                 "cosine codebook is unused by the target configs)")
         self.codebook = EuclideanCodebook(embedding_dim=embedding_dim, num_embeddings=num_embeddings,
                                           kmeans_init=kmeans_init, kmeans_iters=kmeans_iters, decay=decay, eps=eps,
-                                          num_codebook=num_codebook)
+                                          num_codebook=num_codebook, ema_update=ema_update)
 
     def forward(self, x: torch.Tensor):
         """x (B, C, H, W) -> (quantize (B, C, H, W) f32 -- bf16 for bf16 input --, embed_index (B, H, W) i64, loss (1,), code_usage ())."""
@@ -158,7 +182,12 @@ class VectorQuantizer(nn.Module):
         cb = self.codebook
         if cb.kmeans_init and self.training and not cb.initted:
             cb._kmeans_init(rows.detach().float())                           # vq_img.py:165-166
-        quant, idx, loss, dead = _VQFunction.apply(rows, cb.embedding.weight.detach(), self.training,
-                                                   float(self.commitment_weight), cb.prepared())
+        ema = cb.ema_update and self.training
+        weight = cb.embedding.weight.detach()
+        if ema:
+            weight = weight.clone()                          # backward re-reads the codebook THIS forward quantised with
+        quant, idx, loss, dead = _VQFunction.apply(rows, weight, self.training, float(self.commitment_weight), cb.prepared())
+        if ema:
+            cb.ema_step(rows.detach(), idx)
         quantize = quant.reshape(b, h, w, c).permute(0, 3, 1, 2)             # vq_img.py:242 (channels_last view)
         return quantize, idx.reshape(b, h, w), loss, dead
