@@ -431,18 +431,27 @@ def test_grad_sink_accumulates_in_place():
         assert rel(b_.grad - 0.5, a_.grad) < 1e-5
 
 
+@pytest.mark.parametrize("shortcut", ["identity", "projection", "projection_stride2"])
 @pytest.mark.parametrize("mode", ["precise", "fast"])
-def test_bottleneck_grad_link_is_exact(mode):
-    """Identity-shortcut bottleneck: folding the shortcut's gradient into conv1's data-gradient epilogue (nnf.GradLink)
+def test_bottleneck_grad_link_is_exact(mode, shortcut):
+    """Bottleneck: folding the shortcut branch's gradient of the block input into conv1's data-gradient epilogue
+    (nnf.GradLink; identity shortcut: the block's output gradient, projection shortcut: the projection's data gradient)
     must give bit-identical gradients to autograd's separate add (same roundings in the same order)."""
+    from torch import nn
     from vq_seg_amd import nnf
     from vq_seg_amd.models.encoders.resnet import Bottleneck
     torch.manual_seed(1)
-    blk = Bottleneck(256, 64).to(dev())
+    if shortcut == "identity":
+        blk, cin, so = Bottleneck(256, 64), 256, 16
+    else:
+        stride = 2 if shortcut.endswith("2") else 1
+        blk = Bottleneck(128, 64, stride, nn.Sequential(nn.Conv2d(128, 256, 1, stride, bias=False), nn.BatchNorm2d(256)))
+        cin, so = 128, 16 // stride
+    blk = blk.to(dev())
     blk.train()
     dt = torch.float32 if mode == "precise" else torch.bfloat16
-    x0 = cl(synth.uniform(3, (2, 256, 16, 16), -1, 1)).to(dt)
-    g = cl(synth.uniform(4, (2, 256, 16, 16), -1, 1)).to(dt)
+    x0 = cl(synth.uniform(3, (2, cin, 16, 16), -1, 1)).to(dt)
+    g = cl(synth.uniform(4, (2, 256, so, so), -1, 1)).to(dt)
 
     def run(use_link):
         saved = nnf.GradLink
@@ -459,6 +468,31 @@ def test_bottleneck_grad_link_is_exact(mode):
 
     a, b = run(True), run(False)
     assert all(torch.equal(u, v) for u, v in zip(a, b))
+    if shortcut != "identity":                                    # the fused path was really taken: no producer came late
+        x = x0.clone().requires_grad_(True)
+        seen = []
+        saved = nnf.GradLink
+
+        class Spy(saved):
+            def __init__(self):
+                self.sets = 0
+                super().__init__()
+                seen.append(self)
+
+            @property
+            def g(self):
+                return self._g
+
+            @g.setter
+            def g(self, v):
+                self._g = v
+                self.sets += v is not None
+        nnf.GradLink = Spy
+        try:
+            blk(x).backward(g)
+        finally:
+            nnf.GradLink = saved
+        assert len(seen) == 1 and seen[0].closed and seen[0].g is None and seen[0].sets == 1
 
 
 def test_short_k_dispatch_variants_agree():

@@ -105,10 +105,16 @@ def lib() -> ctypes.CDLL:
             raise HipLibraryError("libvqseg_hip.so ABI version mismatch")
         for kv in filter(None, os.environ.get("VQSEG_OPTS", "").split(",")):     # dispatch tunables for A/B runs: "key=value,..."
             key, _, val = kv.partition("=")
+            if key.strip().startswith("py_"):                # host-side switches (A/B runs of the Python layer): PY_OPTS
+                PY_OPTS[key.strip()] = int(val)
+                continue
             if handle.vqseg_set_option(key.strip().encode(), int(val)) < 0:
                 raise HipLibraryError(f"VQSEG_OPTS: unknown option {key!r}")
         _lib = handle
     return _lib
+
+
+PY_OPTS: dict = {}
 
 
 def _check(rc: int, what: str) -> None:

@@ -53,15 +53,16 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        idt = x
-        link = None
-        if self.downsample is not None:
-            idt = nnf.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
-        elif torch.is_grad_enabled() and x.requires_grad:
-            link = nnf.GradLink()              # identity shortcut: conv1's data gradient absorbs the shortcut's gradient
+        # conv1's data gradient absorbs the shortcut branch's gradient of x in its epilogue (nnf.GradLink)
+        link = nnf.GradLink() if (torch.is_grad_enabled() and x.requires_grad) else None
         y = nnf.conv_bn_act(x, self.conv1, self.bn1, link_in=link)
         y = nnf.conv_bn_act(y, self.conv2, self.bn2)
-        return nnf.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=idt, link_out=link)
+        if self.downsample is None:
+            return nnf.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=x, link_out=link)
+        # the projection runs AFTER conv2 so that its backward comes before conv1's (autograd runs later nodes first)
+        idt = nnf.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False,
+                              link_x=link if nnf.py_opt("py_link_projection", 1) else None)
+        return nnf.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=idt)
 
 
 resnet_encoders = {

@@ -96,15 +96,25 @@ def _out_size(h, k, s, p):
 # (`accumulate` flag of the C entry points) and autograd gets None for that parameter -- one tiny add kernel per
 # parameter and backward pass less.  The callback (if any) is told, as a post-accumulate-grad hook would be.
 # ------------------------------------------------------------------------------------------------
+def py_opt(key: str, default: int) -> int:
+    """host-side A/B switch from VQSEG_OPTS ("py_<name>=<int>", see _hip.lib)"""
+    lib()
+    return _hip.PY_OPTS.get(key, default)
+
+
 class GradLink:
     """Carries the gradient of a block's identity branch from the backward of its LAST conv (`link_out`: where the
     residual add happened) to the backward of its FIRST conv (`link_in`), whose data-gradient kernel adds it in its
     epilogue -- instead of autograd materialising both gradients of the block input and adding them in a separate
-    pass.  Valid when both convolutions read the same tensor (identity shortcut)."""
-    __slots__ = ("g",)
+    pass.  Valid when both convolutions read the same tensor (identity shortcut).
+    Projection shortcut: the shortcut's convolution sends the gradient of ITS input (`link_x`) the same way.  Its backward
+    has no dependency on the first conv's, so the order is the autograd engine's choice: a producer that arrives after the
+    consumer has run (`closed`) simply returns its gradient to autograd."""
+    __slots__ = ("g", "closed")
 
     def __init__(self):
         self.g = None
+        self.closed = False
 
 
 _UNIT_AFFINE = {}
@@ -146,7 +156,7 @@ def _sink_done(p) -> None:
 class _ConvBNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x2, residual, weight, gamma, beta, bn, stride, pad, reflect, relu, patches_of, fuse_eval=False,
-                link_in=None, link_out=None):
+                link_in=None, link_out=None, link_x=None):
         """x (N,C1,H,W) [+ x2 (N,C2,H,W)] -> out (N,Cout,Ho,Wo).  `patches_of` = (kh, kw, cin, stride, pad, reflect,
         H, W) when x is an im2col patch matrix of the stem (then the convolution itself is 1x1)."""
         xr = _rows(x)
@@ -203,7 +213,7 @@ class _ConvBNAct(torch.autograd.Function):
                                       out.data_ptr(), _stream()), "vqseg_bn_apply_f")
         ctx.save_for_backward(xr, x2r, y, out, coef, weight, gamma)
         ctx.params = (weight, gamma, beta)                                  # the Parameter objects (see grad sinks)
-        ctx.links = (link_in, link_out)
+        ctx.links = (link_in, link_out, link_x)
         ctx.cfg = (stride, pad, bool(reflect), bool(relu), training, residual is not None, patches_of, (n, h, w, c1, cin, cout,
                                                                                                          kh, kw, ho, wo))
         return _nchw(out)
@@ -237,7 +247,7 @@ class _ConvBNAct(torch.autograd.Function):
                                          _stream()), "vqseg_bn_backward_f")
         if sink_bn:
             _sink_done(p_g), _sink_done(p_b)
-        link_in, link_out = ctx.links
+        link_in, link_out, link_x = ctx.links
         if link_out is not None and has_res:
             link_out.g = g_res                                              # picked up by the block's first conv (GradLink)
         # ---- weight gradient
@@ -271,6 +281,7 @@ class _ConvBNAct(torch.autograd.Function):
             extra = link_in.g if link_in is not None else None          # residual-branch gradient of the same block input
             if link_in is not None:
                 link_in.g = None
+                link_in.closed = True
 
             def dgrad(c_lo, c_cnt):
                 nonlocal extra
@@ -301,12 +312,15 @@ class _ConvBNAct(torch.autograd.Function):
                 if extra is not None:                                       # link not fusable here: plain add
                     g1 = g1 + extra
                     extra = None
-                gx = _nchw(g1)
+                if link_x is not None and not link_x.closed and x2r is None:
+                    link_x.g = g1                                           # the block's first conv adds it (GradLink)
+                else:
+                    gx = _nchw(g1)
             if need2 and x2r is not None:
                 gx2 = _nchw(dgrad(c1, cin - c1))
         g_res_out = _nchw(g_res) if (has_res and link_out is None) else None
         return (gx, gx2, g_res_out, None if sink_w else gw, None if sink_bn else dgb[0],
-                None if sink_bn else dgb[1], None, None, None, None, None, None, None, None, None)
+                None if sink_bn else dgb[1], None, None, None, None, None, None, None, None, None, None)
 
 
 def _stem_weights(weight, precise, kp):
@@ -327,7 +341,7 @@ def _stem_weights(weight, precise, kp):
     return cache[k]
 
 
-def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None, link_in=None, link_out=None):
+def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None, link_in=None, link_out=None, link_x=None):
     """Conv2d (no bias; zero or reflect padding) -> BatchNorm2d -> [+ residual] -> [ReLU] on the HIP kernels.
     `x2`: second input whose channels follow x's (the decoder's concat).  `training` is ignored: the
     BatchNorm module's own mode decides (nn.BatchNorm2d semantics)."""
@@ -339,7 +353,7 @@ def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None, l
     _sink_use(conv.weight, bn.weight, bn.bias)
     return _ConvBNAct.apply(x, x2, residual, conv.weight, bn.weight, bn.bias, bn, conv.stride[0], pad,
                             conv.padding_mode == "reflect" and pad > 0, relu, None, not bn.training and not torch.is_grad_enabled(),
-                            link_in, link_out)
+                            link_in, link_out, link_x)
 
 
 def stem_conv_bn_act(x, conv, bn):
