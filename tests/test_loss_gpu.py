@@ -66,6 +66,35 @@ def test_proto_loss_matches_tensor_ops(variant, margin, scale, easy, dtype):
             assert ge_ref is None and ge_hip is None
 
 
+@pytest.mark.parametrize("c", [32, 64, 8])
+def test_proto_v2_prototype_gradient_over_many_row_tiles(c):
+    """More than 2048 x 256 rows: a workgroup of the backward kernel walks several 256-row tiles and folds its share of
+    the (K x C) prototype gradient once (row tiles in LDS, fixed order); also the widest (64) and narrowest (8) rows."""
+    from vq_seg_amd.models.modules.prototype import ReliablePrototypeLossv2
+    b, h, w, k = 5, 384, 384, 3                               # 737280 rows -> 2 row tiles per workgroup, a ragged tail
+    mod = ReliablePrototypeLossv2(k, c, scale=4.0, margin=0.3, init="normal").to(dev())
+    with torch.no_grad():
+        mod.embedding.weight.copy_(synth.uniform(3, (k, c), -1, 1))
+    mod.train()
+    x = (synth.uniform(4, (b, c, h, w), -1, 1) * 2).to(dev()).contiguous(memory_format=torch.channels_last).bfloat16()
+    x = x[:, :, :, :383] if c == 8 else x                     # 5 * 384 * 383 rows: not a multiple of 256
+    x = x.contiguous(memory_format=torch.channels_last)
+    gt = (synth.uniform(5, (b, h, x.shape[-1]), 0, 1) * k).long().clamp_(0, k - 1).to(dev())
+    w0 = mod.embedding.weight.detach().clone()
+
+    def run(fused):
+        with torch.no_grad():                                 # forward re-normalises the prototypes in place (prototype.py:844)
+            mod.embedding.weight.copy_(w0)
+        return _run(mod, x, (gt, 0.7), fused=fused)
+
+    l_ref, gx_ref, ge_ref = run(False)
+    l_hip, gx_hip, ge_hip = run(True)
+    assert abs(l_hip.item() - l_ref.item()) <= 2e-6 * max(1.0, abs(l_ref.item()))
+    assert rel(gx_hip, gx_ref) < 1e-2 and rel(ge_hip, ge_ref) < 1e-4
+    again = run(True)
+    assert torch.equal(again[2], ge_hip) and torch.equal(again[1], gx_hip)          # deterministic
+
+
 @pytest.mark.parametrize("layout", ["nchw", "nhwc", "cat"])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_dice_loss_matches_tensor_ops(layout, weighted):

@@ -14,7 +14,7 @@ from typing import Optional, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvqseg_hip.so")
+LIB_PATH = os.environ.get("VQSEG_LIB") or os.path.join(_HERE, "libvqseg_hip.so")     # VQSEG_LIB: another build of the same ABI (kernel A/B runs)
 
 # name -> (restype, argtypes); must list every symbol include/vqseg.h declares
 SYMBOLS = {

@@ -172,15 +172,21 @@ __global__ __launch_bounds__(256) void proto_loss_final_kernel(const double* __r
 
 template <typename T>
 __global__ __launch_bounds__(256) void proto_bwd_kernel(const ProtoArgs a, const float* __restrict__ g_loss, T* __restrict__ gx,
-                                                        float* __restrict__ gproto_partial) {
+                                                        float* __restrict__ gproto_partial, int row_tiles) {
     __shared__ float ps[MAXK * MAXC];
-    __shared__ float gp[MAXK * MAXC];
-    for (int i = threadIdx.x; i < a.K * a.C; i += 256) {
-        ps[i] = a.proto[i];
-        gp[i] = 0.0f;
-    }
+    extern __shared__ float tile[];                         // prototype gradient only: rs[256][C + 1], gcs[256][MAXK], part[256]
+    for (int i = threadIdx.x; i < a.K * a.C; i += 256) ps[i] = a.proto[i];
     __syncthreads();
-    const long row = (long)blockIdx.x * PROTO_ROWS_PER_BLOCK + threadIdx.x;
+    // d loss / d p_c[i] = sum_rows gcos_c(row) * r_i(row), r = x / |x|: a (K x rows) . (rows x C) product.  Each tile of 256
+    // rows leaves r and gcos in LDS; thread (group g, pair (c, i)) adds the tile's rows g, g + G, ... in row order.
+    const int KC = a.K * a.C, G = 256 / KC;                 // K * C <= 256
+    const int pair = threadIdx.x % KC, grp = threadIdx.x / KC;
+    const int pc = pair / a.C, pi = pair % a.C;
+    float* rs = tile;
+    float* gcs = tile + 256 * (a.C + 1);
+    float gacc = 0.0f;
+    for (int rt = 0; rt < row_tiles; ++rt) {
+    const long row = ((long)blockIdx.x * row_tiles + rt) * PROTO_ROWS_PER_BLOCK + threadIdx.x;
     float u[MAXC];
     float gc[MAXK] = {0.f, 0.f, 0.f, 0.f};
     float inv_n = 0.0f;
@@ -240,36 +246,43 @@ __global__ __launch_bounds__(256) void proto_bwd_kernel(const ProtoArgs a, const
             }
     }
     if (gproto_partial) {
-        // d loss / d p_c = sum_rows gcos_c * r: wave butterfly per (c, channel), then one LDS add per wave in wave order
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        for (int wv = 0; wv < 4; ++wv) {
 #pragma unroll
-            for (int c = 0; c < MAXK; ++c)
-                if (c < a.K) {
+        for (int i = 0; i < MAXC; ++i)
+            if (i < a.C) rs[threadIdx.x * (a.C + 1) + i] = live ? u[i] * inv_n : 0.0f;
 #pragma unroll
-                    for (int i = 0; i < MAXC; ++i)
-                        if (i < a.C) {
-                            float v = (live && wave == wv) ? gc[c] * (u[i] * inv_n) : 0.0f;
-                            if (wave == wv) {
-#pragma unroll
-                                for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-                                if (lane == 0) gp[c * a.C + i] += v;
-                            }
-                        }
-                }
-            __syncthreads();
+        for (int c = 0; c < MAXK; ++c) gcs[threadIdx.x * MAXK + c] = gc[c];
+        __syncthreads();
+        if (grp < G)
+            for (int r = grp; r < PROTO_ROWS_PER_BLOCK; r += G) gacc = __builtin_fmaf(gcs[r * MAXK + pc], rs[r * (a.C + 1) + pi], gacc);
+        __syncthreads();
+    }
+    }   // row tiles
+    if (gproto_partial) {
+        float* part = gcs + 256 * MAXK;
+        part[threadIdx.x] = grp < G ? gacc : 0.0f;
+        __syncthreads();
+        if ((int)threadIdx.x < KC) {
+            float s = 0.0f;
+            for (int g = 0; g < G; ++g) s += part[g * KC + threadIdx.x];
+            gproto_partial[(long)blockIdx.x * KC + threadIdx.x] = s;
         }
-        for (int i = threadIdx.x; i < a.K * a.C; i += 256) gproto_partial[(long)blockIdx.x * a.K * a.C + i] = gp[i];
     }
 }
 
+// one workgroup per prototype entry: 256 strided double sums over the row-tile partials, folded in a fixed tree
 __global__ __launch_bounds__(256) void proto_gproto_final_kernel(const float* __restrict__ partial, long n_blocks, int n,
                                                                  float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ double red[256];
+    const int i = blockIdx.x;
     double s = 0.0;
-    for (long b = 0; b < n_blocks; ++b) s += (double)partial[b * n + i];
-    out[i] = (float)s;
+    for (long b = threadIdx.x; b < n_blocks; b += 256) s += (double)partial[b * n + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[i] = (float)red[0];
 }
 
 }  // namespace
@@ -286,11 +299,20 @@ hipError_t launch_proto_forward(const ProtoArgs& a, double* partial, double* los
 
 hipError_t launch_proto_backward(const ProtoArgs& a, const float* g_loss, void* gx, float* gproto_partial, float* gproto,
                                  hipStream_t st) {
-    const long nb = proto_blocks(a.M);
-    if (a.bf16) hipLaunchKernelGGL(proto_bwd_kernel<__bf16>, dim3((unsigned)nb), dim3(256), 0, st, a, g_loss, (__bf16*)gx, gproto_partial);
-    else hipLaunchKernelGGL(proto_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, a, g_loss, (float*)gx, gproto_partial);
-    if (gproto_partial && gproto)
-        hipLaunchKernelGGL(proto_gproto_final_kernel, dim3((a.K * a.C + 255) / 256), dim3(256), 0, st, gproto_partial, nb, a.K * a.C, gproto);
+    // with a prototype gradient a workgroup walks several 256-row tiles (<= 2048 workgroups), so that the per-workgroup
+    // fold of the (K x C) partial is paid once per few thousand rows
+    const bool gp = gproto_partial && gproto;
+    int row_tiles = 1;
+    if (gp) {
+        const long want = (proto_blocks(a.M) + 2047) / 2048;
+        row_tiles = (int)(want < 1 ? 1 : want);
+    }
+    const long nb = (proto_blocks(a.M) + row_tiles - 1) / row_tiles;
+    const size_t lds = gp ? (size_t)(256 * (a.C + 1) + 256 * MAXK + 256) * sizeof(float) : 0;
+    float* gpp = gp ? gproto_partial : nullptr;
+    if (a.bf16) hipLaunchKernelGGL(proto_bwd_kernel<__bf16>, dim3((unsigned)nb), dim3(256), lds, st, a, g_loss, (__bf16*)gx, gpp, row_tiles);
+    else hipLaunchKernelGGL(proto_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), lds, st, a, g_loss, (float*)gx, gpp, row_tiles);
+    if (gp) hipLaunchKernelGGL(proto_gproto_final_kernel, dim3(a.K * a.C), dim3(256), 0, st, gproto_partial, nb, a.K * a.C, gproto);
     return hipGetLastError();
 }
 
