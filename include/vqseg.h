@@ -291,6 +291,13 @@ int vqseg_dice_sums_backward_f(const float* logits, int64_t stride_b, int64_t st
 int vqseg_softmax_stats_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px, int b, int c,
                           int64_t hw, int64_t* label, float* entropy, float* top, void* stream);
 
+/* Confusion counts per image: counts[b][t][p] = number of pixels with ground truth t (in [0, c); others skipped) and
+ * arg-max class p (first maximum).  Replaces Measurement._make_confusion_matrix (measurement.py:12-20: np.bincount of
+ * c * target + pred on the host) without the host round trip torch.bincount needs.  logits layout as for the Dice
+ * sums; 2..4 classes; counts [b][c][c] i64, overwritten. */
+int vqseg_confusion_counts_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px,
+                             const int64_t* target, int b, int c, int64_t hw, int64_t* counts, void* stream);
+
 /* Exact order statistics of n floats by radix select: out2[0] = the k-th smallest (0-based), out2[1] = the (k+1)-th
  * (clamped to the last).  The two values bracket the virtual index of np.percentile in make_regularized_pseudo_label
  * (deprecated/train_with_test_pt_pseudo_entropy_reg.py:35); the host interpolates.  Replaces the full device sort of

@@ -193,3 +193,29 @@ def test_order_stats_rejects_bad_arguments():
     assert L.vqseg_order_stats_f(x.data_ptr(), 0, 0, ws.data_ptr(), ws.numel(), out.data_ptr(), None) != 0
     assert L.vqseg_order_stats_f(x.data_ptr(), 16, 3, ws.data_ptr(), 8, out.data_ptr(), None) != 0                 # workspace
     assert L.vqseg_order_stats_f(None, 16, 3, ws.data_ptr(), ws.numel(), out.data_ptr(), None) != 0
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("shape", [(3, 3, 70, 61), (2, 4, 128, 96), (1, 2, 9, 5)])
+def test_confusion_counts_match_measurement(shape, layout):
+    """vqseg_confusion_counts_f against Measurement._make_confusion_matrix (measurement.py:12-20) on the host: exact,
+    including ties of the arg-max (first maximum) and pixels whose label is outside [0, C) (skipped)."""
+    from vq_seg_amd.measurement import Measurement, confusion_matrix_device
+    b, c, h, w = shape
+    logits = (synth.uniform(b * h + w, shape, -2, 2) * 4).round() / 4          # quarter steps: plenty of ties
+    target = (synth.uniform(7, (b, h, w), 0, 1) * c).long().clamp_(0, c - 1)
+    ref = Measurement(c)._make_confusion_matrix(logits.numpy(), target.numpy())
+    x = logits.to(dev())
+    if layout == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    got = confusion_matrix_device(x, target.to(dev()), c)
+    assert got.dtype == torch.int64 and torch.equal(got.cpu(), torch.from_numpy(ref))
+    assert got.sum().item() == b * h * w
+    target[:, ::3, ::2] = 255                                                  # ignore label: not counted
+    got = confusion_matrix_device(x, target.to(dev()), c)
+    keep = target != 255
+    assert got.sum().item() == keep.sum().item()
+    pred = logits.argmax(1)
+    for t in range(c):
+        for p_ in range(c):
+            assert got[:, t, p_].sum().item() == ((target == t) & (pred == p_) & keep).sum().item()

@@ -38,6 +38,8 @@ hipError_t launch_softmax_stats(const DiceArgs& a, long long* label, float* entr
 // out2[0], out2[1] = the k-th and (k+1)-th smallest (0-based; the second clamped to n-1) of x[0..n): exact radix select
 size_t order_stats_workspace_bytes();
 hipError_t launch_order_stats(const float* x, long n, long k, void* workspace, float* out2, hipStream_t st);
+// out[b][t][p] += 1 per pixel with ground truth t in [0, C) and arg-max class p (zeroed here first)
+hipError_t launch_confusion(const DiceArgs& a, long long* out, hipStream_t st);
 constexpr int DICE_PX_PER_BLOCK = 4096;
 long dice_blocks(long HW);
 hipError_t launch_dice_forward(const DiceArgs& a, double* partial, float* inter, float* sets, hipStream_t st);

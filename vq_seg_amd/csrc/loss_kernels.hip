@@ -459,6 +459,44 @@ __global__ __launch_bounds__(256) void softmax_stats_kernel(const DiceArgs a, lo
 }
 }  // namespace
 
+namespace {
+// Confusion counts of measurement.py:12-20 (Measurement._make_confusion_matrix: bincount of C * target + argmax(pred)) per
+// image, rows = ground truth.  Integer counts (LDS histogram per workgroup, then integer atomics): order-independent.
+__global__ __launch_bounds__(256) void confusion_kernel(const DiceArgs a, unsigned long long* __restrict__ out) {
+    __shared__ unsigned cnt[DMAXC * DMAXC];
+    if (threadIdx.x < DMAXC * DMAXC) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int b = blockIdx.y;
+    const long p0 = (long)blockIdx.x * DICE_PX_PER_BLOCK;
+    for (long px = p0 + threadIdx.x; px < p0 + DICE_PX_PER_BLOCK && px < a.HW; px += 256) {
+        const long long t = a.target[(long)b * a.HW + px];
+        float mx = -__builtin_inff();
+        int arg = 0;
+#pragma unroll
+        for (int c = 0; c < DMAXC; ++c)
+            if (c < a.C) {
+                const float z = a.logits[(long)b * a.sb + c * a.sc + px * a.sp];
+                if (z > mx) {                                       // first maximum, as torch.argmax
+                    mx = z;
+                    arg = c;
+                }
+            }
+        if (t >= 0 && t < a.C) atomicAdd(&cnt[(int)t * a.C + arg], 1u);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.C * a.C && cnt[threadIdx.x])
+        atomicAdd(&out[(long)b * a.C * a.C + threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+}
+}  // namespace
+
+hipError_t launch_confusion(const DiceArgs& a, long long* out, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)a.B * a.C * a.C * sizeof(long long), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)dice_blocks(a.HW), (unsigned)a.B), dim3(256), 0, st, a,
+                       reinterpret_cast<unsigned long long*>(out));
+    return hipGetLastError();
+}
+
 hipError_t launch_softmax_stats(const DiceArgs& a, long long* label, float* entropy, float* top, hipStream_t st) {
     hipLaunchKernelGGL(softmax_stats_kernel, dim3((unsigned)((a.HW + 255) / 256), (unsigned)a.B), dim3(256), 0, st, a, label, entropy, top);
     return hipGetLastError();

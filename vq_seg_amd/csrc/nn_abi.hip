@@ -306,6 +306,15 @@ int vqseg_softmax_stats_f(const float* logits, int64_t stride_b, int64_t stride_
     return e == hipSuccess ? 0 : hipfail(e, "softmax_stats_kernel");
 }
 
+int vqseg_confusion_counts_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px, const int64_t* target, int b,
+                             int c, int64_t hw, int64_t* counts, void* stream) {
+    vqseg::DiceArgs a;
+    if (int rc = dice_args(a, logits, stride_b, stride_c, stride_px, target, b, c, hw, 0)) return rc;
+    if (!counts) return bad("confusion_counts: null pointer");
+    hipError_t e = vqseg::launch_confusion(a, reinterpret_cast<long long*>(counts), static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "confusion_kernel");
+}
+
 size_t vqseg_order_stats_workspace_bytes(void) { return vqseg::order_stats_workspace_bytes(); }
 
 int vqseg_order_stats_f(const float* x, int64_t n, int64_t k, void* workspace, size_t workspace_bytes, float* out2, void* stream) {

@@ -2,7 +2,8 @@
 
 `Measurement` keeps the reference's numpy interface (the evaluator calls it with numpy arrays);
 `confusion_matrix_device` / `miou_device` compute the same quantities on the device from logits and
-labels with one bincount, so the training loop does not need a per-step `.cpu().numpy()` round trip.
+labels (one HIP pass, vqseg_confusion_counts_f), so the training loop needs neither a per-step `.cpu().numpy()` round
+trip nor the host synchronisation torch.bincount implies.
 """
 import numpy as np
 import torch
@@ -60,6 +61,21 @@ class Measurement:
 def confusion_matrix_device(logits: torch.Tensor, target: torch.Tensor, num_classes: int) -> torch.Tensor:
     """(N, C, H, W) logits, (N, H, W) int labels -> (N, C, C) int64 counts, rows = ground truth."""
     n = logits.shape[0]
+    if logits.is_cuda and logits.dim() == 4 and 2 <= num_classes <= 4 and logits.shape[1] == num_classes:
+        from . import _hip
+        x = logits.detach()
+        x = x if x.dtype == torch.float32 else x.float()
+        b, c, h, w = x.shape
+        sb, sc, sh, sw = x.stride()
+        if sh != w * sw:
+            x = x.contiguous()
+            sb, sc, sh, sw = x.stride()
+        tgt = target.reshape(b, h * w).long().contiguous()
+        out = torch.empty((b, c, c), dtype=torch.int64, device=x.device)
+        with torch.cuda.device(x.device):
+            _hip._check(_hip.lib().vqseg_confusion_counts_f(x.data_ptr(), sb, sc, sw, tgt.data_ptr(), b, c, h * w, out.data_ptr(),
+                                                            torch.cuda.current_stream().cuda_stream), "vqseg_confusion_counts_f")
+        return out
     cats = num_classes * target.reshape(n, -1).long() + logits.argmax(dim=1).reshape(n, -1)
     cats = cats + (num_classes ** 2) * torch.arange(n, device=cats.device)[:, None]
     return torch.bincount(cats.reshape(-1), minlength=n * num_classes ** 2).reshape(n, num_classes, num_classes)
