@@ -284,6 +284,20 @@ int vqseg_dice_sums_backward_f(const float* logits, int64_t stride_b, int64_t st
                                const int64_t* target, int b, int c, int64_t hw, int64_t ignore_index,
                                const float* g_inter, const float* g_sets, float* g_logits, void* stream);
 
+/* The same pass with the cross-entropy term of the v2 recipe riding along (train_vqreptunet1x1v2.py:165-187:
+ * 0.5 * nn.CrossEntropyLoss(ignore_index=255) + Dice on the same logits and targets):
+ *   ce[b][0] = sum over pixels with target != ignore_index of -log softmax(logits)[target],  ce[b][1] = their number;
+ * the mean CE is sum_b ce[b][0] / sum_b ce[b][1] on the host.  backward adds g_ce[b][0] * (softmax - onehot) on those pixels.
+ * `ce` / `g_ce` may be NULL (= the two entry points above). */
+int vqseg_dice_ce_sums_forward_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px,
+                                 const int64_t* target, int b, int c, int64_t hw, int64_t ignore_index,
+                                 void* workspace, size_t workspace_bytes, float* inter, float* sets, float* ce,
+                                 void* stream);
+int vqseg_dice_ce_sums_backward_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px,
+                                  const int64_t* target, int b, int c, int64_t hw, int64_t ignore_index,
+                                  const float* g_inter, const float* g_sets, const float* g_ce, float* g_logits,
+                                  void* stream);
+
 /* Pseudo-label statistics in one pass over the logits (layout as for the Dice sums): per pixel the arg-max class (i64),
  * the entropy -sum p log(p + 1e-10) and the top probability of softmax(logits); any output may be NULL.  Replaces
  * softmax -> argmax / log / mul / sum / max of make_regularized_pseudo_label (deprecated/train_with_test_pt_pseudo_entropy_reg.py:30-39),

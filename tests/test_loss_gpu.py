@@ -219,3 +219,42 @@ def test_confusion_counts_match_measurement(shape, layout):
     for t in range(c):
         for p_ in range(c):
             assert got[:, t, p_].sum().item() == ((target == t) & (pred == p_) & keep).sum().item()
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_fused_ce_dice_matches_the_two_reference_losses(layout, weighted):
+    """0.5 * CrossEntropyLoss(ignore_index=255) + DiceLoss (the v2 recipe's terms, train_vqreptunet1x1v2.py:165-187) from
+    ONE pass over the logits (vqseg_dice_ce_sums_*) against the two tensor-op formulations, value and gradient; with
+    ignored pixels, an image whose pixels are all ignored, and very confident wrong predictions (large nll)."""
+    from vq_seg_amd import nnf
+    from vq_seg_amd.loss.dice_loss import ce_dice_loss
+    b, c, h, w = 4, 3, 70, 52
+    logits = synth.uniform(11, (b, c, h, w), -6, 6)
+    logits[0, :, :8] *= 8.0                                                     # |logit| up to 48: nll ~ 90
+    target = (synth.uniform(12, (b, h, w), 0, 1) * c).long().clamp_(0, c - 1)
+    target[:, ::5, ::3] = 255
+    target[3] = 255                                                             # a fully ignored image
+    wt = torch.tensor([0.2, 0.5, 0.3]) if weighted else None
+    x0 = logits.to(dev())
+    if layout == "nhwc":
+        x0 = x0.contiguous(memory_format=torch.channels_last)
+    tg = target.to(dev())
+
+    def run(fused):
+        saved = nnf.dice_sums_supported
+        if not fused:
+            nnf.dice_sums_supported = lambda *_a, **_k: False
+        try:
+            x = x0.clone().requires_grad_(True)
+            loss = ce_dice_loss(x, tg, c, 0.5, wt, 255)
+            (loss * 2.0).backward()
+            return loss.detach(), x.grad
+        finally:
+            nnf.dice_sums_supported = saved
+
+    l_ref, g_ref = run(False)
+    l_hip, g_hip = run(True)
+    assert abs(l_hip.item() - l_ref.item()) <= 1e-5 * abs(l_ref.item())
+    assert rel(g_hip, g_ref) < 1e-5
+    assert (g_hip[3] == 0).all()

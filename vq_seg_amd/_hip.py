@@ -74,6 +74,10 @@ SYMBOLS = {
                                           c_void_p, c_void_p, c_void_p]),
     "vqseg_dice_sums_backward_f": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p,
                                            c_void_p, c_void_p, c_void_p]),
+    "vqseg_dice_ce_sums_forward_f": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p,
+                                             c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vqseg_dice_ce_sums_backward_f": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqseg_softmax_stats_f": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqseg_confusion_counts_f": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "vqseg_order_stats_workspace_bytes": (c_size_t, []),

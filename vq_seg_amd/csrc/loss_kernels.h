@@ -42,7 +42,9 @@ hipError_t launch_order_stats(const float* x, long n, long k, void* workspace, f
 hipError_t launch_confusion(const DiceArgs& a, long long* out, hipStream_t st);
 constexpr int DICE_PX_PER_BLOCK = 4096;
 long dice_blocks(long HW);
-hipError_t launch_dice_forward(const DiceArgs& a, double* partial, float* inter, float* sets, hipStream_t st);
-hipError_t launch_dice_backward(const DiceArgs& a, const float* g_inter, const float* g_sets, float* g_logits, hipStream_t st);
+// ce (nullable): [B][2] = (sum of -log softmax[target] over kept pixels, number of kept pixels); g_ce (nullable): [B][2], [b][0] used
+hipError_t launch_dice_forward(const DiceArgs& a, double* partial, float* inter, float* sets, float* ce, hipStream_t st);
+hipError_t launch_dice_backward(const DiceArgs& a, const float* g_inter, const float* g_sets, const float* g_ce, float* g_logits,
+                                hipStream_t st);
 
 }  // namespace vqseg

@@ -323,7 +323,8 @@ hipError_t launch_proto_backward(const ProtoArgs& a, const float* g_loss, void* 
 namespace {
 constexpr int DMAXC = 4;
 
-__device__ __forceinline__ void dice_pixel(const DiceArgs& a, int b, long px, float (&p)[DMAXC], int& tgt, bool& keep) {
+// nll: -log softmax(logits)[target] of a kept pixel (nn.CrossEntropyLoss(ignore_index) skips the others), 0 otherwise
+__device__ __forceinline__ void dice_pixel(const DiceArgs& a, int b, long px, float (&p)[DMAXC], int& tgt, bool& keep, float& nll) {
     const long long t = a.target[(long)b * a.HW + px];
     keep = t != a.ignore_index;
     tgt = keep ? (int)t : 0;
@@ -342,21 +343,28 @@ __device__ __forceinline__ void dice_pixel(const DiceArgs& a, int b, long px, fl
             sum += p[c];
         }
     const float inv = 1.0f / sum;
+    float zt = 0.0f;
 #pragma unroll
     for (int c = 0; c < DMAXC; ++c)
-        if (c < a.C) p[c] *= inv;
+        if (c < a.C) {
+            p[c] *= inv;
+            if (c == tgt) zt = z[c];
+        }
+    nll = keep ? logf(sum) + mx - zt : 0.0f;
 }
 
 __global__ __launch_bounds__(256) void dice_fwd_kernel(const DiceArgs a, double* __restrict__ partial) {
     __shared__ double red[256];
     const int b = blockIdx.y;
     const long p0 = (long)blockIdx.x * DICE_PX_PER_BLOCK;
-    double inter[DMAXC] = {0, 0, 0, 0}, sets[DMAXC] = {0, 0, 0, 0};
+    double inter[DMAXC] = {0, 0, 0, 0}, sets[DMAXC] = {0, 0, 0, 0}, ce[2] = {0, 0};       // ce: sum of nll, kept pixels
     for (long px = p0 + threadIdx.x; px < p0 + DICE_PX_PER_BLOCK && px < a.HW; px += 256) {
-        float p[DMAXC];
+        float p[DMAXC], nll;
         int tgt;
         bool keep;
-        dice_pixel(a, b, px, p, tgt, keep);
+        dice_pixel(a, b, px, p, tgt, keep, nll);
+        ce[0] += (double)nll;
+        ce[1] += keep ? 1.0 : 0.0;
 #pragma unroll
         for (int c = 0; c < DMAXC; ++c)
             if (c < a.C) {
@@ -365,9 +373,10 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const DiceArgs a, double*
                 sets[c] += (double)(p[c] + oh);
             }
     }
-    double* out = partial + ((long)b * gridDim.x + blockIdx.x) * 2 * a.C;
-    for (int q = 0; q < 2 * a.C; ++q) {
-        red[threadIdx.x] = q < a.C ? inter[q] : sets[q - a.C];
+    const int Q = 2 * a.C + 2;
+    double* out = partial + ((long)b * gridDim.x + blockIdx.x) * Q;
+    for (int q = 0; q < Q; ++q) {
+        red[threadIdx.x] = q < a.C ? inter[q] : q < 2 * a.C ? sets[q - a.C] : ce[q - 2 * a.C];
         __syncthreads();
         for (int m = 128; m >= 1; m >>= 1) {
             if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
@@ -379,17 +388,19 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const DiceArgs a, double*
 }
 
 __global__ __launch_bounds__(64) void dice_final_kernel(const double* __restrict__ partial, long n_blocks, int C,
-                                                        float* __restrict__ inter, float* __restrict__ sets) {
-    const int b = blockIdx.x, q = threadIdx.x;
-    if (q >= 2 * C) return;
+                                                        float* __restrict__ inter, float* __restrict__ sets, float* __restrict__ ce) {
+    const int b = blockIdx.x, q = threadIdx.x, Q = 2 * C + 2;
+    if (q >= Q) return;
     double s = 0.0;
-    for (long i = 0; i < n_blocks; ++i) s += partial[((long)b * n_blocks + i) * 2 * C + q];
+    for (long i = 0; i < n_blocks; ++i) s += partial[((long)b * n_blocks + i) * Q + q];
     if (q < C) inter[b * C + q] = (float)s;
-    else sets[b * C + q - C] = (float)s;
+    else if (q < 2 * C) sets[b * C + q - C] = (float)s;
+    else if (ce) ce[b * 2 + q - 2 * C] = (float)s;            // [b][0] = sum of nll over kept pixels, [b][1] = their number
 }
 
 __global__ __launch_bounds__(256) void dice_bwd_kernel(const DiceArgs a, const float* __restrict__ g_inter,
-                                                       const float* __restrict__ g_sets, float* __restrict__ g_logits) {
+                                                       const float* __restrict__ g_sets, const float* __restrict__ g_ce,
+                                                       float* __restrict__ g_logits) {
     const int b = blockIdx.y;
     const long p0 = (long)blockIdx.x * DICE_PX_PER_BLOCK;
     float gi[DMAXC], gs[DMAXC];
@@ -399,11 +410,12 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const DiceArgs a, const f
             gi[c] = g_inter[b * a.C + c];
             gs[c] = g_sets[b * a.C + c];
         }
+    const float gce = g_ce ? g_ce[b * 2] : 0.0f;               // d loss / d (sum of nll of image b)
     for (long px = p0 + threadIdx.x; px < p0 + DICE_PX_PER_BLOCK && px < a.HW; px += 256) {
-        float p[DMAXC];
+        float p[DMAXC], nll;
         int tgt;
         bool keep;
-        dice_pixel(a, b, px, p, tgt, keep);
+        dice_pixel(a, b, px, p, tgt, keep, nll);
         float dp[DMAXC], dotp = 0.0f;
 #pragma unroll
         for (int c = 0; c < DMAXC; ++c)
@@ -413,7 +425,9 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const DiceArgs a, const f
             }
 #pragma unroll
         for (int c = 0; c < DMAXC; ++c)
-            if (c < a.C) g_logits[(long)b * a.sb + c * a.sc + px * a.sp] = keep ? p[c] * (dp[c] - dotp) : 0.0f;   // logits * keep
+            if (c < a.C)                                       // Dice: logits * keep;  CE: softmax - onehot on kept pixels
+                g_logits[(long)b * a.sb + c * a.sc + px * a.sp] =
+                    keep ? __builtin_fmaf(gce, p[c] - (c == tgt ? 1.0f : 0.0f), p[c] * (dp[c] - dotp)) : 0.0f;
     }
 }
 }  // namespace
@@ -659,15 +673,17 @@ hipError_t launch_order_stats(const float* x, long n, long k, void* workspace, f
 
 long dice_blocks(long HW) { return (HW + DICE_PX_PER_BLOCK - 1) / DICE_PX_PER_BLOCK; }
 
-hipError_t launch_dice_forward(const DiceArgs& a, double* partial, float* inter, float* sets, hipStream_t st) {
+hipError_t launch_dice_forward(const DiceArgs& a, double* partial, float* inter, float* sets, float* ce, hipStream_t st) {
     const long nb = dice_blocks(a.HW);
     hipLaunchKernelGGL(dice_fwd_kernel, dim3((unsigned)nb, (unsigned)a.B), dim3(256), 0, st, a, partial);
-    hipLaunchKernelGGL(dice_final_kernel, dim3((unsigned)a.B), dim3(64), 0, st, partial, nb, a.C, inter, sets);
+    hipLaunchKernelGGL(dice_final_kernel, dim3((unsigned)a.B), dim3(64), 0, st, partial, nb, a.C, inter, sets, ce);
     return hipGetLastError();
 }
 
-hipError_t launch_dice_backward(const DiceArgs& a, const float* g_inter, const float* g_sets, float* g_logits, hipStream_t st) {
-    hipLaunchKernelGGL(dice_bwd_kernel, dim3((unsigned)dice_blocks(a.HW), (unsigned)a.B), dim3(256), 0, st, a, g_inter, g_sets, g_logits);
+hipError_t launch_dice_backward(const DiceArgs& a, const float* g_inter, const float* g_sets, const float* g_ce, float* g_logits,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(dice_bwd_kernel, dim3((unsigned)dice_blocks(a.HW), (unsigned)a.B), dim3(256), 0, st, a, g_inter, g_sets, g_ce,
+                       g_logits);
     return hipGetLastError();
 }
 

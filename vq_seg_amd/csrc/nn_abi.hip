@@ -273,28 +273,42 @@ static int dice_args(vqseg::DiceArgs& a, const float* logits, int64_t sb, int64_
 
 size_t vqseg_dice_workspace_bytes(int b, int c, int64_t hw) {
     if (b <= 0 || c <= 0 || hw <= 0) return 0;
-    return (size_t)b * vqseg::dice_blocks(hw) * 2 * c * sizeof(double);
+    return (size_t)b * vqseg::dice_blocks(hw) * (2 * c + 2) * sizeof(double);
+}
+
+int vqseg_dice_ce_sums_forward_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px, const int64_t* target, int b,
+                                 int c, int64_t hw, int64_t ignore_index, void* workspace, size_t workspace_bytes, float* inter,
+                                 float* sets, float* ce, void* stream) {
+    vqseg::DiceArgs a;
+    if (int rc = dice_args(a, logits, stride_b, stride_c, stride_px, target, b, c, hw, ignore_index)) return rc;
+    if (!workspace || !inter || !sets) return bad("dice: null pointer");
+    if (workspace_bytes < vqseg_dice_workspace_bytes(b, c, hw)) return vqseg_set_error(VQSEG_ENOSPC, "dice: workspace too small");
+    hipError_t e = vqseg::launch_dice_forward(a, static_cast<double*>(workspace), inter, sets, ce, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "dice_fwd_kernel");
+}
+
+int vqseg_dice_ce_sums_backward_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px, const int64_t* target, int b,
+                                  int c, int64_t hw, int64_t ignore_index, const float* g_inter, const float* g_sets, const float* g_ce,
+                                  float* g_logits, void* stream) {
+    vqseg::DiceArgs a;
+    if (int rc = dice_args(a, logits, stride_b, stride_c, stride_px, target, b, c, hw, ignore_index)) return rc;
+    if (!g_inter || !g_sets || !g_logits) return bad("dice: null pointer");
+    hipError_t e = vqseg::launch_dice_backward(a, g_inter, g_sets, g_ce, g_logits, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "dice_bwd_kernel");
 }
 
 int vqseg_dice_sums_forward_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px, const int64_t* target, int b,
                               int c, int64_t hw, int64_t ignore_index, void* workspace, size_t workspace_bytes, float* inter,
                               float* sets, void* stream) {
-    vqseg::DiceArgs a;
-    if (int rc = dice_args(a, logits, stride_b, stride_c, stride_px, target, b, c, hw, ignore_index)) return rc;
-    if (!workspace || !inter || !sets) return bad("dice: null pointer");
-    if (workspace_bytes < vqseg_dice_workspace_bytes(b, c, hw)) return vqseg_set_error(VQSEG_ENOSPC, "dice: workspace too small");
-    hipError_t e = vqseg::launch_dice_forward(a, static_cast<double*>(workspace), inter, sets, static_cast<hipStream_t>(stream));
-    return e == hipSuccess ? 0 : hipfail(e, "dice_fwd_kernel");
+    return vqseg_dice_ce_sums_forward_f(logits, stride_b, stride_c, stride_px, target, b, c, hw, ignore_index, workspace, workspace_bytes,
+                                        inter, sets, nullptr, stream);
 }
 
 int vqseg_dice_sums_backward_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px, const int64_t* target, int b,
                                int c, int64_t hw, int64_t ignore_index, const float* g_inter, const float* g_sets, float* g_logits,
                                void* stream) {
-    vqseg::DiceArgs a;
-    if (int rc = dice_args(a, logits, stride_b, stride_c, stride_px, target, b, c, hw, ignore_index)) return rc;
-    if (!g_inter || !g_sets || !g_logits) return bad("dice: null pointer");
-    hipError_t e = vqseg::launch_dice_backward(a, g_inter, g_sets, g_logits, static_cast<hipStream_t>(stream));
-    return e == hipSuccess ? 0 : hipfail(e, "dice_bwd_kernel");
+    return vqseg_dice_ce_sums_backward_f(logits, stride_b, stride_c, stride_px, target, b, c, hw, ignore_index, g_inter, g_sets, nullptr,
+                                         g_logits, stream);
 }
 
 int vqseg_softmax_stats_f(const float* logits, int64_t stride_b, int64_t stride_c, int64_t stride_px, int b, int c, int64_t hw,

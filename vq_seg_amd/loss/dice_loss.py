@@ -35,6 +35,24 @@ def dice_loss(pred, target, num_classes: int = 3, weight=None, ignore_index: int
     return 1 - dice.mean()
 
 
+def ce_dice_loss(pred, target, num_classes: int = 3, ce_weight: float = 0.5, weight=None, ignore_index: int = 255):
+    """ce_weight * F.cross_entropy(pred, target, ignore_index) + dice_loss(pred, target, ...): the supervised and CPS terms of
+    the v2 recipe (train_vqreptunet1x1v2.py:165-187).  On the HIP path both read the logits in ONE pass, forward and
+    backward (nnf.dice_ce_sums); otherwise the two reference formulations are evaluated one after the other."""
+    from .. import nnf
+    if nnf.dice_sums_supported(pred, num_classes) and ignore_index is not None:
+        inter, sets, ce = nnf.dice_ce_sums(pred, target, ignore_index)
+        dice = (2 * inter / (sets + 1e-6)).mean(dim=0)
+        if weight is not None:
+            weight = weight.to(pred.device)
+            d = torch.sum((1 - dice) * weight / torch.sum(weight)) / num_classes
+        else:
+            d = 1 - dice.mean()
+        return ce_weight * (ce[:, 0].sum() / ce[:, 1].sum()) + d
+    return ce_weight * F.cross_entropy(pred, target.long(), ignore_index=ignore_index) + \
+        dice_loss(pred, target, num_classes, weight=weight, ignore_index=ignore_index)
+
+
 class DiceLoss(nn.Module):
     def __init__(self, num_classes, weight=None, ignore_index=None):
         super().__init__()

@@ -558,7 +558,7 @@ def proto_loss(x, proto, labels, keep=None, conf=None, variant=1, scale=1.0, mar
 # ------------------------------------------------------------------------------------------------
 class _DiceSums(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target, ignore_index):
+    def forward(ctx, pred, target, ignore_index, want_ce=False):
         b, c, h, w = pred.shape
         sb, sc, sh, sw = pred.stride()
         if sh != w * sw:                                   # pixels must be linear in memory (NCHW and NHWC both are)
@@ -569,24 +569,28 @@ class _DiceSums(torch.autograd.Function):
         nbytes = L.vqseg_dice_workspace_bytes(b, c, h * w)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=pred.device)
         out = torch.empty(2, b, c, dtype=torch.float32, device=pred.device)
+        ce = torch.empty(b, 2, dtype=torch.float32, device=pred.device) if want_ce else None
         ign = -(1 << 62) if ignore_index is None else int(ignore_index)
         with torch.cuda.device(pred.device):
-            _check(L.vqseg_dice_sums_forward_f(pred.data_ptr(), sb, sc, sw, tgt.data_ptr(), b, c, h * w, ign, ws.data_ptr(), nbytes,
-                                               out[0].data_ptr(), out[1].data_ptr(), _stream()), "vqseg_dice_sums_forward_f")
+            _check(L.vqseg_dice_ce_sums_forward_f(pred.data_ptr(), sb, sc, sw, tgt.data_ptr(), b, c, h * w, ign, ws.data_ptr(), nbytes,
+                                                  out[0].data_ptr(), out[1].data_ptr(), _p(ce), _stream()), "vqseg_dice_ce_sums_forward_f")
         ctx.save_for_backward(pred, tgt)
-        ctx.cfg = (b, c, h * w, ign, (sb, sc, sw))
+        ctx.cfg = (b, c, h * w, ign, (sb, sc, sw), want_ce)
+        if want_ce:
+            return out[0], out[1], ce
         return out[0], out[1]
 
     @staticmethod
-    def backward(ctx, g_inter, g_sets):
+    def backward(ctx, g_inter, g_sets, g_ce=None):
         pred, tgt = ctx.saved_tensors
-        b, c, hw, ign, (sb, sc, sw) = ctx.cfg
+        b, c, hw, ign, (sb, sc, sw), want_ce = ctx.cfg
         g = torch.empty_strided(pred.shape, pred.stride(), dtype=torch.float32, device=pred.device)
         gi, gs = g_inter.float().contiguous(), g_sets.float().contiguous()
+        gc = g_ce.float().contiguous() if (want_ce and g_ce is not None) else None
         with torch.cuda.device(pred.device):
-            _check(lib().vqseg_dice_sums_backward_f(pred.data_ptr(), sb, sc, sw, tgt.data_ptr(), b, c, hw, ign, gi.data_ptr(), gs.data_ptr(),
-                                                    g.data_ptr(), _stream()), "vqseg_dice_sums_backward_f")
-        return g, None, None
+            _check(lib().vqseg_dice_ce_sums_backward_f(pred.data_ptr(), sb, sc, sw, tgt.data_ptr(), b, c, hw, ign, gi.data_ptr(),
+                                                       gs.data_ptr(), _p(gc), g.data_ptr(), _stream()), "vqseg_dice_ce_sums_backward_f")
+        return g, None, None, None
 
 
 def dice_sums_supported(pred, num_classes: int) -> bool:
@@ -596,6 +600,13 @@ def dice_sums_supported(pred, num_classes: int) -> bool:
 def dice_sums(pred, target, ignore_index):
     """(inter, sets), each (B, C) float32: sum over pixels of softmax * onehot and of softmax + onehot (dice_loss.py:24-26)."""
     return _DiceSums.apply(pred, target, ignore_index)
+
+
+def dice_ce_sums(pred, target, ignore_index):
+    """(inter, sets, ce): the Dice sums plus ce (B, 2) = (sum of -log softmax[target], number of pixels) over the pixels whose
+    target != ignore_index -- nn.CrossEntropyLoss(ignore_index)'s mean is ce[:, 0].sum() / ce[:, 1].sum() -- in the same pass
+    over the logits, forward and backward (vqseg_dice_ce_sums_*)."""
+    return _DiceSums.apply(pred, target, ignore_index, True)
 
 
 def softmax_stats(logits, want_label=True, want_entropy=True, want_top=False):

@@ -20,6 +20,7 @@ from torch import nn
 
 from . import dist as vdist
 from .loss import make_loss
+from .loss.dice_loss import DiceLoss, ce_dice_loss
 from .measurement import confusion_matrix_device, miou_device
 from . import nnf
 from .models import init_weight
@@ -338,9 +339,8 @@ class CPSTrainer:
             pl1, pl2 = torch.argmax(pred_1, dim=1).long(), torch.argmax(pred_2, dim=1).long()
             f1 = score_mask(pred_1, pl1, cfg.confidence_threshold)
             f2 = score_mask(pred_2, pl2, cfg.confidence_threshold)
-            cps = 0.5 * self.ce(pred_1, f2) + 0.5 * self.ce(pred_2, f1) + self.criterion(pred_1, f2) + self.criterion(pred_2, f1)
-            sup_1 = 0.5 * self.ce(ps1, l_target) + self.criterion(ps1, l_target)
-            sup_2 = 0.5 * self.ce(ps2, l_target) + self.criterion(ps2, l_target)
+            cps = self._ce_dice(pred_1, f2) + self._ce_dice(pred_2, f1)
+            sup_1, sup_2 = self._ce_dice(ps1, l_target), self._ce_dice(ps2, l_target)
         commitment = (c_l1 + c_l2 + c_u1 + c_u2) * cfg.total_commitment_loss_weight
         prototype = (p_l1 + p_l2 + p_u1 + p_u2) * cfg.total_prototype_loss_weight
         lr = self.sched.get_lr(self.iter)
@@ -362,6 +362,13 @@ class CPSTrainer:
                 "commitment_loss": commitment.detach().sum(), "prototype_loss": prototype.detach(), "miou": miou,
                 "lr": torch.tensor(lr)}
 
+    def _ce_dice(self, pred, target):
+        """0.5 * CE(ignore 255) + criterion (train_vqreptunet1x1v2.py:165-187); with the Dice criterion both terms come from
+        one fused pass over the logits."""
+        if isinstance(self.criterion, DiceLoss):
+            return ce_dice_loss(pred, target, self.criterion.num_classes, 0.5, self.criterion.weight, self.criterion.ignore_index)
+        return 0.5 * self.ce(pred, target) + self.criterion(pred, target)
+
     def supervised_step(self, l_input, l_target) -> torch.Tensor:
         """Plain supervised step of model 1 (Dice + 0.5 CE), for the single-model throughput figure."""
         m = self.models[0]
@@ -371,7 +378,7 @@ class CPSTrainer:
         pred, closs, _u, ploss = self._fwd(m, l_input, l_target, **kw)
         self._join()
         pred = pred.float()
-        loss = 0.5 * self.ce(pred, l_target) + self.criterion(pred, l_target) + closs.sum() + 0.01 * ploss.float()
+        loss = self._ce_dice(pred, l_target) + closs.sum() + 0.01 * ploss.float()
         loss.backward()
         if self._two_streams:
             torch.cuda.current_stream().wait_stream(self._streams[0])
