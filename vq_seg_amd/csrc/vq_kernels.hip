@@ -99,7 +99,11 @@ __global__ __launch_bounds__(64) void vq_code_norms(const float* __restrict__ W,
 constexpr int ROWS_PER_WAVE = 32;
 constexpr int WAVES = 4;
 constexpr int ROWS_PER_WG = ROWS_PER_WAVE * WAVES;
-constexpr int STAGE_FLOATS = 4096;   // BK * 32T floats = 16 KiB
+#ifndef VQ_BIG_STAGE
+#define VQ_BIG_STAGE 0
+#endif
+// floats per LDS stage = BK * 32T: 16 KiB, or (VQ_BIG_STAGE, wide workgroups) 32 KiB = half as many barriers
+constexpr int stage_floats(int T) { return (VQ_BIG_STAGE && T >= 4) ? 8192 : 4096; }
 
 __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
     // one wave-instruction: 64 lanes x 16 B -> 1 KiB contiguous in LDS at lds_wave_base
@@ -118,7 +122,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const TX* __restr
                                                                int C, int Cp, int Kp,
                                                                unsigned long long* __restrict__ keys) {
     constexpr int CODES = 32 * T;                // codes per workgroup
-    constexpr int BK = 128 / T;                  // channels per stage
+    constexpr int STAGE_FLOATS = stage_floats(T);
+    constexpr int BK = STAGE_FLOATS / (32 * T);  // channels per stage
     constexpr int JB = BK / 8;                   // 8-channel blocks per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Bs = reinterpret_cast<float*>(smem);                 // [2][BK/4][CODES][4]
@@ -147,8 +152,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const TX* __restr
     auto fill = [&](int stage, int buf) {
         float* dst = Bs + buf * STAGE_FLOATS;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int piece = wave * 4 + q;                     // 0..15, 256 floats each
+        for (int q = 0; q < STAGE_FLOATS / 1024; ++q) {
+            const int piece = wave * (STAGE_FLOATS / 1024) + q; // 256 floats each
             const int fl = piece * 256 + lane * 4;              // float offset inside the stage
             const int c4 = fl / (CODES * 4);                    // slab (4-channel group) inside the stage
             const int code = (fl % (CODES * 4)) >> 2;
@@ -772,6 +777,7 @@ int profile_collect(int max_records, int64_t* n, int* c, int* k, float* ms) {
 template <int T, typename TX>
 static void launch_assign_t(const TX* x, const float* E4, const float* en, int64_t N, int C, int Kp,
                             unsigned long long* keys, hipStream_t st) {
+    constexpr int STAGE_FLOATS = stage_floats(T);
     static_assert((size_t)WAVES * 32 * 33 * sizeof(unsigned long long) <= (2 * STAGE_FLOATS + 256) * sizeof(float), "key scratch aliases the B stages");
     const size_t lds = (size_t)(2 * STAGE_FLOATS + 256 + WAVES * 32) * sizeof(float);
     const dim3 grid((unsigned)((N + ROWS_PER_WG - 1) / ROWS_PER_WG), (unsigned)(Kp / (32 * T)));
