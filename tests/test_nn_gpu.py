@@ -218,6 +218,16 @@ def test_conv3x3_patch_kernel(case, force_patch_kernel):
     assert rc == 0, L.vqseg_last_error()
     torch.cuda.synchronize()
     assert rel(y.float(), ref) < 2 ** -7
+    # 1-D launch with the Cout chunks of a pixel tile on one XCD (conv3x3_patch_xcd_pair): same workgroups, same bits
+    y2 = torch.full_like(y, float("nan"))
+    stat2 = torch.full_like(stat, float("nan"))
+    prev = L.vqseg_set_option(b"conv3x3_patch_xcd_pair", 1)
+    rc = L.vqseg_conv2d_f(xa.data_ptr(), xb.data_ptr() if c2 else None, c1, hi.data_ptr(), None, y2.data_ptr(), stat2.data_ptr(),
+                          n, h, w, cin, cout, 3, 3, 1, 1, int(reflect), 1, h, w, 0, st)
+    L.vqseg_set_option(b"conv3x3_patch_xcd_pair", prev)
+    assert rc == 0, L.vqseg_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y) and torch.equal(stat2[:n * h * w // (64 if cout >= 64 else 32)], stat[:n * h * w // (64 if cout >= 64 else 32)])
     # BatchNorm partials of the fp32 accumulators: merged mean / biased variance per channel
     m = n * h * w
     rps = 64 if cout >= 64 else 32                         # rows per statistics slot (vqseg_conv_stat_slots)

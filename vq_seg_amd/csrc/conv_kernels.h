@@ -20,6 +20,7 @@ struct ConvArgs {
     const float* ep_shift;
     const void* ep_res;         // optional residual rows [N, Ho, Wo, Cout] of the activation type
     int ep_relu;
+    int pair_chunks = 0, pair_tiles = 0;   // patch kernel, 1-D launch: Cout chunks per pixel tile / pixel tiles (0: 2-D grid)
 };
 
 struct WgradArgs {

@@ -680,14 +680,22 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     const int tw_shift = (p.W & 31) == 0 ? 5 : 4;
     const int TW = 1 << tw_shift, TH = TBM >> tw_shift, PW = TW + 2, PH = TH + 2;
     const int tiles_x = p.W >> tw_shift, tiles_y = p.H / TH;
-    const int tile_id = blockIdx.x;
+    // 1-D launch (pair_chunks > 0): the workgroups that share a pixel tile (one per Cout chunk) sit 8 ids apart, i.e. on the
+    // same XCD at about the same time, so the patch is fetched from HBM once and then served by that XCD's L2
+    int tile_id = blockIdx.x, co_chunk = blockIdx.y;
+    if (p.pair_chunks > 0) {
+        const unsigned group = 8u * (unsigned)p.pair_chunks, within = blockIdx.x % group;
+        tile_id = (int)(blockIdx.x / group) * 8 + (int)(within & 7u);
+        co_chunk = (int)(within >> 3);
+        if (tile_id >= p.pair_tiles) return;
+    }
     int t = tile_id;
     const int txi = t % tiles_x;
     t /= tiles_x;
     const int tyi = t % tiles_y;
     const int n = t / tiles_y;
     const int oh0 = tyi * TH, ow0 = txi * TW;
-    const int co0 = blockIdx.y * BN;
+    const int co0 = co_chunk * BN;
 
     const int slot = lane & (ROWB / 16 - 1), lrow = lane / (ROWB / 16);     // 16-byte slot and row of this lane in a DMA instruction
     // ---- this lane's weight rows
@@ -834,6 +842,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
 }
 
 static int g_patch_min_wgs = 256;
+static int g_patch_pair = 0;                                // 1: Cout chunks of a pixel tile share an XCD (1-D launch, see the kernel)
 static int g_patch_wide = 0;                                // 1: take the 256-channel tile where it fills the chip (measured 3-5 % slower than the unrolled 128 tile)
 static int g_short_k_small = 1;                             // K loops of up to this many stages take the 128x128 tile at 4 waves/SIMD
 static int g_short_k_single = 8;                            // K loops of up to this many stages: single-buffered 128x128 tile, 4 workgroups/CU
@@ -858,6 +867,11 @@ int conv_set_option(const char* key, int value) {
     if (key && !strcmp(key, "conv3x3_patch_unroll")) {
         const int prev = g_patch_unroll;
         g_patch_unroll = value;
+        return prev;
+    }
+    if (key && !strcmp(key, "conv3x3_patch_xcd_pair")) {
+        const int prev = g_patch_pair;
+        g_patch_pair = value ? 1 : 0;
         return prev;
     }
     if (key && !strcmp(key, "conv3x3_patch_wide_tile")) {
@@ -886,7 +900,17 @@ static void launch_patch_t(const ConvArgs& a, hipStream_t st) {
     const size_t out_tile = (size_t)256 * (BN + 8) * 2;
     if (out_tile > lds) lds = out_tile;
     const int tw = (a.W % 32 == 0) ? 32 : 16, th = 256 / tw;
-    dim3 grid((unsigned)((long)a.N * (a.H / th) * (a.W / tw)), (unsigned)(a.Cout / BN));
+    const long tiles = (long)a.N * (a.H / th) * (a.W / tw);
+    const int chunks = a.Cout / BN;
+    if (g_patch_pair && chunks > 1) {
+        ConvArgs b = a;
+        b.pair_chunks = chunks;
+        b.pair_tiles = (int)tiles;
+        hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK>), dim3((unsigned)((tiles + 7) / 8 * 8 * chunks)), dim3(512),
+                           lds, st, b);
+        return;
+    }
+    dim3 grid((unsigned)tiles, (unsigned)chunks);
     hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK>), grid, dim3(512), lds, st, a);
 }
 
