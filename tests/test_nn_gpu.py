@@ -518,7 +518,8 @@ def test_short_k_dispatch_variants_agree():
         hi = torch.empty(L.vqseg_conv_packed_elems(cout, cin, 1, 1, 0), dtype=torch.int16, device=dev())
         assert L.vqseg_conv_pack_weights_f32(wt.data_ptr(), cout, cin, 1, 1, 0, hi.data_ptr(), None, st) == 0
         outs = []
-        for opts in ({}, {"conv_short_k_single_buffer": 8, "conv_short_k_small_tile": 0}, {"conv_short_k_small_tile": 8}):
+        for opts in ({}, {"conv_short_k_single_buffer": 8, "conv_short_k_small_tile": 0}, {"conv_short_k_small_tile": 8},
+                     {"conv_xcd_pair": 0}, {"conv_xcd_pair": 16}):       # 2-D grid / Cout chunks of an M tile on one XCD
             prev = {k: L.vqseg_set_option(k.encode(), v) for k, v in opts.items()}
             y = torch.full((n, h, w, cout), float("nan"), dtype=torch.bfloat16, device=dev())
             rc = L.vqseg_conv2d_f(x.data_ptr(), None, cin, hi.data_ptr(), None, y.data_ptr(), None, n, h, w, cin, cout, 1, 1, 1, 0, 0, 1, h, w, 0, st)
@@ -529,4 +530,4 @@ def test_short_k_dispatch_variants_agree():
         torch.cuda.synchronize()
         ref = (x.float().reshape(-1, cin) @ wt.reshape(cout, cin).bfloat16().float().t()).reshape(n, h, w, cout)
         assert rel(outs[0].float(), ref) < 2 ** -7
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        assert all(torch.equal(outs[0], o) for o in outs[1:])

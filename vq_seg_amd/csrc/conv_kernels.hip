@@ -459,8 +459,18 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
     const int r = lane & 31, h = lane >> 5;
 
     const long M = (long)p.N * p.Ho * p.Wo;
-    const long m0 = (long)blockIdx.x * TBM;
-    const int co0 = blockIdx.y * BN;
+    // 1-D launch (pair_chunks > 0): the Cout chunks of an M tile sit 8 workgroup ids apart = on the same XCD at about the
+    // same time, so the A rows come from HBM once and from that XCD's L2 for the other chunks
+    long m_tile = blockIdx.x;
+    int co_chunk = blockIdx.y;
+    if (p.pair_chunks > 0) {
+        const unsigned group = 8u * (unsigned)p.pair_chunks, within = blockIdx.x % group;
+        m_tile = (long)(blockIdx.x / group) * 8 + (within & 7u);
+        co_chunk = (int)(within >> 3);
+        if (m_tile >= p.pair_tiles) return;
+    }
+    const long m0 = m_tile * TBM;
+    const int co0 = co_chunk * BN;
 
     // ---- this lane's A rows: instruction i of this wave covers tile rows 8*(A_INSTR*wave + i) .. +7; lane -> row l>>3
     const int slot = lane & 7;
@@ -615,6 +625,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
     conv_epilogue<TBM, BN, false, MT, NTT, NT, NW * 64>(acc, p, smem, M, m0, co0, wm, wn, r, h, tid);
 }
 
+static int g_glds_pair = 4;                                 // layers with 2..this many Cout chunks: the chunks of an M tile share an XCD
+                                                            // (1-D launch, see the kernel; measured -3..-6 % at 2-4 chunks, +5 % at 8)
+
 template <int TBM, int BN, int NW, int NBUF, int MINW = 1>
 static void launch_glds_t(const ConvArgs& a, hipStream_t st) {
     const int n_stage = a.KH * a.KW * (a.Cin / 64);
@@ -624,7 +637,17 @@ static void launch_glds_t(const ConvArgs& a, hipStream_t st) {
     const size_t out_tile = (size_t)TBM * (BN + 8) * 2;
     if (out_tile > lds) lds = out_tile;
     const long M = (long)a.N * a.Ho * a.Wo;
-    dim3 grid((unsigned)((M + TBM - 1) / TBM), (unsigned)((a.Cout + BN - 1) / BN));
+    const long m_tiles = (M + TBM - 1) / TBM;
+    const int chunks = (a.Cout + BN - 1) / BN;
+    if (chunks > 1 && chunks <= g_glds_pair && m_tiles < (1L << 30)) {
+        ConvArgs b = a;
+        b.pair_chunks = chunks;
+        b.pair_tiles = (int)m_tiles;
+        hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW>), dim3((unsigned)((m_tiles + 7) / 8 * 8 * chunks)),
+                           dim3(NW * 64), lds, st, b);
+        return;
+    }
+    dim3 grid((unsigned)m_tiles, (unsigned)chunks);
     hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW>), grid, dim3(NW * 64), lds, st, a);
 }
 
@@ -867,6 +890,11 @@ int conv_set_option(const char* key, int value) {
     if (key && !strcmp(key, "conv3x3_patch_unroll")) {
         const int prev = g_patch_unroll;
         g_patch_unroll = value;
+        return prev;
+    }
+    if (key && !strcmp(key, "conv_xcd_pair")) {
+        const int prev = g_glds_pair;
+        g_glds_pair = value;
         return prev;
     }
     if (key && !strcmp(key, "conv3x3_patch_xcd_pair")) {
