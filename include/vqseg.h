@@ -43,6 +43,8 @@ const char* vqseg_kernel_name(const char* entry_point);
  *   "conv3x3_patch_min_workgroups"  minimum grid of the patch-reuse 3x3 kernel before the generic implicit-GEMM
  *                                   kernel is preferred (default 256 = one workgroup per CU)
  *   "conv3x3_patch_unroll", "conv3x3_patch_wide_tile"   variants of that kernel (tap loop unrolled; 256-channel tile)
+ *   "vq_max_tiles_per_wave"         cap (8, 4, 2, 1) on the 32-code accumulator tiles a wave of the VQ distance kernel
+ *                                   holds (default 8; 4 measured equal within 2 % on every benchmark shape)
  *   "conv_xcd_pair"                 implicit-GEMM layers with 2..value Cout chunks launch 1-D so that the chunks of an
  *                                   M tile run on the same XCD and share the input rows through its L2 (default 4; 0: off)
  *   "conv3x3_patch_xcd_pair"        1: the Cout chunks of a pixel tile are dispatched onto the same XCD (default 0:

@@ -7,6 +7,7 @@
 
 #include "../../include/vqseg.h"
 #include "conv_kernels.h"
+#include "vq_kernels.h"
 #include "nn_kernels.h"
 #include "loss_kernels.h"
 #include <math.h>
@@ -88,7 +89,8 @@ int vqseg_conv2d_affine_f(const void* x, const void* x2, int c1, const void* w_h
 
 int vqseg_set_option(const char* key, int value) {
     if (!key || value < 0) return bad("set_option: null key or negative value");
-    const int prev = vqseg::conv_set_option(key, value);
+    int prev = vqseg::conv_set_option(key, value);
+    if (prev < 0) prev = vqseg::vq_set_option(key, value);
     return prev < 0 ? bad("set_option: unknown key") : prev;
 }
 

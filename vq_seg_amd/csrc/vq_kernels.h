@@ -14,6 +14,7 @@ struct VqPlan {
     size_t off_prepared, off_keys, off_hist, off_partial, bytes;
     int gather_blocks;
 };
+int vq_set_option(const char* key, int value);              // returns the previous value, -1: unknown key / bad value
 struct KmPlan {
     VqPlan vq;
     size_t off_idx, off_counts, off_offsets, off_members, off_sums, off_counts64, off_hist, off_segoff, off_partial, bytes;

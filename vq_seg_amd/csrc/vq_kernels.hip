@@ -25,6 +25,7 @@
 //   d          = sqrt(max(fmaf(-2, dot, |x|^2) + |e|^2, 0))        (correctly rounded sqrt)
 //   idx        = lowest k attaining min d
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -696,6 +697,16 @@ size_t prepared_bytes(int C, int K) {
     return (((size_t)C * Kp + Kp) * sizeof(float) + 255) & ~(size_t)255;
 }
 
+static int g_vq_max_tiles = 8;                              // cap on T (option "vq_max_tiles_per_wave": 8, 4, 2 or 1)
+int vq_set_option(const char* key, int value) {
+    if (key && !strcmp(key, "vq_max_tiles_per_wave") && (value == 8 || value == 4 || value == 2 || value == 1)) {
+        const int prev = g_vq_max_tiles;
+        g_vq_max_tiles = value;
+        return prev;
+    }
+    return -1;
+}
+
 VqPlan vq_plan(int64_t N, int C, int K) {
     VqPlan p;
     p.Cp = C;
@@ -717,7 +728,7 @@ VqPlan vq_plan(int64_t N, int C, int K) {
     const long row_blocks = (N + ROWS_PER_WG - 1) / ROWS_PER_WG;
     const int tiles = p.Kp / 32;
     p.T = 1;
-    for (int t = 8; t >= 1; t >>= 1) {
+    for (int t = g_vq_max_tiles; t >= 1; t >>= 1) {
         if (tiles % t) continue;
         if (row_blocks * (tiles / t) >= 512 || t == 1) {
             p.T = t;
