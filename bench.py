@@ -189,8 +189,26 @@ def main():
             raise AssertionError(f"ranks diverged in {len(bad)} of {len(names)} parameters, e.g. {bad[:6]} ... {bad[-3:]}")
         note(f"rank {rank}: parameter checksums identical on all {world} ranks")
 
+    recs = _hip.profile_collect(64 * args.steps) if rank == 0 else []
+    # next to the CPS figure, plain forward + backward + Adam of ONE network on the B labelled images
+    # (ordinary supervised training throughput) -- measured after, and outside of, the timed region
+    (l_in, l_tg), _ul = batches[0]
+    trainer.supervised_step(l_in, l_tg)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ts = time.perf_counter()
+    for _ in range(3):
+        trainer.supervised_step(l_in, l_tg)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    tsup = torch.tensor([(time.perf_counter() - ts) / 3], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tsup, op=dist.ReduceOp.MAX)
+    sup_s = float(tsup.item())
+
     if rank == 0:
-        recs = _hip.profile_collect(64 * args.steps)
         flops = sum(2.0 * n * c * k for n, c, k, _ in recs)
         ms = sum(r[3] for r in recs)
         per_shape = {}
@@ -224,6 +242,9 @@ def main():
                          "note": "algorithmic flops 2*N*K*C per launch / HIP-event time on the launch stream, "
                                  "all launches inside the timed region; peak = fp32 MFMA (MI355X_MICROARCH.md)"},
         }
+        line["supervised_step"] = {"images_per_sec": round(args.batch * world / sup_s, 2), "ms_per_step": round(sup_s * 1e3, 2),
+                                   "what": "forward + backward + Adam of ONE network on the labelled half of the batch "
+                                           "(0.5 CE + Dice + commitment + prototype loss), 3 steps after the timed region"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
