@@ -32,6 +32,7 @@ os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 SIZE, K_CODES = 512, 512
 
@@ -217,6 +218,10 @@ def main():
             e[0] += 1
             e[1] += m
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # the other roof (quote both): algorithmic bytes per row = C*s_in (rows) + C*s_out (quantised rows) + 8 (index)
+        elem = 2 if args.dtype == "bf16" else 4
+        alg_bytes = sum(n * (2.0 * c * elem + 8) for n, c, k, _ in recs)
+        hbm_gbs = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic(per_shape)
         images = 2 * args.batch * world * args.steps
         line = {
@@ -235,6 +240,10 @@ def main():
             "roofline": {"kernel": "vq_assign_f32_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "other_roof": {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
+                                        "note": "algorithmic bytes (rows in + quantised rows out + index) over the same launch times: "
+                                                "the fp32 distance contraction sits far on the MFMA side of the ridge"},
                          "launches": len(recs), "avg_launch_us": round(ms / max(len(recs), 1) * 1e3, 2),
                          "per_shape": {s: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2),
                                            "tflops": round(v[2] / (v[1] / v[0] * 1e-3) / 1e12, 2)}

@@ -385,6 +385,18 @@ def test_maxpool_bilinear_head(dtype):
         out.backward(cl(gg).to(dtype))
         assert rel(out.float(), y) < max(tol, 1e-6), (align, ho, wo)
         assert rel(xg.grad.float(), xr.grad) < max(tol, 2e-6), (align, ho, wo)
+    # the logits' shapes: 3 channels (one pixel per thread) and another odd count (one element per thread), fp32, x2 upsampling
+    if dtype == torch.float32:
+        for ch in (3, 5):
+            x3 = synth.uniform(7, (2, ch, 20, 24), -1, 1)
+            xr = x3.clone().requires_grad_(True)
+            y = F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True)
+            gg = synth.uniform(8, tuple(y.shape), -1, 1)
+            y.backward(gg)
+            xg = cl(x3).requires_grad_(True)
+            out = nnf.upsample_bilinear(xg, scale_factor=2, align_corners=True)
+            out.backward(cl(gg))
+            assert rel(out, y) < 1e-6 and rel(xg.grad, xr.grad) < 2e-6, ch
     # 1x1 head: fp32 logits
     w = synth.uniform(4, (3, 32, 1, 1), -1, 1)
     x = synth.uniform(5, (2, 32, 20, 20), -1, 1)
@@ -531,3 +543,38 @@ def test_short_k_dispatch_variants_agree():
         ref = (x.float().reshape(-1, cin) @ wt.reshape(cout, cin).bfloat16().float().t()).reshape(n, h, w, cout)
         assert rel(outs[0].float(), ref) < 2 ** -7
         assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+def test_stem_patch_matrix_is_shared_inside_a_scope_only():
+    """nnf.stem_share_begin/end: stems that unfold the SAME image tensor (same object, same version) inside the scope reuse one
+    patch matrix -- across modules and streams; a different tensor, an in-place change of the tensor, or the end of the scope
+    each get a fresh unfold.  Outputs are bit-identical to the unshared path."""
+    from vq_seg_amd import nnf
+    torch.manual_seed(0)
+    conv_a, bn_a = nn.Conv2d(3, 64, 7, 2, 3, bias=False, padding_mode="reflect").to(dev()), nn.BatchNorm2d(64).to(dev())
+    conv_b, bn_b = nn.Conv2d(3, 64, 7, 2, 3, bias=False, padding_mode="reflect").to(dev()), nn.BatchNorm2d(64).to(dev())
+    x = cl(synth.uniform(1, (2, 3, 64, 64), 0, 1))
+    y = cl(synth.uniform(2, (2, 3, 64, 64), 0, 1))
+    with torch.no_grad():
+        ref_a, ref_b = nnf.stem_conv_bn_act(x, conv_a, bn_a), nnf.stem_conv_bn_act(x, conv_b, bn_b)
+        assert nnf._STEM_SHARE is None
+        nnf.stem_share_begin()
+        try:
+            out_a = nnf.stem_conv_bn_act(x, conv_a, bn_a)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                out_b = nnf.stem_conv_bn_act(x, conv_b, bn_b)               # other module, other stream: same matrix
+            torch.cuda.current_stream().wait_stream(side)
+            assert len(nnf._STEM_SHARE) == 1
+            nnf.stem_conv_bn_act(y, conv_a, bn_a)
+            assert len(nnf._STEM_SHARE) == 2
+            x.mul_(0.5)                                                     # same object, new version: unfolded again
+            out_c = nnf.stem_conv_bn_act(x, conv_a, bn_a)
+            assert len(nnf._STEM_SHARE) == 3
+        finally:
+            nnf.stem_share_end()
+        assert nnf._STEM_SHARE is None
+        ref_c = nnf.stem_conv_bn_act(x, conv_a, bn_a)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, ref_a) and torch.equal(out_b, ref_b) and torch.equal(out_c, ref_c)

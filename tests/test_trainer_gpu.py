@@ -88,3 +88,18 @@ def test_cps_steps_with_the_ema_codebook_extension():
         torch.cuda.synchronize()
         sums.append(torch.stack([p.detach().double().sum() for m in tr.models for p in m.parameters()]).cpu())
     assert torch.equal(sums[0], sums[1])
+
+
+def test_shared_stem_patches_change_nothing():
+    """The step unfolds each batch once for its six stems (nnf.stem_share_*): parameters after two steps are bit-identical
+    to unfolding in every forward."""
+    from vq_seg_amd import _hip
+    res = []
+    for share in (1, 0):
+        _hip.lib()
+        _hip.PY_OPTS["py_stem_share"] = share
+        try:
+            res.append(_run(True, "v1", True)[1])
+        finally:
+            _hip.PY_OPTS.pop("py_stem_share", None)
+    assert torch.equal(res[0], res[1])

@@ -434,12 +434,39 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 template <typename T, int VC>
 __device__ __forceinline__ void ldc(const T* p, long i, float (&v)[VecN<T>::N]) {
     if constexpr (VC == 1) v[0] = ld(p, i);
-    else ldv(p, i, v);
+    else if constexpr (VC == 3) {                          // the 3-class logits: one pixel per thread, three scalar accesses
+#pragma unroll
+        for (int e = 0; e < 3; ++e) v[e] = ld(p, i + e);
+    } else ldv(p, i, v);
 }
 template <typename T, int VC>
 __device__ __forceinline__ void stc(T* p, long i, const float (&v)[VecN<T>::N]) {
     if constexpr (VC == 1) st(p, i, v[0]);
-    else stv(p, i, v);
+    else if constexpr (VC == 3) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) st(p, i + e, v[e]);
+    } else stv(p, i, v);
+}
+
+// flat index -> (channel group, x, y, image): 32-bit divisions whenever the index fits (it does for every tensor of the
+// model: 64-bit integer division costs more ALU time than these copy-like kernels spend on memory)
+__device__ __forceinline__ void split_nhwc(long i, int cv, int W, int H, int& c, int& w, int& h, int& n) {
+    if (i < (1L << 31)) {
+        unsigned u = (unsigned)i;
+        c = (int)(u % (unsigned)cv);
+        u /= (unsigned)cv;
+        w = (int)(u % (unsigned)W);
+        u /= (unsigned)W;
+        h = (int)(u % (unsigned)H);
+        n = (int)(u / (unsigned)H);
+    } else {
+        c = (int)(i % cv);
+        long t = i / cv;
+        w = (int)(t % W);
+        t /= W;
+        h = (int)(t % H);
+        n = (int)(t / H);
+    }
 }
 
 template <typename T, int VC>
@@ -449,12 +476,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
     const int cv = C / VC;
     const long total = (long)N * Ho * Wo * cv;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % cv) * VC;
-        long t = i / cv;
-        const int ow = (int)(t % Wo);
-        t /= Wo;
-        const int oh = (int)(t % Ho);
-        const int n = (int)(t / Ho);
+        int c, ow, oh, n;
+        split_nhwc(i, cv, Wo, Ho, c, ow, oh, n);
+        c *= VC;
         float best[V];
         unsigned char bpos[V];
 #pragma unroll
@@ -495,12 +519,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const unsigned cha
     const int cv = C / VC;
     const long total = (long)N * H * W * cv;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % cv) * VC;
-        long t = i / cv;
-        const int iw = (int)(t % W);
-        t /= W;
-        const int ih = (int)(t % H);
-        const int n = (int)(t / H);
+        int c, iw, ih, n;
+        split_nhwc(i, cv, W, H, c, iw, ih, n);
+        c *= VC;
         float acc[V];
 #pragma unroll
         for (int e = 0; e < VC; ++e) acc[e] = 0.0f;
@@ -546,12 +567,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     const int cv = C / VC;
     const long total = (long)N * H * W * cv;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % cv) * VC;
-        long t = i / cv;
-        const int iw = (int)(t % W);
-        t /= W;
-        const int ih = (int)(t % H);
-        const int n = (int)(t / H);
+        int c, iw, ih, n;
+        split_nhwc(i, cv, W, H, c, iw, ih, n);
+        c *= VC;
         float acc[V];
 #pragma unroll
         for (int e = 0; e < VC; ++e) acc[e] = 0.0f;
@@ -619,12 +637,9 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__
     const int cv = C / VC;
     const long total = (long)N * Ho * Wo * cv;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % cv) * VC;
-        long t = i / cv;
-        const int ow = (int)(t % Wo);
-        t /= Wo;
-        const int oh = (int)(t % Ho);
-        const int n = (int)(t / Ho);
+        int c, ow, oh, n;
+        split_nhwc(i, cv, Wo, Ho, c, ow, oh, n);
+        c *= VC;
         int h0, h1, w0, w1;
         float lh, lw;
         bil_src(oh, H, Ho, align, h0, h1, lh);
@@ -651,13 +666,10 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
     const long total = (long)N * H * W * cv;
     const int rh = (Ho + H - 1) / H + 1, rw = (Wo + W - 1) / W + 1;       // search radius in output pixels
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % cv) * VC;
-        long t = i / cv;
-        const int iw = (int)(t % W);
-        t /= W;
-        const int ih = (int)(t % H);
-        const int n = (int)(t / H);
-        const int ohc = (int)(((long)ih * Ho) / H), owc = (int)(((long)iw * Wo) / W);
+        int c, iw, ih, n;
+        split_nhwc(i, cv, W, H, c, iw, ih, n);
+        c *= VC;
+        const int ohc = (int)(((unsigned)ih * (unsigned)Ho) / (unsigned)H), owc = (int)(((unsigned)iw * (unsigned)Wo) / (unsigned)W);
         float acc[V];
 #pragma unroll
         for (int e = 0; e < VC; ++e) acc[e] = 0.0f;
@@ -840,15 +852,15 @@ template <typename TO>
 __global__ __launch_bounds__(256) void im2col_stem7_kernel(const float* __restrict__ x, int N, int H, int W, int stride, int pad,
                                                            int reflect, int Ho, int Wo, int Kp, TO* __restrict__ out) {
     constexpr int KW = 7, CIN = 3, K = 147;
-    const int cpr = Kp / 8;                                 // 8-column chunks per row
-    const long total = (long)N * Ho * Wo * cpr;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const unsigned cpr = Kp / 8;                            // 8-column chunks per row
+    const unsigned total = (unsigned)N * Ho * Wo * cpr;     // < 2^32 (checked by the launcher): 32-bit index arithmetic --
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {   // 64-bit divisions cost more than the copy
         const int ch = (int)(i % cpr);
-        long t = i / cpr;
-        const int ow = (int)(t % Wo);
-        t /= Wo;
-        const int oh = (int)(t % Ho);
-        const int n = (int)(t / Ho);
+        unsigned t = i / cpr;
+        const int ow = (int)(t % (unsigned)Wo);
+        t /= (unsigned)Wo;
+        const int oh = (int)(t % (unsigned)Ho);
+        const int n = (int)(t / (unsigned)Ho);
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -866,7 +878,7 @@ __global__ __launch_bounds__(256) void im2col_stem7_kernel(const float* __restri
                 if (ih >= 0 && ih < H && iw >= 0 && iw < W) v[e] = x[(((long)n * H + ih) * W + iw) * CIN + ci];
             }
         }
-        TO* dst = out + i * 8;
+        TO* dst = out + (size_t)i * 8;
         if constexpr (sizeof(TO) == 2) {
             u32x4 r;
 #pragma unroll
@@ -890,12 +902,9 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const T* __restrict__
     const long total = (long)N * H * W * cv;
     const int Hp = H + 2, Wp = W + 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % cv) * VC;
-        long t = i / cv;
-        const int w = (int)(t % W);
-        t /= W;
-        const int h = (int)(t % H);
-        const int n = (int)(t / H);
+        int c, w, h, n;
+        split_nhwc(i, cv, W, H, c, w, h, n);
+        c *= VC;
         // padded rows mapping to h: h+1 always; 0 if h == 1; Hp-1 if h == H-2
         int hs[3], ws[3], nh = 0, nw = 0;
         hs[nh++] = h + 1;
@@ -1054,6 +1063,7 @@ hipError_t launch_bilinear(int bf16, int backward, const void* src, int N, int H
         else bilinear_t<__bf16, 1>(backward, src, N, H, W, C, Ho, Wo, align, dst, st_);
     } else {
         if (C % 4 == 0) bilinear_t<float, 4>(backward, src, N, H, W, C, Ho, Wo, align, dst, st_);
+        else if (C == 3) bilinear_t<float, 3>(backward, src, N, H, W, C, Ho, Wo, align, dst, st_);
         else bilinear_t<float, 1>(backward, src, N, H, W, C, Ho, Wo, align, dst, st_);
     }
     return hipGetLastError();
@@ -1087,7 +1097,7 @@ hipError_t launch_reduce_partials(const float* partial, long n_blocks, long n, f
 
 hipError_t launch_im2col_stem(int out_bf16, const float* x, int N, int H, int W, int Cin, int KH, int KW, int stride, int pad,
                               int reflect, int Ho, int Wo, int Kp, void* out, hipStream_t st_) {
-    if (KH == 7 && KW == 7 && Cin == 3 && Kp % 8 == 0) {
+    if (KH == 7 && KW == 7 && Cin == 3 && Kp % 8 == 0 && (long)N * Ho * Wo * (Kp / 8) < (1L << 31)) {
         const unsigned g8 = grid_for((long)N * Ho * Wo * (Kp / 8));
         if (out_bf16)
             hipLaunchKernelGGL((im2col_stem7_kernel<__bf16>), dim3(g8), dim3(256), 0, st_, x, N, H, W, stride, pad, reflect, Ho, Wo, Kp,

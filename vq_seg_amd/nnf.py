@@ -10,6 +10,7 @@ Every function here has exactly one implementation; CPU tensors are refused (no 
 from __future__ import annotations
 
 from typing import Optional
+import weakref
 
 import torch
 
@@ -356,6 +357,41 @@ def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None, l
                             link_in, link_out, link_x)
 
 
+# Within ONE training step the same image tensor goes through several stems: both networks of a CPS pair see the same
+# batches, and the unlabelled batch passes twice (pseudo-label forward, training forward).  The patch matrix depends on the
+# image alone, so a caller may open a sharing scope for the step (trainer.CPSTrainer does): forwards on the SAME tensor
+# object (same version) inside the scope reuse one matrix.  Nothing is kept across scopes -- every step's images are
+# unfolded in that step.
+_STEM_SHARE = None
+
+
+def stem_share_begin():
+    global _STEM_SHARE
+    _STEM_SHARE = []
+
+
+def stem_share_end():
+    global _STEM_SHARE
+    _STEM_SHARE = None
+
+
+def _shared_stem_patches(x, cfg, make):
+    if _STEM_SHARE is None:
+        return make()
+    cur = torch.cuda.current_stream(x.device)
+    for ref, ver, key, patches, ev, st in _STEM_SHARE:
+        if ref() is x and ver == x._version and key == cfg:
+            if st != cur:                                   # produced on the other network's stream
+                cur.wait_event(ev)
+                patches.record_stream(cur)
+            return patches
+    patches = make()
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    _STEM_SHARE.append((weakref.ref(x), x._version, cfg, patches, ev, cur))
+    return patches
+
+
 def stem_conv_bn_act(x, conv, bn):
     """7x7 stride-2 stem on a 3-channel fp32 image: im2col patch matrix (zero / reflect padding) + 1x1 MFMA conv."""
     if not x.is_cuda:
@@ -368,10 +404,15 @@ def stem_conv_bn_act(x, conv, bn):
     ho, wo = _out_size(h, kh, s, p), _out_size(w, kw, s, p)
     kp = (kh * kw * cin + 31) // 32 * 32
     dt = act_dtype()
-    patches = torch.empty((n, ho, wo, kp), dtype=dt, device=x.device)
-    with torch.cuda.device(x.device):
-        _check(lib().vqseg_im2col_f(int(dt == torch.bfloat16), xr.data_ptr(), n, h, w, cin, kh, kw, s, p, int(reflect), ho, wo, kp,
-                                    patches.data_ptr(), _stream()), "vqseg_im2col_f")
+
+    def make():
+        out = torch.empty((n, ho, wo, kp), dtype=dt, device=x.device)
+        with torch.cuda.device(x.device):
+            _check(lib().vqseg_im2col_f(int(dt == torch.bfloat16), xr.data_ptr(), n, h, w, cin, kh, kw, s, p, int(reflect), ho, wo, kp,
+                                        out.data_ptr(), _stream()), "vqseg_im2col_f")
+        return out
+
+    patches = _shared_stem_patches(x, (dt, kh, kw, s, p, reflect), make)
     _sink_use(conv.weight, bn.weight, bn.bias)
     return _ConvBNAct.apply(_nchw(patches), None, None, conv.weight, bn.weight, bn.bias, bn, 1, 0, False, True,
                             (kh, kw, cin, s, p, reflect, h, w), not bn.training and not torch.is_grad_enabled())

@@ -311,6 +311,22 @@ class CPSTrainer:
         m1, m2 = self.models
         for b in self.buckets:
             b.zero()
+        if l_input.is_cuda:
+            # one layout conversion per batch instead of one per forward, and one stem patch matrix per batch for the six
+            # forwards of the step (nnf.stem_share_*): the two networks and the two passes over the unlabelled batch see
+            # the same images
+            l_input = l_input.contiguous(memory_format=torch.channels_last)
+            ul_input = ul_input.contiguous(memory_format=torch.channels_last)
+            if nnf.py_opt("py_stem_share", 1):
+                nnf.stem_share_begin()
+        try:
+            return self._step(l_input, l_target, ul_input, epoch_frac)
+        finally:
+            nnf.stem_share_end()
+
+    def _step(self, l_input, l_target, ul_input, epoch_frac):
+        cfg = self.cfg
+        m1, m2 = self.models
         with torch.no_grad():                                           # pseudo labels from eval passes
             m1.eval(); m2.eval()
             o1, o2 = self._fwd_pair((ul_input,), (ul_input,))
