@@ -490,11 +490,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
         a_chunk[i] = slot ^ ((trow >> 1) & 7);           // channel chunk (8 bf16) this lane fetches for its slot
     }
     // ---- this lane's B rows (weights): wave w covers tile rows [w * BN/NW, (w+1) * BN/NW)
-    int b_row[B_INSTR], b_chunk[B_INSTR];
+    // byte offset of (row, swizzled slot) inside the packed image, ~0u: no such row (zero page); the (tap, chunk) part of the
+    // address is uniform and lives in scalar registers
+    unsigned w_off[B_INSTR];
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
-        b_row[i] = B_ROWS_PER_WAVE * wave + 8 * i + (lane >> 3);
-        b_chunk[i] = slot ^ ((b_row[i] >> 1) & 7);
+        const int b_row = B_ROWS_PER_WAVE * wave + 8 * i + (lane >> 3);
+        const int co = co0 + b_row;
+        const bool ok = co < p.Cout && b_row < B_ROWS_PER_WAVE * (wave + 1);
+        w_off[i] = ok ? ((unsigned)co * (unsigned)(p.KH * p.KW * ((p.Cin + 31) / 32 * 32)) + (unsigned)((slot ^ ((b_row >> 1) & 7)) << 3)) * 2u
+                      : ~0u;
     }
 
     f32x16 acc[MT][NTT];
@@ -509,7 +514,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
     const int cin_p = (p.Cin + 31) / 32 * 32;
     const int chunks_per_tap = p.Cin / BK;
     const int n_stage = n_taps * chunks_per_tap;
-    const long w_row = (long)n_taps * cin_p;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
     long a_pix[A_INSTR];                                   // pixel offset of this lane's rows for the current tap, -1 = zero
@@ -551,13 +555,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
             const long off = a_pix[i] * csrc + cbase + a_chunk[i] * 8;
             glds16(a_pix[i] >= 0 ? src + off * 2 : zero, As + (A_INSTR * wave + i) * 1024);
         }
+        const char* wbase = reinterpret_cast<const char*>(p.w_hi) + ((long)tap * cin_p + ci0) * 2;             // uniform
 #pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            const int co = co0 + b_row[i];
-            const bool ok = co < p.Cout && b_row[i] < B_ROWS_PER_WAVE * (wave + 1);
-            const unsigned short* wp = p.w_hi + (long)co * w_row + (long)tap * cin_p + ci0 + b_chunk[i] * 8;
-            glds16(ok ? reinterpret_cast<const char*>(wp) : zero, Bs + (B_ROWS_PER_WAVE * wave + 8 * i) * 128);
-        }
+        for (int i = 0; i < B_INSTR; ++i)
+            glds16(w_off[i] != ~0u ? wbase + w_off[i] : zero, Bs + (B_ROWS_PER_WAVE * wave + 8 * i) * 128);
     };
 
     auto compute = [&](int buf) {
@@ -664,6 +665,9 @@ static void launch_glds_t(const ConvArgs& a, hipStream_t st) {
 //   of the current chunk) + a ring of NBW weight stages; counted vmcnt, one raw barrier per tap.
 // Rows are unpadded 128 B with the 16-byte chunks XOR-swizzled through the DMA source address.
 // =====================================================================================================
+#ifndef CONV_SETPRIO
+#define CONV_SETPRIO 0            // 1: s_setprio pair around every MFMA cluster of the patch kernel (measured: see DESIGN 4.2)
+#endif
 struct TileRows {                                           // tile row -> output pixel row of a 2-D pixel tile
     long base;                                              // (n * H + oh0) * W + ow0
     int tw_shift, W;
@@ -721,12 +725,17 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     const int co0 = co_chunk * BN;
 
     const int slot = lane & (ROWB / 16 - 1), lrow = lane / (ROWB / 16);     // 16-byte slot and row of this lane in a DMA instruction
-    // ---- this lane's weight rows
-    int b_chunk[WI];
+    // ---- this lane's weight rows: byte offset of (row, swizzled 16-byte slot) inside the packed image; the (tap, chunk) part of
+    // the address is uniform and stays in scalar registers (one 32-bit VGPR per DMA instruction instead of a 64-bit pointer
+    // per instruction and tap).  Rows past Cout (tiles narrower than the DMA granule) re-read the last row: their outputs are
+    // never stored.
+    unsigned w_off[WI];
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
         const int row = RPI * (wave * WI + i) + lrow;
-        b_chunk[i] = slot ^ swz(row);
+        int co = co0 + row;
+        co = co < p.Cout ? co : p.Cout - 1;
+        w_off[i] = ((unsigned)co * (unsigned)(9 * ((p.Cin + 31) / 32 * 32)) + (unsigned)((slot ^ swz(row)) << 3)) * 2u;
     }
     // ---- MFMA A rows: tile row -> patch pixel (tap (0, 0))
     int a_pp[MT];
@@ -747,7 +756,6 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     const int cin_p = (p.Cin + 31) / 32 * 32;
     const int n_chunks = p.Cin / CK;
     const int n_stage = n_chunks * 9;
-    const long w_row = 9L * cin_p;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
     // patch rows: instruction i (0..PI-1) of this wave covers patch pixels RPI * (wave + NW * i) .. + RPI - 1.  The row's
@@ -773,13 +781,9 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     };
     auto issue_weights = [&](int chunk, int tap, int wslot) {
         char* Bs = wring + wslot * W_BYTES;
+        const char* sbase = reinterpret_cast<const char*>(p.w_hi) + ((long)tap * cin_p + chunk * CK) * 2;      // uniform
 #pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const int row = RPI * (wave * WI + i) + lrow;
-            const int co = co0 + row;
-            const unsigned short* wp = p.w_hi + (long)co * w_row + (long)tap * cin_p + chunk * CK + b_chunk[i] * 8;
-            glds16(co < p.Cout ? reinterpret_cast<const char*>(wp) : zero, Bs + (wave * WI + i) * 1024);
-        }
+        for (int i = 0; i < WI; ++i) glds16(sbase + w_off[i], Bs + (wave * WI + i) * 1024);
     };
     auto compute = [&](int chunk, int tapoff, int wslot) {
         const char* Ps = patch0 + (chunk & 1) * PATCH_BYTES;
@@ -797,11 +801,17 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
                 const int row = (wn * NT + b) * 32 + r;
                 bfr[b] = *reinterpret_cast<const bf16x8*>(Bs + row * ROWB + (((kk * 2 + h) ^ swz(row)) << 4));
             }
+#if CONV_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+#if CONV_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
     };
 
@@ -867,6 +877,9 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
 static int g_patch_min_wgs = 256;
 static int g_patch_pair = 0;                                // 1: Cout chunks of a pixel tile share an XCD (1-D launch, see the kernel)
 static int g_patch_wide = 0;                                // 1: take the 256-channel tile where it fills the chip (measured 3-5 % slower than the unrolled 128 tile)
+#ifndef SHORTK_MINW
+#define SHORTK_MINW 4               // waves per SIMD the short-K tiles are compiled for (4: 128 registers, the epilogue spills ~18)
+#endif
 static int g_short_k_small = 1;                             // K loops of up to this many stages take the 128x128 tile at 4 waves/SIMD
 static int g_short_k_single = 8;                            // K loops of up to this many stages: single-buffered 128x128 tile, 4 workgroups/CU
 static int g_patch_unroll = 1;                              // 128-channel tile: tap loop unrolled
@@ -1020,8 +1033,8 @@ hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
         const long t256 = ((M + 255) / 256) * ((a.Cout + 255) / 256), t256x128 = ((M + 255) / 256) * ((a.Cout + 127) / 128);
         (void)t256;
         const int n_stage = a.KH * a.KW * (a.Cin / 64);
-        if (n_stage <= g_short_k_small && bn == 128) launch_glds_t<128, 128, 4, 2, 4>(a, st);
-        else if (n_stage <= g_short_k_single && bn == 128) launch_glds_t<128, 128, 4, 1, 4>(a, st);   // epilogue-bound: more, independent workgroups per CU
+        if (n_stage <= g_short_k_small && bn == 128) launch_glds_t<128, 128, 4, 2, SHORTK_MINW>(a, st);
+        else if (n_stage <= g_short_k_single && bn == 128) launch_glds_t<128, 128, 4, 1, SHORTK_MINW>(a, st);   // epilogue-bound: more, independent workgroups per CU
         else if (a.Cout % 128 == 0 && t256x128 >= 512) launch_glds_t<256, 128, 8, 3>(a, st);
         else if (bn == 128) launch_glds_t<128, 128, 4, 2>(a, st);
         else if (bn == 64) launch_glds_t<128, 64, 4, 3>(a, st);

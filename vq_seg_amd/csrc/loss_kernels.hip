@@ -375,8 +375,21 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const DiceArgs a, double*
     }
     const int Q = 2 * a.C + 2;
     double* out = partial + ((long)b * gridDim.x + blockIdx.x) * Q;
-    for (int q = 0; q < Q; ++q) {
-        red[threadIdx.x] = q < a.C ? inter[q] : q < 2 * a.C ? sets[q - a.C] : ce[q - 2 * a.C];
+    double vals[2 * DMAXC + 2];                                 // [inter | sets | ce] at compile-time positions (registers, no scratch)
+#pragma unroll
+    for (int c = 0; c < DMAXC; ++c) {
+        vals[c] = inter[c];
+        vals[DMAXC + c] = sets[c];
+    }
+    vals[2 * DMAXC] = ce[0];
+    vals[2 * DMAXC + 1] = ce[1];
+#pragma unroll
+    for (int qq = 0; qq < 2 * DMAXC + 2; ++qq) {
+        // slot qq of the padded layout is output q of the dense one (classes >= C are skipped)
+        const int cls = qq < DMAXC ? qq : qq < 2 * DMAXC ? qq - DMAXC : 0;
+        if (qq < 2 * DMAXC && cls >= a.C) continue;
+        const int q = qq < DMAXC ? qq : qq < 2 * DMAXC ? a.C + cls : 2 * a.C + (qq - 2 * DMAXC);
+        red[threadIdx.x] = vals[qq];
         __syncthreads();
         for (int m = 128; m >= 1; m >>= 1) {
             if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
