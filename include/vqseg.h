@@ -47,6 +47,8 @@ const char* vqseg_kernel_name(const char* entry_point);
  *                                   holds (default 8; 4 measured equal within 2 % on every benchmark shape)
  *   "conv_xcd_pair"                 implicit-GEMM layers with 2..value Cout chunks launch 1-D so that the chunks of an
  *                                   M tile run on the same XCD and share the input rows through its L2 (default 4; 0: off)
+ *   "conv3x3_patch_chunk_stage"     1 (default): 3x3 layers with 32-channel K chunks and <= 64 outputs (or 32 inputs) load all nine
+ *                                   taps' weights with the patch -- one wait and barrier per chunk instead of per tap; 0: tap ring
  *   "conv3x3_patch_xcd_pair"        1: the Cout chunks of a pixel tile are dispatched onto the same XCD (default 0:
  *                                   measured equal; the kernel does not wait on HBM for its patches)
  *   "conv_short_k_small_tile", "conv_short_k_single_buffer"   K loops of up to that many 64-channel stages take the

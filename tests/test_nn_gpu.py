@@ -186,6 +186,8 @@ PATCH_CASES = [
     # 32-channel chunks (channel counts that are not multiples of 64)
     (2, 32, 0, 32, 16, 32, False), (1, 96, 0, 128, 16, 16, True), (2, 32, 0, 64, 8, 32, True), (1, 32, 32, 128, 16, 32, False),
     (2, 160, 0, 32, 8, 32, False),
+    # chunk stages (all nine taps' weights with the patch): single chunk x 128 / 64 / 32 outputs, several chunks x 64 / 32
+    (2, 32, 0, 128, 16, 32, False), (1, 32, 0, 256, 8, 32, True), (1, 96, 0, 64, 16, 16, False), (2, 32, 64, 32, 16, 32, True),
 ]
 
 

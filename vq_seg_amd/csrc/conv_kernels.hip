@@ -693,11 +693,18 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     constexpr int W_BYTES = W_ROWS * ROWB;
     constexpr int WI = W_BYTES / 1024 / NW;                // weight DMA instructions per wave and tap
     static_assert(W_BYTES % (1024 * NW) == 0 && (CK == 64 || CK == 32), "weight tile must split evenly over the waves");
+    // NBW == 0, "chunk stages": the weights of ALL nine taps of a chunk travel with its patch (one wait + one barrier per
+    // chunk, none per tap).  For tiles whose taps are one or two K steps long a tap-by-tap ring only adds a DMA latency and a
+    // barrier to every tap; the whole tap set of such a tile is small (9 x BN x CK x 2 B).
+    constexpr bool CHUNK_STAGE = NBW == 0;
+    constexpr int WT_BYTES = CHUNK_STAGE ? BN * ROWB : W_BYTES;             // LDS bytes per tap
+    constexpr int WCI = 9 * BN * ROWB / 1024, WCW = (WCI + NW - 1) / NW;    // chunk-stage weight DMA instructions: all / per wave
+    static_assert(!CHUNK_STAGE || (BN * ROWB) % 1024 == 0, "a tap's weight tile must be whole DMA instructions");
     auto swz = [](int row) { return CK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const patch0 = smem;
-    char* const wring = smem + 2 * PATCH_BYTES;
+    char* const wring = smem + ((CHUNK_STAGE && p.Cin / CK == 1) ? 1 : 2) * PATCH_BYTES;     // single-chunk layers: one patch buffer
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -785,9 +792,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < WI; ++i) glds16(sbase + w_off[i], Bs + (wave * WI + i) * 1024);
     };
-    auto compute = [&](int chunk, int tapoff, int wslot) {
+    auto compute = [&](int chunk, int tapoff, const char* Bs) {
         const char* Ps = patch0 + (chunk & 1) * PATCH_BYTES;
-        const char* Bs = wring + wslot * W_BYTES;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             bf16x8 af[MT], bfr[NT];
@@ -815,6 +821,39 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
         }
     };
 
+    if constexpr (CHUNK_STAGE) {
+        auto issue_chunk = [&](int chunk) {
+#pragma unroll
+            for (int i = 0; i < PI; ++i) issue_patch(chunk, i);
+            char* wb = wring + (chunk & 1) * (9 * WT_BYTES);
+#pragma unroll
+            for (int i = 0; i < WCW; ++i) {
+                const int j = wave * WCW + i;                          // wave-uniform
+                if (j < WCI) {
+                    const int tap = j / (BN * ROWB / 1024), rg = j % (BN * ROWB / 1024);
+                    const int row = RPI * rg + lrow;
+                    int co = co0 + row;
+                    co = co < p.Cout ? co : p.Cout - 1;                // outputs of such rows are never stored
+                    const unsigned short* wp = p.w_hi + (long)co * (9L * cin_p) + (long)tap * cin_p + chunk * CK + ((slot ^ swz(row)) << 3);
+                    glds16(reinterpret_cast<const char*>(wp), wb + j * 1024);
+                }
+            }
+        };
+        issue_chunk(0);
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): this chunk's patch and weights have landed
+            __builtin_amdgcn_s_barrier();                              // ... for every wave; the other buffers are free
+            if (chunk + 1 < n_chunks) issue_chunk(chunk + 1);
+            const char* wb = wring + (chunk & 1) * (9 * WT_BYTES);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) compute(chunk, (tap / 3) * PW + tap % 3, wb + tap * WT_BYTES);
+        }
+        __syncthreads();
+        const long M = (long)p.N * p.H * p.W;
+        const TileRows rows{((long)n * p.H + oh0) * p.W + ow0, tw_shift, p.W};
+        conv_epilogue<TBM, BN, false, MT, NT, NT, NW * 64, TileRows>(acc, p, smem, M, (long)tile_id * TBM, co0, wm, wn, r, h, tid, rows);
+        return;
+    }
     // ---- prologue: whole patch of chunk 0, weights of the first NBW - 1 stages
 #pragma unroll
     for (int i = 0; i < PI; ++i) issue_patch(0, i);
@@ -863,7 +902,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
             // NBW == 4: the slot being refilled was last read a whole stage ago, so the DMA issue can follow this stage's
             // MFMAs (which then start right behind the barrier) instead of preceding them
             if (NBW < 4) issue_next();
-            compute(chunk, (tap / 3) * PW + tap % 3, wslot);
+            compute(chunk, (tap / 3) * PW + tap % 3, wring + wslot * W_BYTES);
             if (NBW >= 4) issue_next();
             wslot = wslot == NBW - 1 ? 0 : wslot + 1;
         }
@@ -876,6 +915,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
 
 static int g_patch_min_wgs = 256;
 static int g_patch_pair = 0;                                // 1: Cout chunks of a pixel tile share an XCD (1-D launch, see the kernel)
+static int g_patch_chunk_stage = 1;                         // 32-channel chunks: chunk stages instead of the per-tap weight ring
 static int g_patch_wide = 0;                                // 1: take the 256-channel tile where it fills the chip (measured 3-5 % slower than the unrolled 128 tile)
 #ifndef SHORTK_MINW
 #define SHORTK_MINW 4               // waves per SIMD the short-K tiles are compiled for (4: 128 registers, the epilogue spills ~18)
@@ -915,6 +955,11 @@ int conv_set_option(const char* key, int value) {
         g_patch_pair = value ? 1 : 0;
         return prev;
     }
+    if (key && !strcmp(key, "conv3x3_patch_chunk_stage")) {
+        const int prev = g_patch_chunk_stage;
+        g_patch_chunk_stage = value ? 1 : 0;
+        return prev;
+    }
     if (key && !strcmp(key, "conv3x3_patch_wide_tile")) {
         const int prev = g_patch_wide;
         g_patch_wide = value ? 1 : 0;
@@ -938,6 +983,10 @@ static void launch_patch_t(const ConvArgs& a, hipStream_t st) {
     constexpr int ROWB = CK * 2, RPI = 1024 / ROWB, PI = (344 + RPI * 8 - 1) / (RPI * 8);
     constexpr int W_ROWS = (BN * ROWB >= 8 * 1024) ? BN : 8 * 1024 / ROWB;
     size_t lds = 2 * (size_t)PI * 8 * 1024 + (size_t)NBW * W_ROWS * ROWB;
+    if (NBW == 0) {                                          // chunk stages: one or two (patch + nine taps of weights) buffers
+        const int nb = a.Cin / CK > 1 ? 2 : 1;
+        lds = (size_t)nb * ((size_t)PI * 8 * 1024 + 9 * (size_t)BN * ROWB);
+    }
     const size_t out_tile = (size_t)256 * (BN + 8) * 2;
     if (out_tile > lds) lds = out_tile;
     const int tw = (a.W % 32 == 0) ? 32 : 16, th = 256 / tw;
@@ -1009,7 +1058,11 @@ hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
         else if (bn == 64) launch_t<64, true, 32>(a, st);
         else launch_t<32, true, 32>(a, st);
     } else if (!k64 && conv3x3_patch_ok(a)) {                // 32-channel chunks (the last decoder level and its gradients)
-        if (a.Cout == 64) launch_patch_t<64, 3, true, 32>(a, st);
+        // taps of one or two K steps: all nine taps' weights ride with the patch (chunk stages) where that fits LDS
+        if (g_patch_chunk_stage && a.Cout == 64) launch_patch_t<64, 0, true, 32>(a, st);
+        else if (g_patch_chunk_stage && a.Cout == 32) launch_patch_t<32, 0, true, 32>(a, st);
+        else if (g_patch_chunk_stage && a.Cin == 32) launch_patch_t<128, 0, true, 32>(a, st);
+        else if (a.Cout == 64) launch_patch_t<64, 3, true, 32>(a, st);
         else if (a.Cout == 32) launch_patch_t<32, 3, true, 32>(a, st);
         else launch_patch_t<128, 3, true, 32>(a, st);
     } else if (k64 && conv3x3_patch_ok(a)) {
