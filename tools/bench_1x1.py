@@ -12,7 +12,8 @@ LAYERS = [("l1.conv1", 256, 64, 128, 1, 1, 0), ("l1.conv3", 64, 256, 128, 1, 1, 
           ("l2.conv1", 512, 128, 64, 1, 1, 0), ("l2.conv3", 128, 512, 64, 1, 1, 0), ("l2.down", 256, 512, 128, 1, 2, 0),
           ("l3.conv1", 1024, 256, 32, 1, 1, 0), ("l3.conv3", 256, 1024, 32, 1, 1, 0), ("l4.conv1", 2048, 512, 16, 1, 1, 0),
           ("l4.conv3", 512, 2048, 16, 1, 1, 0), ("l1.conv2", 64, 64, 128, 3, 1, 1), ("l4.conv2", 512, 512, 16, 3, 1, 1),
-          ("l2.conv2s2", 128, 128, 128, 3, 2, 1), ("dec4.0", 192, 32, 256, 3, 1, 1), ("dec4.1", 32, 32, 256, 3, 1, 1)]
+          ("l2.conv2s2", 128, 128, 128, 3, 2, 1), ("dec4.0", 192, 32, 256, 3, 1, 1), ("dec4.1", 32, 32, 256, 3, 1, 1),
+          ("dec4.0 dgA", 32, 128, 256, 3, 1, 1), ("dec4.0 dgB", 32, 64, 256, 3, 1, 1), ("dec3.1", 128, 128, 128, 3, 1, 1)]
 st = torch.cuda.current_stream().cuda_stream
 SETS = 4
 for name, cin, cout, hw, k, s, p in LAYERS:
