@@ -1,0 +1,4 @@
+"""`import loss` of the reference trainer -> vq_seg_amd.loss (see compat/_vqseg_compat.py)."""
+from _vqseg_compat import bind as _bind
+
+_bind(__name__, "vq_seg_amd.loss")

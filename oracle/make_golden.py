@@ -393,6 +393,52 @@ def gen_unet(ref):
         json.dump({k: list(v) for k, v in shapes.items()}, f)
 
 
+# ---------------------------------------------------------------- CPS iterations of the trainers (SURVEY 8c fixture (9))
+def _ref_ns(ref):
+    import types
+    return types.SimpleNamespace(models=ref.models, make_loss=ref.loss.make_loss, Measurement=ref.measurement.Measurement,
+                                 CosineAnnealingLR=ref.lr_schedulers.CosineAnnealingLR)
+
+
+def gen_cps(ref):
+    """Two iterations of the trainers' loop bodies on the reference's own modules (tests/cps_loop.py restates the loop
+    body once; the trainer files are not importable): v1 = deprecated/train_with_test_pt_pseudo_entropy_reg.py:141-203 with
+    backward + Adam; v2 = train_vqreptunet1x1v2.py:137-196 forward terms only (its backward raises on fp32)."""
+    from tests import cps_loop
+    dev = torch.device("cpu")
+    for version, backward in ((1, True), (2, False)):
+        outs = cps_loop.run_iterations(_ref_ns(ref), version, dev, n_iters=2, backward=backward, to_cfg=ref.AttrDict,
+                                       prepare=prepare_model)
+        arrays = {}
+        for i, o in enumerate(outs):
+            for k, v in o.items():
+                if k.startswith("grad_none"):
+                    arrays[f"it{i}/{k}"] = np.array(v)
+                elif k.startswith("param/"):
+                    arrays[k] = v
+                elif isinstance(v, float):
+                    arrays[f"it{i}/{k}"] = np.array(v, dtype=np.float64)
+                else:
+                    arrays[f"it{i}/{k}"] = v
+        meta = dict(version=version, size=cps_loop.SIZE, batch=cps_loop.BATCH, seeds=list(cps_loop.SEEDS), train=cps_loop.TRAIN,
+                    backward=backward, n_iters=2,
+                    source=("deprecated/train_with_test_pt_pseudo_entropy_reg.py:141-203" if version == 1 else
+                            "train_vqreptunet1x1v2.py:137-196 (forward terms; backward raises in the reference, q10)") +
+                           " restated in tests/cps_loop.py, driven on the reference's models / loss / measurement / utils modules")
+        save(f"cps_iter_v{version}", meta, **arrays)
+
+
+def gen_curve(ref):
+    """The CPU side of the mIoU-parity run: tests/cps_loop.py::run_curve on the reference's modules (v1 recipe)."""
+    from tests import cps_loop
+    import time
+    t0 = time.time()
+    out = cps_loop.run_curve(_ref_ns(ref), torch.device("cpu"), to_cfg=ref.AttrDict, prepare=prepare_model)
+    print(f"  curve: {time.time() - t0:.0f}s  test mIoU {out['test_miou']}")
+    save("cps_curve_v1", dict(spec=cps_loop.CURVE, k=[0, 0, 64, 64, 64],
+                              source="tests/cps_loop.py::run_curve on the reference's modules (v1 recipe, fp32 CPU)"), **out)
+
+
 def probe(t, limit=16384, take=4096):
     """Large tensors are stored as a strided sample (fixtures stay small)."""
     flat = t.detach().reshape(-1)
@@ -410,9 +456,9 @@ def hash_shapes(shapes):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_harness.ref_modules()
-    which = set(sys.argv[1:]) or {"vq", "kmeans", "decoder", "proto", "losses", "models", "unet"}
+    which = set(sys.argv[1:]) or {"vq", "kmeans", "decoder", "proto", "losses", "models", "unet", "cps", "curve"}
     for tag, fn in (("vq", gen_vq), ("kmeans", gen_kmeans), ("decoder", gen_decoder), ("proto", gen_proto),
-                    ("losses", gen_losses), ("models", gen_models), ("unet", gen_unet)):
+                    ("losses", gen_losses), ("models", gen_models), ("unet", gen_unet), ("cps", gen_cps), ("curve", gen_curve)):
         if tag in which:
             print(f"[{tag}]")
             fn(ref)

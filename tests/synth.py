@@ -97,3 +97,16 @@ def decoder_shapes(encoder_channels, decoder_channels, prefix: str = "decoder") 
             shapes[f"{base}.1.num_batches_tracked"] = ()
         prev = co
     return shapes
+
+
+PALETTE = ((0.25, 0.20, 0.15), (0.20, 0.55, 0.25), (0.55, 0.60, 0.20))     # soil / crop / weed colours
+
+
+def blob_images(seed: int, b: int, size: int, cell: int = 16, noise: float = 0.15, num_classes: int = 3):
+    """Synthetic crop/weed batch: (images (b, 3, size, size) in [0, 1], labels (b, size, size) int64).  Every class paints its
+    blobs in one colour, plus uniform noise -- a learnable stand-in for CWFID (no dataset can travel), deterministic on any
+    machine like everything else here (`trainer.SyntheticCropWeed` is the same recipe on torch's generator)."""
+    lab = blob_labels(seed, b, size, num_classes, cell)
+    pal = torch.tensor(PALETTE[:num_classes], dtype=torch.float32)
+    img = pal[lab].permute(0, 3, 1, 2) + noise * uniform(seed + 7919, (b, 3, size, size))
+    return img.clamp(0.0, 1.0).contiguous(), lab

@@ -253,3 +253,54 @@ def test_evaluation_loop_matches_measurement_on_numpy():
     assert abs(got["test_precision"] - prec / n) < 1e-12 and abs(got["test_recall"] - rec / n) < 1e-12
     assert abs(got["test_f1score"] - f1 / n) < 1e-12
     assert np.allclose(got["test_ious"], np.round(ious / n, 5))
+
+
+def _prepared_oracle_params(version, seed, x, gt, margin, scale):
+    """oracle/make_golden.py::prepare_model on the functional oracle (the recipe test_whole_model uses)."""
+    sd = _model_params("vqreptunet1x1", seed)
+    ks = (0, 0, 512, 512, 512)
+    kw0 = dict(percent=80.0) if version == 1 else dict(th=0.7)
+    with torch.no_grad():
+        R.resnet_encoder(sd, x, True, momentum=1.0)
+        feats = R.resnet_encoder(sd, x, False)[1:]
+        for i in (2, 3, 4):
+            sd[f"codebook.{i}.codebook.embedding.weight"] = cases.codebook_from_rows(cases.rows_of(feats[i]), 512, 900 + i)
+        R.vq_unet_forward(sd, x, True, ks, gt=gt, version=version, margin=margin, scale=scale, momentum=1.0, **kw0)
+    return sd
+
+
+@pytest.mark.parametrize("version", [1, 2])
+def test_cps_iterations(version):
+    """SURVEY 8c fixture (9): oracle/cps_ref.py against two iterations of the trainers' loop bodies run on the reference's own
+    modules (v1: with backward + Adam; v2: forward terms -- the reference's v2 backward raises, q10)."""
+    from oracle.cps_ref import CPSReference
+    from tests import cps_loop
+    fx = golden_io.load(f"cps_iter_v{version}")
+    data = cps_loop.batches(2)
+    cfg = cps_loop.model_cfg(version)["params"]
+    sds = [_prepared_oracle_params(version, seed, data[0][0], data[0][1], cfg["margin"], cfg["scale"]) for seed in cps_loop.SEEDS]
+    ref = CPSReference(sds, version=version, margin=cfg["margin"], scale=cfg["scale"], lr=cps_loop.TRAIN["learning_rate"],
+                       min_lr=cps_loop.TRAIN["min_lr"], total_iters=1000, th=cps_loop.TRAIN["confidence_threshold"],
+                       drop_percent=cps_loop.TRAIN["unsup_loss_drop_percent"], proto_w=cps_loop.TRAIN["total_prototype_loss_weight"])
+    for i, (l_in, l_tg, ul_in) in enumerate(data):
+        out = ref.step(l_in, l_tg, ul_in, backward=fx.meta["backward"])
+        for key in ("loss", "sup_loss_1", "sup_loss_2", "cps_loss", "commitment_loss", "prototype_loss", "step_miou"):
+            assert out[key] == pytest.approx(float(fx[f"it{i}/{key}"]), rel=2e-5), (i, key)
+        assert out["lr"] == pytest.approx(float(fx[f"it{i}/lr"]), rel=1e-12)
+        for key in ("mask_1", "mask_2"):                       # pseudo-label masks: exact (same ATen ops on both sides)
+            assert torch.equal(out[key].to(torch.uint8), fx[f"it{i}/{key}"]), (i, key)
+        for key in ("score_1", "pred_sup_1", "pred_ul_2"):
+            close(out[key], fx[f"it{i}/{key}"], rtol=1e-3, atol=1e-4)
+    if fx.meta["backward"]:
+        for tag, p in (("m1", ref.p[0]), ("m2", ref.p[1])):
+            for key in cps_loop.PROBES:
+                want = fx[f"param/{tag}/{key}"]
+                got = golden_io.probe(p[key])
+                assert (got - want).abs().max().item() <= 1e-5 * (want.abs().max().item() + 1e-12), (tag, key)   # 0.1 x one Adam step
+            close(p["encoder.bn1.running_var"], fx[f"param/{tag}/encoder.bn1.running_var"], rtol=1e-5)
+            for key in cps_loop.PROBES:                        # gradients of the last iteration (still on the tensors)
+                want = fx[f"it1/grad/{tag}/{key}"]
+                got = golden_io.probe(p[key].grad)
+                assert ((got - want).norm() / (want.norm() + 1e-30)).item() <= 2e-3, (tag, key)
+        none = set(fx["it0/grad_none/m1"].tolist())
+        assert {f"codebook.{i}.codebook.embedding.weight" for i in (2, 3, 4)} | {"prototype_loss.embedding.weight"} == none

@@ -167,6 +167,10 @@ class CPSConfig:
     bn_eps: float = 1e-5
     bn_momentum: float = 0.1
     amp_dtype: Optional[torch.dtype] = None   # torch.bfloat16 = the ROCm-native counterpart of the reference's fp16 AMP
+    eval_amp: bool = False                    # False = the reference: the two no-grad pseudo-label forwards run OUTSIDE autocast, in
+                                              # fp32 (train_vqreptunet1x1v2.py:143-149; deprecated/train_with_test_pt_pseudo_entropy_
+                                              # reg.py:150-156); True = an all-bf16 step (a build-side speed mode, NOT the reference's)
+    keep_aux: bool = False                    # keep the step's pseudo-label masks / scores in `CPSTrainer.aux` (parity tests)
     bucket_mb: float = 64.0
     two_streams: bool = True                  # each network of the pair on its own HIP stream (see CPSTrainer.__init__)
     seed: int = 42
@@ -199,11 +203,14 @@ def score_mask(pred: torch.Tensor, pseudo: torch.Tensor, th: float = 0.7) -> tor
 
 
 class CPSTrainer:
-    def __init__(self, cfg: CPSConfig, device):
+    def __init__(self, cfg: CPSConfig, device, models: Optional[List[nn.Module]] = None):
+        """`models`: an already built (model_1, model_2) pair on `device` (fixtures with given weights); else the pair is built
+        from cfg.model as the reference trainer does (train_vqreptunet1x1v2.py:70-80)."""
         self.cfg, self.device = cfg, device
+        self.aux: Dict[str, torch.Tensor] = {}
         torch.manual_seed(cfg.seed)                      # same initial weights on every rank
-        self.models = [make_model(cfg.model).to(device), make_model(cfg.model).to(device)]
-        if cfg.init_weights:                             # train_vqreptunet1x1v2.py:73-80
+        self.models = list(models) if models is not None else [make_model(cfg.model).to(device), make_model(cfg.model).to(device)]
+        if cfg.init_weights and models is None:          # train_vqreptunet1x1v2.py:73-80
             for m in self.models:
                 init_weight([m.decoder, m.segmentation_head], nn.init.kaiming_normal_, nn.BatchNorm2d, cfg.bn_eps,
                             cfg.bn_momentum, mode="fan_in", nonlinearity="relu")
@@ -244,12 +251,13 @@ class CPSTrainer:
         self._pending_sides.add(side)
         return out
 
-    def _fwd_pair(self, a1, a2, **kw):
+    def _fwd_pair(self, a1, a2, use_amp=True, **kw):
         """model 1 on a1 = (x[, gt]) and model 2 on a2, phase by phase: encoders overlap on the two streams, the VQ phases
         run one after the other with the other stream idle (the distance kernels fill the GPU on their own, and their
-        in-stream timing -- bench.py's roofline -- then measures the kernel, not the sharing), decoders overlap again."""
+        in-stream timing -- bench.py's roofline -- then measures the kernel, not the sharing), decoders overlap again.
+        `use_amp=False`: this pair runs outside autocast whatever cfg.amp_dtype says (the pseudo-label passes)."""
         m1, m2 = self.models
-        amp = self.cfg.amp_dtype
+        amp = self.cfg.amp_dtype if use_amp else None
 
         def on(stream, fn, *args, **kws):
             if stream is None:
@@ -329,7 +337,7 @@ class CPSTrainer:
         m1, m2 = self.models
         with torch.no_grad():                                           # pseudo labels from eval passes
             m1.eval(); m2.eval()
-            o1, o2 = self._fwd_pair((ul_input,), (ul_input,))
+            o1, o2 = self._fwd_pair((ul_input,), (ul_input,), use_amp=cfg.eval_amp)
             score_1, score_2 = o1[0], o2[0]
             self._join()
             score_1, score_2 = score_1.float(), score_2.float()
@@ -357,6 +365,9 @@ class CPSTrainer:
             f2 = score_mask(pred_2, pl2, cfg.confidence_threshold)
             cps = self._ce_dice(pred_1, f2) + self._ce_dice(pred_2, f1)
             sup_1, sup_2 = self._ce_dice(ps1, l_target), self._ce_dice(ps2, l_target)
+        if cfg.keep_aux:
+            m_1, m_2 = (pseudo_1, pseudo_2) if cfg.recipe == "v1" else (f1, f2)
+            self.aux = dict(mask_1=m_1, mask_2=m_2, score_1=score_1, score_2=score_2, pred_sup_1=ps1.detach(), pred_ul_2=pu2.detach())
         commitment = (c_l1 + c_l2 + c_u1 + c_u2) * cfg.total_commitment_loss_weight
         prototype = (p_l1 + p_l2 + p_u1 + p_u2) * cfg.total_prototype_loss_weight
         lr = self.sched.get_lr(self.iter)
