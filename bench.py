@@ -25,8 +25,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# Ops still on PyTorch-ROCm/MIOpen (DESIGN.md "status") must not run MIOpen's exhaustive per-shape search on a
-# fresh box (minutes of silence); the hand-written HIP kernels are unaffected by this.
+# No convolution of the path goes through MIOpen (all are hand-written HIP); should an ATen fallback ever reach it (the plain
+# `unet` plumbing model's 3x3 head does), it must not run an exhaustive per-shape search on a fresh box (minutes of silence).
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 import torch  # noqa: E402
@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="labelled images per GPU per step (+ as many unlabelled)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval-amp", action="store_true",
+                    help="run the two no-grad pseudo-label forwards under autocast too (all-bf16 step; NOT the reference's "
+                         "precision: its trainers run them in fp32, outside autocast)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,7 +146,7 @@ def main():
 
     t_start = time.perf_counter()
     cfg = CPSConfig(model=model_cfg(), recipe="v1", total_iters=args.steps + args.warmup + 1,
-                    amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
+                    amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None, eval_amp=args.eval_amp)
     trainer = CPSTrainer(cfg, device)
     data = SyntheticCropWeed(SIZE, args.batch, device, seed=42)
     batches = [(data.labelled(), data.unlabelled()) for _ in range(2)]      # resident in HBM before timing
@@ -209,6 +212,27 @@ def main():
         dist.all_reduce(tsup, op=dist.ReduceOp.MAX)
     sup_s = float(tsup.item())
 
+    # the all-bf16 variant of the step (pseudo-label forwards under autocast as well), reported NEXT to the headline: a build-side
+    # speed mode, not the reference's precision -- `value` above is the step whose every forward has the reference's precision
+    all_bf16_s = None
+    if args.dtype == "bf16" and not args.eval_amp:
+        trainer.cfg.eval_amp = True
+        one(0)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ta = time.perf_counter()
+        for i in range(args.steps):
+            one(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tt = torch.tensor([time.perf_counter() - ta], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        all_bf16_s = float(tt.item())
+        trainer.cfg.eval_amp = False
+
     if rank == 0:
         flops = sum(2.0 * n * c * k for n, c, k, _ in recs)
         ms = sum(r[3] for r in recs)
@@ -236,6 +260,10 @@ def main():
                        "images_per_step_per_gpu": 2 * args.batch, "labelled_per_gpu": args.batch,
                        "unlabelled_per_gpu": args.batch, "parallelism": f"dp{world}",
                        "vq_dtype": "f32 (exact fp32 MFMA, bit-exact argmin)", "conv_dtype": args.dtype,
+                       "precision_per_forward": {
+                           "4 training forwards + 4 backwards": args.dtype + (" (under autocast, like the reference's AMP region; its fp16 -> bf16)" if args.dtype == "bf16" else ""),
+                           "2 no-grad pseudo-label forwards": ("bf16 (--eval-amp: NOT the reference's precision)" if (args.eval_amp and args.dtype == "bf16")
+                                                               else "fp32 (outside autocast, train_vqreptunet1x1v2.py:143-149)")},
                        "final_loss": round(loss, 5)},
             "roofline": {"kernel": "vq_assign_f32_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -254,6 +282,10 @@ def main():
         line["supervised_step"] = {"images_per_sec": round(args.batch * world / sup_s, 2), "ms_per_step": round(sup_s * 1e3, 2),
                                    "what": "forward + backward + Adam of ONE network on the labelled half of the batch "
                                            "(0.5 CE + Dice + commitment + prototype loss), 3 steps after the timed region"}
+        if all_bf16_s is not None:
+            line["all_bf16_step"] = {"images_per_sec": round(images / all_bf16_s, 3), "ms_per_step": round(all_bf16_s / args.steps * 1e3, 3),
+                                     "what": "the same step with the two pseudo-label forwards under bf16 autocast too (CPSConfig.eval_amp=True); "
+                                             "narrower than the reference's trainer there, so it is NOT the headline"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
