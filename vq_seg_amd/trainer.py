@@ -218,6 +218,7 @@ class CPSTrainer:
             for m in self.models:
                 for t in list(m.parameters()) + list(m.buffers()):
                     dist.broadcast(t.data, src=0)
+                nnf.invalidate_weight_caches(m)          # `.data` writes do not bump the version counter (_wcache)
         for m in self.models:
             m.async_code_usage = True                     # no host sync inside forward (usage is read after the step)
         self.buckets = [GradBuckets(list(m.parameters()), cfg.bucket_mb) for m in self.models]

@@ -19,6 +19,7 @@ import torch
 from torch import nn
 
 from .. import _hip
+from .._wcache import cache_of as _cache_of, invalidate as _invalidate
 from ..dist import world_size as _world_size, broadcast0 as _broadcast0, all_reduce_sum as _all_reduce_sum
 
 
@@ -117,14 +118,13 @@ class EuclideanCodebook(nn.Module):
             self.register_buffer("embed_avg", self.embedding.weight.detach().clone())
 
     def prepared(self) -> torch.Tensor:
-        """Kernel-side image of the codebook (include/vqseg.h: vqseg_vq_prepare_f32), rebuilt only
-        when the weight tensor changes (version counter / storage / device)."""
+        """Kernel-side image of the codebook (include/vqseg.h: vqseg_vq_prepare_f32), rebuilt only when the weight may have
+        changed (_wcache: version counter / storage / device, every optimiser step, explicit invalidation after `.data` writes)."""
         w = self.embedding.weight
-        key = (w._version, w.data_ptr(), str(w.device))
-        if getattr(self, "_prep_key", None) != key:
-            self._prep_blob = _hip.vq_prepare(w.detach())
-            self._prep_key = key
-        return self._prep_blob
+        cache = _cache_of(w)
+        if "vq_prepared" not in cache:
+            cache["vq_prepared"] = _hip.vq_prepare(w.detach())
+        return cache["vq_prepared"]
 
     @torch.no_grad()
     def _kmeans_init(self, rows: torch.Tensor):
@@ -132,7 +132,7 @@ class EuclideanCodebook(nn.Module):
             return
         means, bins = kmeans(rows, self.num_embeddings, self.kmeans_iters)
         self.embedding.weight.copy_(means)                   # in place on the parameter itself: bumps its version counter,
-        self._prep_key = None                                # which (with this) retires the prepared image of the old codebook
+        _invalidate(self.embedding.weight)                   # which (with this) retires the prepared image of the old codebook
         if self.ema_update:
             self.embed_avg.copy_(means)
             self.cluster_size.copy_(bins.to(self.cluster_size.dtype))
@@ -146,7 +146,7 @@ class EuclideanCodebook(nn.Module):
             _all_reduce_sum(sums)
             _all_reduce_sum(counts)
         _hip.vq_ema_update(self.cluster_size, self.embed_avg, self.embedding.weight.detach(), sums, counts, self.decay, self.eps)
-        self._prep_key = None                                # the kernel wrote the weight behind autograd's back
+        _invalidate(self.embedding.weight)                   # the kernel wrote the weight behind autograd's back
 
     def forward(self, x: torch.Tensor):
         """x (B, HW, C) -> quantized (B, HW, C), embed_idx (B, HW), code_usage (dead-code %)."""
