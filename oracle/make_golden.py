@@ -173,6 +173,57 @@ def gen_decoder(ref):
         save(case["name"], meta, **arrays)
 
 
+# ---------------------------------------------------------------- one decoder block at the benchmark's own size
+BLOCK_CASE = dict(name="decoder_block0_b32", cin=2048, cout=1024, b=32, s=16)
+
+
+def block_inputs(case=BLOCK_CASE):
+    """Deepest decoder block at bench scale: 2048 -> 1024 -> 1024 channels on 32 x 16 x 16 pixels (B = 32 at 512 x 512)."""
+    from collections import OrderedDict
+    cin, cout, b, s = case["cin"], case["cout"], case["b"], case["s"]
+    shapes = OrderedDict()
+    for j, ci in enumerate((cin, cout)):
+        shapes[f"{j}.0.weight"] = (cout, ci, 3, 3)
+        shapes[f"{j}.1.weight"] = (cout,)
+        shapes[f"{j}.1.bias"] = (cout,)
+        shapes[f"{j}.1.running_mean"] = (cout,)
+        shapes[f"{j}.1.running_var"] = (cout,)
+        shapes[f"{j}.1.num_batches_tracked"] = ()
+    x = synth.relu_features(3500, (b, cin, s, s))
+    sd = synth.synth_state_dict(shapes, 3501)
+    g = synth.uniform(3502, (b, cout, s, s), -1.0, 1.0)
+    return x, sd, g
+
+
+def stats(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.pow(2).sum().item(), t.abs().max().item()])
+
+
+def gen_decoder_block(ref):
+    """double_conv_block (models/networks/unet/decoder.py:7-12) at the channel counts and pixel count the benchmark runs, so that
+    the kernels the bench dispatches there (multi-chunk patch-reuse forward / data gradient, nine-tap weight gradient) are
+    compared with the reference's own block.  Outputs are stored as strided probes + float64 checksums (33 MB otherwise)."""
+    x, sd, g = block_inputs()
+    blk = ref.decoder.double_conv_block(BLOCK_CASE["cin"], BLOCK_CASE["cout"])
+    blk.load_state_dict(sd)
+    blk.eval()
+    with torch.no_grad():
+        y_eval = blk(x)
+    blk.train()
+    xr = x.clone().requires_grad_(True)
+    y = blk(xr)
+    (y * g).sum().backward()
+    post = blk.state_dict()
+    save(BLOCK_CASE["name"], dict(BLOCK_CASE, x_sum=synth.checksum(x), source="models/networks/unet/decoder.py:7-12 double_conv_block"),
+         y_eval=probe(y_eval), y_eval_stats=stats(y_eval), y_train=probe(y), y_train_stats=stats(y),
+         grad_x=probe(xr.grad), grad_x_stats=stats(xr.grad),
+         grad_w0=probe(blk[0][0].weight.grad), grad_w0_stats=stats(blk[0][0].weight.grad),
+         grad_w1=probe(blk[1][0].weight.grad), grad_w1_stats=stats(blk[1][0].weight.grad),
+         grad_bn_w1=blk[1][1].weight.grad, grad_bn_b1=blk[1][1].bias.grad, grad_bn_w0=blk[0][1].weight.grad,
+         run_mean0=post["0.1.running_mean"], run_var0=post["0.1.running_var"], run_var1=post["1.1.running_var"])
+
+
 # ---------------------------------------------------------------- prototype losses, dice/CE, metrics, lr
 def proto_inputs(seed=4000, b=2, c=32, s=16):
     feat = synth.uniform(seed, (b, c, s, s), -1.0, 1.0)
@@ -456,9 +507,9 @@ def hash_shapes(shapes):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_harness.ref_modules()
-    which = set(sys.argv[1:]) or {"vq", "kmeans", "decoder", "proto", "losses", "models", "unet", "cps", "curve"}
+    which = set(sys.argv[1:]) or {"vq", "kmeans", "decoder", "proto", "losses", "models", "unet", "cps", "curve", "block"}
     for tag, fn in (("vq", gen_vq), ("kmeans", gen_kmeans), ("decoder", gen_decoder), ("proto", gen_proto),
-                    ("losses", gen_losses), ("models", gen_models), ("unet", gen_unet), ("cps", gen_cps), ("curve", gen_curve)):
+                    ("losses", gen_losses), ("models", gen_models), ("unet", gen_unet), ("cps", gen_cps), ("curve", gen_curve), ("block", gen_decoder_block)):
         if tag in which:
             print(f"[{tag}]")
             fn(ref)

@@ -129,3 +129,21 @@ def prepare_module_model(model, x, gt, version, to_input=lambda t: t):
         else:
             model(x, gt, th=0.7)
     set_bn_momentum(model, 0.1)
+
+
+def block_inputs(meta):
+    """oracle/make_golden.py::block_inputs: one decoder block at bench scale (2048 -> 1024 -> 1024 channels, 32 x 16 x 16 pixels)."""
+    from collections import OrderedDict
+    cin, cout, b, s = meta["cin"], meta["cout"], meta["b"], meta["s"]
+    shapes = OrderedDict()
+    for j, ci in enumerate((cin, cout)):
+        shapes[f"{j}.0.weight"] = (cout, ci, 3, 3)
+        shapes[f"{j}.1.weight"] = (cout,)
+        shapes[f"{j}.1.bias"] = (cout,)
+        shapes[f"{j}.1.running_mean"] = (cout,)
+        shapes[f"{j}.1.running_var"] = (cout,)
+        shapes[f"{j}.1.num_batches_tracked"] = ()
+    x = synth.relu_features(3500, (b, cin, s, s))
+    sd = synth.synth_state_dict(shapes, 3501)
+    g = synth.uniform(3502, (b, cout, s, s), -1.0, 1.0)
+    return x, sd, g

@@ -1,0 +1,129 @@
+"""BASELINE.json configurations 2 and 4 at model level (3 is the bench; 1 is tests/test_model_gpu.py::test_plain_unet...):
+  #2  vqreptunet1x1   512 x 512, K = 256,  bf16 activations (autocast)
+  #4  vqreptunet1x1v2 1024 x 1024, K = 1024, bf16 activations
+Two CPSTrainer steps each (finite terms, codebooks initialised by k-means in the first training forward), then the
+size-independent VQ properties of tests/test_vq_gpu.py::test_full_size_properties on the model's OWN bf16 encoder features
+and k-means codebooks -- real near-tie structure instead of synthetic rows -- plus the count of rows whose two best codes
+are closer than 1e-5 relative (the only rows whose index may legitimately be examined).
+Also: one decoder block at the benchmark's own channel / pixel counts against the reference's double_conv_block."""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases, golden_io, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("recipe,size,k,batch", [("v1", 512, 256, 2), ("v2", 1024, 1024, 1)])
+def test_baseline_config_steps_and_vq_properties_on_own_features(recipe, size, k, batch):
+    from vq_seg_amd import _hip
+    from vq_seg_amd.trainer import CPSConfig, CPSTrainer, SyntheticCropWeed
+    name = "vqreptunet1x1" if recipe == "v1" else "vqreptunet1x1v2"
+    margin, scale = (0.0, 1.0) if recipe == "v1" else (0.5, 30.0)
+    model = {"name": name, "params": {"encoder_name": "resnet50", "num_classes": 3, "depth": 5,
+                                      "vq_cfg": {"num_embeddings": [0, 0, k, k, k], "distance": "euclidean", "kmeans_init": True},
+                                      "margin": margin, "scale": scale, "use_feature": False, "encoder_weights": None}}
+    torch.manual_seed(0)
+    tr = CPSTrainer(CPSConfig(model=model, recipe=recipe, total_iters=10, amp_dtype=torch.bfloat16), dev())
+    data = SyntheticCropWeed(size, batch, dev(), seed=3)
+    (l_in, l_tg), ul_in = data.labelled(), data.unlabelled()
+    for _ in range(2):
+        out = tr.step(l_in, l_tg, ul_in)
+        for key, v in out.items():
+            assert torch.isfinite(torch.as_tensor(v)).all(), key
+    m = tr.models[0]
+    assert all(m.codebook[i].codebook.initted for i in (2, 3, 4))
+    m.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        feats = m.encode(ul_in.contiguous(memory_format=torch.channels_last))
+    report = []
+    for lvl in (2, 3, 4):
+        f = feats[lvl]
+        assert f.dtype == torch.bfloat16
+        b, c, h, w = f.shape
+        rows = f.permute(0, 2, 3, 1).reshape(-1, c).contiguous()                   # bf16 rows as the layer sees them
+        W = m.codebook[lvl].codebook.embedding.weight.detach()
+        n = rows.shape[0]
+        quant, idx, _loss, dead, dmin = _hip.vq_forward(rows, W, False, 1.0, want_dmin=True)
+        # (1) epsilon-argmin in fp64 on a row sample, and the near-tie count on the same sample
+        sub = torch.arange(0, n, max(n // 4096, 1), device=dev())
+        d2 = torch.cdist(rows[sub].double(), W.double()).pow(2)
+        top2 = torch.topk(d2, 2, dim=1, largest=False).values
+        chosen = d2.gather(1, idx[sub, None])[:, 0]
+        assert ((chosen - top2[:, 0]) <= 1e-5 * top2[:, 0].clamp_min(1e-6)).all(), f"level {lvl}: argmin is not a minimiser"
+        gap = (top2[:, 1] - top2[:, 0]) / top2[:, 1].clamp_min(1e-30)
+        near = int((gap < 1e-5).sum())
+        wrong = int((d2.argmin(1) != idx[sub]).sum())
+        report.append(f"{recipe} {size}^2 K={k} level {lvl}: N={n} C={c}; sampled {sub.numel()} rows: top-2 gap < 1e-5 in {near}, "
+                      f"index != fp64 argmin in {wrong}, min gap {gap.min().item():.2e}, dead codes {float(dead):.1f} %")
+        assert wrong <= near                                                        # only near-ties may differ from the fp64 argmin
+        # (2) exact gather (bf16 rows out: the fp32 code rounded once)
+        assert torch.equal(quant, W[idx].to(torch.bfloat16))
+        # (3) histogram
+        cnt = torch.bincount(idx, minlength=k)
+        assert float(dead) == float(100 * ((cnt == 0).sum() / k))
+        # (4) the fp32-rows entry point sees the same bf16 values -> the same indices; permutation equivariance
+        assert torch.equal(_hip.vq_assign(rows.float(), W), idx)
+        perm = torch.randperm(n, device=dev())
+        assert torch.equal(_hip.vq_assign(rows[perm].contiguous(), W), idx[perm])
+    print("\n".join(report))
+
+
+def _block(sd):
+    from vq_seg_amd.models.networks.unet.decoder import double_conv_block
+    blk = double_conv_block(2048, 1024)
+    blk.load_state_dict(sd)
+    return blk.to(dev())
+
+
+def _probe_close(t, want, want_stats, tol, what):
+    got = golden_io.probe(t).double().cpu()
+    want = want.double()
+    scale = float(want_stats[2])                                     # max |.| of the WHOLE reference tensor
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale, f"{what}: probe max err {err:.3e} > {tol:g} * {scale:.3e}"
+    l2 = ((got - want).norm() / (want.norm() + 1e-30)).item()
+    assert l2 <= tol, f"{what}: probe rel L2 {l2:.3e}"
+    s1, s2 = t.detach().double().sum().item(), t.detach().double().pow(2).sum().item()
+    assert abs(s2 - float(want_stats[1])) <= 4 * tol * float(want_stats[1]), f"{what}: sum of squares {s2} vs {float(want_stats[1])}"
+    return err / scale, l2, s1
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_decoder_block_at_bench_scale_matches_reference(mode):
+    """double_conv_block(2048, 1024) on 32 x 16 x 16 pixels (models/networks/unet/decoder.py:7-12; fixture decoder_block0_b32 from
+    oracle/make_golden.py::gen_decoder_block): the natural dispatch at this size is what bench.py runs there -- bf16: multi-chunk
+    patch-reuse forward + zero-pad data gradient (conv3x3_patch_kernel<128,...,64>, 32 / 16 channel chunks), nine-tap weight gradient
+    (conv_wgrad3x3_kernel), BN statistics in the epilogue; fp32: the bf16x3 precise kernels.  Strided probes + fp64 checksums."""
+    from tests.cases import block_inputs
+    fx = golden_io.load("decoder_block0_b32")
+    x, sd, g = block_inputs(fx.meta)
+    assert synth.checksum(x) == fx.meta["x_sum"]
+    amp = mode == "bf16"
+    tol_f, tol_g = (2e-2, 3e-2) if amp else (1e-3, 2e-3)
+    xg = x.to(dev()).contiguous(memory_format=torch.channels_last)
+    blk = _block(sd)
+    blk.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        y = blk(xg)
+    _probe_close(y.float(), fx["y_eval"], fx["y_eval_stats"], tol_f, "eval output")
+    blk.train()
+    xr = xg.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        y = blk(xr)
+    _probe_close(y.float(), fx["y_train"], fx["y_train_stats"], tol_f, "train output")
+    (y.float() * g.to(dev())).sum().backward()
+    _probe_close(xr.grad.float(), fx["grad_x"], fx["grad_x_stats"], tol_g, "grad x")
+    _probe_close(blk[0][0].weight.grad, fx["grad_w0"], fx["grad_w0_stats"], tol_g, "grad w0")
+    _probe_close(blk[1][0].weight.grad, fx["grad_w1"], fx["grad_w1_stats"], tol_g, "grad w1")
+    for name, got in (("grad_bn_w1", blk[1][1].weight.grad), ("grad_bn_b1", blk[1][1].bias.grad), ("grad_bn_w0", blk[0][1].weight.grad)):
+        want = fx[name].double()
+        assert ((got.double().cpu() - want).norm() / want.norm()).item() <= tol_g, name
+    post = blk.state_dict()
+    for name, key in (("run_mean0", "0.1.running_mean"), ("run_var0", "0.1.running_var"), ("run_var1", "1.1.running_var")):
+        assert torch.allclose(post[key].cpu(), fx[name], rtol=2e-2 if amp else 1e-4, atol=1e-3 if amp else 1e-6), name

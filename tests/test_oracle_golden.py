@@ -304,3 +304,26 @@ def test_cps_iterations(version):
                 assert ((got - want).norm() / (want.norm() + 1e-30)).item() <= 2e-3, (tag, key)
         none = set(fx["it0/grad_none/m1"].tolist())
         assert {f"codebook.{i}.codebook.embedding.weight" for i in (2, 3, 4)} | {"prototype_loss.embedding.weight"} == none
+
+
+def test_decoder_block_at_bench_scale():
+    """oracle conv3x3_bn_relu x 2 == the reference's double_conv_block(2048, 1024) on 32 x 16 x 16 pixels (probes + checksums)."""
+    fx = golden_io.load("decoder_block0_b32")
+    x, sd, g = cases.block_inputs(fx.meta)
+    assert synth.checksum(x) == fx.meta["x_sum"]
+    p = {"blk." + k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        y = R.conv3x3_bn_relu(R.conv3x3_bn_relu(x, p, "blk.0", False), p, "blk.1", False)
+    close(golden_io.probe(y), fx["y_eval"], rtol=1e-4, atol=1e-5)
+    assert float(y.double().pow(2).sum()) == pytest.approx(float(fx["y_eval_stats"][1]), rel=1e-5)
+    for k, v in p.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    y = R.conv3x3_bn_relu(R.conv3x3_bn_relu(xr, p, "blk.0", True), p, "blk.1", True)
+    close(golden_io.probe(y), fx["y_train"], rtol=1e-4, atol=1e-5)
+    (y * g).sum().backward()
+    close(golden_io.probe(xr.grad), fx["grad_x"], rtol=1e-3, atol=1e-5 * float(fx["grad_x_stats"][2]))
+    close(golden_io.probe(p["blk.0.0.weight"].grad), fx["grad_w0"], rtol=1e-3, atol=1e-5 * float(fx["grad_w0_stats"][2]))
+    close(p["blk.1.1.weight"].grad, fx["grad_bn_w1"], rtol=1e-3, atol=1e-4 * float(fx["grad_bn_w1"].abs().max()))
+    close(p["blk.0.1.running_var"], fx["run_var0"], rtol=1e-5)

@@ -28,7 +28,7 @@ def _run(two_streams, recipe, amp):
     return losses, chk
 
 
-@pytest.mark.parametrize("recipe,amp", [("v1", True), ("v2", False)])
+@pytest.mark.parametrize("recipe,amp", [("v1", True), ("v2", False), ("v2", True), ("v1", False)])
 def test_two_streams_change_nothing(recipe, amp):
     la, ca = _run(False, recipe, amp)
     lb, cb = _run(True, recipe, amp)
