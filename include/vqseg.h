@@ -93,6 +93,10 @@ int vqseg_vq_forward_f32(const float* x, const float* codebook, const void* prep
 int vqseg_vq_assign_f32(const float* x, const float* codebook, const void* prepared,
                         int64_t n_rows, int channels, int n_codes, int64_t* idx, float* dmin,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* The same for bf16 rows (autocast activations; every bf16 value is an exact float, the arithmetic is the fp32 one). */
+int vqseg_vq_assign_bf16(const void* x, const float* codebook, const void* prepared,
+                         int64_t n_rows, int channels, int n_codes, int64_t* idx, float* dmin,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Prepared codebook: the kernel-side image of an nn.Embedding weight (4-channel
  * interleaved, code-padded copy + |e_k|^2).  The reference's codebook never changes after

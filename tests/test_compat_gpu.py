@@ -67,8 +67,10 @@ def compare_iterations(got, fx, backward_in_fixture, mask_slack=(4, 82)):
         for tag in ("m1", "m2"):
             for key in cps_loop.PROBES + ["encoder.bn1.running_var"]:
                 a, b = torch.from_numpy(got[f"param/{tag}/{key}"]).double(), fx[f"param/{tag}/{key}"].double()
-                err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
-                assert err <= 1e-3, (tag, key, err)
+                # Adam's step is ~ lr * sign(g): a gradient entry within rounding error of zero may move its weight the other way,
+                # 2 * lr per step -> at most 4 * lr = 4e-4 after the two steps (and 1e-3 of scale for the running statistics)
+                err = (a - b).abs().max().item()
+                assert err <= max(1e-3 * b.abs().max().item(), 4.2 * cps_loop.TRAIN["learning_rate"]), (tag, key, err)
         none = set(fx["it0/grad_none/m1"].tolist())
         assert set(got["it0/grad_none/m1"].tolist()) == none
     print("\n".join(report))

@@ -32,6 +32,8 @@ SYMBOLS = {
     "vqseg_vq_backward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "vqseg_vq_assign_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_size_t, c_void_p]),
+    "vqseg_vq_assign_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_size_t, c_void_p]),
     "vqseg_vq_prepared_bytes": (c_size_t, [c_int, c_int]),
     "vqseg_vq_prepare_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "vqseg_vq_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p,
@@ -200,10 +202,10 @@ def vq_assign(rows: torch.Tensor, codebook: torch.Tensor, want_dmin: bool = Fals
     nbytes = L.vqseg_vq_workspace_bytes(n, c, k)
     ws = _workspace(nbytes, dev)
     with torch.cuda.device(dev):
-        rc = L.vqseg_vq_assign_f32(xp, wp, prepared.data_ptr() if prepared is not None else None, n, c, k,
-                                   idx.data_ptr(), dmin.data_ptr() if want_dmin else None,
-                                   ws.data_ptr(), nbytes, _stream())
-    _check(rc, "vqseg_vq_assign_f32")
+        fn = L.vqseg_vq_assign_bf16 if bf16 else L.vqseg_vq_assign_f32        # the entry point must match the row type
+        rc = fn(xp, wp, prepared.data_ptr() if prepared is not None else None, n, c, k,
+                idx.data_ptr(), dmin.data_ptr() if want_dmin else None, ws.data_ptr(), nbytes, _stream())
+    _check(rc, "vqseg_vq_assign_bf16" if bf16 else "vqseg_vq_assign_f32")
     return (idx, dmin) if want_dmin else idx
 
 

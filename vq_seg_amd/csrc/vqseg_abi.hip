@@ -111,6 +111,12 @@ int vqseg_vq_assign_f32(const float* x, const float* codebook, const void* prepa
     return vq_assign_any(x, 0, codebook, prepared, n, c, k, idx, dmin, ws, ws_bytes, stream);
 }
 
+int vqseg_vq_assign_bf16(const void* x, const float* codebook, const void* prepared, int64_t n, int c, int k,
+                         int64_t* idx, float* dmin, void* ws, size_t ws_bytes, void* stream) {
+    if (c % 8) return fail(VQSEG_EINVAL, "bf16 rows need channels %% 8 == 0");
+    return vq_assign_any(x, 1, codebook, prepared, n, c, k, idx, dmin, ws, ws_bytes, stream);
+}
+
 static int vq_forward_any(const void* x, int bf16, const float* codebook, const void* prepared, int64_t n, int c, int k,
                           int training, float cw, void* quant, int64_t* idx, float* loss, float* dead_pct, float* dmin,
                           void* ws, size_t ws_bytes, void* stream) {
