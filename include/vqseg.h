@@ -266,6 +266,24 @@ int vqseg_head1x1_backward_f(int bf16, const void* x, const float* w, const floa
 int vqseg_im2col_f(int out_bf16, const float* x, int n, int h, int w, int cin, int kh, int kw, int stride,
                    int pad, int reflect, int ho, int wo, int kp, void* out, void* stream);
 int vqseg_reflect_fold_f(int bf16, const void* gp, int n, int h, int w, int c, void* gx, void* stream);
+
+/* ----------------------------------------------------------------------------------
+ * "Split-3" activations: the fp32-precision NO-GRAD EVAL forward (the trainers' pseudo-label passes, outside autocast:
+ * train_vqreptunet1x1v2.py:143-149) on the bf16 MFMA kernels.  A logical fp32 tensor [rows][C] is kept as [rows][3C] bf16 =
+ * [hi | lo | hi] with hi = bf16(v), lo = bf16(v - hi) (v = hi + lo to ~2^-17).  A PLAIN bf16 convolution over the 3C channels
+ * with the weight image [w_hi | w_hi | w_lo] computes x_hi w_hi + x_lo w_hi + x_hi w_lo: the same three products, fp32
+ * accumulation, as the "precise" kernels (vqseg_conv2d_f precise = 1), on the LDS-DMA / patch-reuse kernels instead.
+ *   vqseg_conv2d_affine_f(..., precise = 2): x / x2 / res / y are split-3 tensors, cin / c1 / cout LOGICAL channel counts
+ *       (Cin, C1 % 32 == 0, Cout % 8 == 0), w_hi = vqseg_conv_pack_weights_s3_f32's image, w_lo unused.
+ *   vqseg_im2col_f(out_bf16 = 2, ...): split-3 patch rows [3 * kp] (7x7x3 stem only).
+ *   split / merge: fp32 rows <-> split-3 rows;  maxpool / bilinear: the forward ops of vqseg_maxpool3x3s2_f /
+ *       vqseg_bilinear_f on split-3 tensors (values hi + lo, re-split on the way out).  channels % 8 == 0.
+ * ---------------------------------------------------------------------------------- */
+int vqseg_conv_pack_weights_s3_f32(const float* w, int cout, int cin, int c1, int kh, int kw, void* out, void* stream);
+int vqseg_s3_split_f(const float* x, int64_t rows, int channels, void* y, void* stream);
+int vqseg_s3_merge_f(const void* x, int64_t rows, int channels, float* y, void* stream);
+int vqseg_s3_maxpool3x3s2_f(const void* x, int n, int h, int w, int c, void* y, void* stream);
+int vqseg_s3_bilinear_f(const void* x, int n, int h, int w, int c, int ho, int wo, int align_corners, void* y, void* stream);
 int vqseg_cast_f(int to_bf16, const void* x, int64_t n, void* y, void* stream);
 
 /* Reliable prototype losses (models/modules/prototype.py:500-613 ReliablePrototypeLoss = variant 1, :778-888

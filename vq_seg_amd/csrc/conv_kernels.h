@@ -21,6 +21,9 @@ struct ConvArgs {
     const void* ep_res;         // optional residual rows [N, Ho, Wo, Cout] of the activation type
     int ep_relu;
     int pair_chunks = 0, pair_tiles = 0;   // patch kernel, 1-D launch: Cout chunks per pixel tile / pixel tiles (0: 2-D grid)
+    // "split-3" output (fast kernels + fused epilogue only): y and ep_res rows are [3 * Cout] bf16 = [hi | lo | hi] of the fp32
+    // value (see vqseg.h, vqseg_conv2d_affine_f precise == 2); the input is such a tensor too, seen as 3 * C plain bf16 channels
+    int out_s3 = 0;
 };
 
 struct WgradArgs {
@@ -43,5 +46,6 @@ hipError_t launch_wgrad_reduce(const float* partial, int slabs, int Cout, int Ci
 size_t packed_elems(int Cout, int Cin, int KH, int KW, int transpose_flip);
 hipError_t launch_pack_weights(const float* w, int Cout, int Cin, int KH, int KW, int transpose_flip, unsigned short* hi,
                                unsigned short* lo, hipStream_t st);
+hipError_t launch_pack_weights_s3(const float* w, int Cout, int Cin, int C1, int KH, int KW, unsigned short* out, hipStream_t st);
 
 }  // namespace vqseg

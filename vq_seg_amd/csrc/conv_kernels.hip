@@ -67,11 +67,71 @@ struct LinearRows {                                          // tile row -> outp
     __device__ __forceinline__ long operator()(int row) const { return m0 + row; }
 };
 
-template <int TBM, int BN, bool PRECISE, int MT, int NTT, int NT, int NTHR, typename RowMap = LinearRows>
+template <int TBM, int BN, bool PRECISE, int MT, int NTT, int NT, int NTHR, typename RowMap = LinearRows, bool S3 = false>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const ConvArgs& p, char* smem, long M, long m0, int co0,
                                               int wm, int wn, int r, int h, int tid, RowMap row_to_m = LinearRows{-1}) {
     if constexpr (__is_same(RowMap, LinearRows)) row_to_m.m0 = m0;
     const long wrow0 = m0 + (long)wm * MT * 32;
+    if constexpr (S3) {
+        // split-3 output: the fp32 result v = acc * scale + shift (+ residual, ReLU) leaves as [hi | lo | hi] bf16, hi = bf16(v),
+        // lo = bf16(v - hi): 3 * Cout channels per pixel row.  Staged through LDS as two bf16 tiles so that the stores (and the
+        // residual loads) are whole 16-byte row segments.  Host side guarantees Cout % 8 == 0 and a fused epilogue.
+        static_assert(!PRECISE, "split-3 output belongs to the bf16 kernels");
+        constexpr int OS = BN + 8;
+        __bf16* th = reinterpret_cast<__bf16*>(smem);
+        __bf16* tl = th + TBM * OS;
+        const bool ep_res = p.ep_res != nullptr;
+#pragma unroll
+        for (int b = 0; b < NTT; ++b) {
+            const int col = (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
+            const bool cok = co0 + col < p.Cout;
+            const float esc = cok ? p.ep_scale[co0 + col] : 1.0f, esh = cok ? p.ep_shift[co0 + col] : 0.0f;
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (wm * MT + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    float v = __builtin_fmaf(acc[a][b][i], esc, esh);
+                    if (p.ep_relu && !ep_res && !(v > 0.0f)) v = 0.0f;
+                    const __bf16 vh = (__bf16)v;
+                    th[row * OS + col] = vh;
+                    tl[row * OS + col] = (__bf16)(v - (float)vh);
+                }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 8;
+        const long rs = 3L * p.Cout;                         // output (and residual) row stride in elements
+        for (int idx = tid; idx < TBM * CPR; idx += NTHR) {
+            const int row = idx / CPR, ch = idx % CPR;
+            const long m = row_to_m(row);
+            const int co = co0 + ch * 8;
+            if (m < M && co < p.Cout) {
+                u32x4 vh = *reinterpret_cast<const u32x4*>(th + (size_t)row * OS + ch * 8);
+                u32x4 vl = *reinterpret_cast<const u32x4*>(tl + (size_t)row * OS + ch * 8);
+                if (ep_res) {
+                    const unsigned short* rp = reinterpret_cast<const unsigned short*>(p.ep_res) + m * rs + co;
+                    const u32x4 rh = *reinterpret_cast<const u32x4*>(rp);
+                    const u32x4 rl = *reinterpret_cast<const u32x4*>(rp + p.Cout);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v0 = (__builtin_bit_cast(float, vh[e] << 16) + __builtin_bit_cast(float, vl[e] << 16)) +
+                                   (__builtin_bit_cast(float, rh[e] << 16) + __builtin_bit_cast(float, rl[e] << 16));
+                        float v1 = (__builtin_bit_cast(float, vh[e] & 0xFFFF0000u) + __builtin_bit_cast(float, vl[e] & 0xFFFF0000u)) +
+                                   (__builtin_bit_cast(float, rh[e] & 0xFFFF0000u) + __builtin_bit_cast(float, rl[e] & 0xFFFF0000u));
+                        if (p.ep_relu && !(v0 > 0.0f)) v0 = 0.0f;
+                        if (p.ep_relu && !(v1 > 0.0f)) v1 = 0.0f;
+                        vh[e] = pack2(v0, v1);
+                        vl[e] = pack2(v0 - bf16_round(v0), v1 - bf16_round(v1));
+                    }
+                }
+                unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + m * rs + co;
+                *reinterpret_cast<u32x4*>(yp) = vh;
+                *reinterpret_cast<u32x4*>(yp + p.Cout) = vl;
+                *reinterpret_cast<u32x4*>(yp + 2 * p.Cout) = vh;
+            }
+        }
+        return;
+    }
     if (p.stat_partial) {
         // one (mean, M2) partial per SLOT of RPS consecutive rows: 64 rows (two 32-row tiles) or 32 when the wave has one
         constexpr int TPS = MT >= 2 ? 2 : 1, RPS = TPS * 32;
@@ -199,7 +259,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
     }
 }
 
-template <int BN, bool PRECISE, int BK>
+template <int BN, bool PRECISE, int BK, bool S3 = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int BKP = BK + 8;                          // bf16 elements per LDS row (16-byte pad)
     constexpr int NT = BN / 64;                          // 32-wide N tiles per wave (BN=128 -> 2; 64 -> 1)
@@ -413,7 +473,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         __syncthreads();
     }
 
-    conv_epilogue<BM, BN, PRECISE, MT, NTT, NT, 256>(acc, p, smem, M, m0, co0, wm, wn, r, h, tid);
+    conv_epilogue<BM, BN, PRECISE, MT, NTT, NT, 256, LinearRows, S3>(acc, p, smem, M, m0, co0, wm, wn, r, h, tid);
 }
 
 // =====================================================================================================
@@ -437,7 +497,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int TBM, int BN, int NW, int NBUF, int MINW = 1>
+template <int TBM, int BN, int NW, int NBUF, int MINW = 1, bool S3 = false>
 __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const ConvArgs p) {
     constexpr int BK = 64;
     // wave grid WM x WN over the TBM x BN tile; wave tile (MT*32) x (NT*32)
@@ -623,7 +683,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
     }
     }
     __syncthreads();                                       // all MFMAs done: LDS is free for the output tile
-    conv_epilogue<TBM, BN, false, MT, NTT, NT, NW * 64>(acc, p, smem, M, m0, co0, wm, wn, r, h, tid);
+    conv_epilogue<TBM, BN, false, MT, NTT, NT, NW * 64, LinearRows, S3>(acc, p, smem, M, m0, co0, wm, wn, r, h, tid);
 }
 
 static int g_glds_pair = 4;                                 // layers with 2..this many Cout chunks: the chunks of an M tile share an XCD
@@ -635,7 +695,7 @@ static void launch_glds_t(const ConvArgs& a, hipStream_t st) {
     // ring slots actually used: a short K loop (1x1 layers with 64..128 input channels) then leaves LDS for more
     // resident workgroups, whose loads overlap each other's epilogues
     size_t lds = (size_t)(TBM + BN) * 64 * 2 * (n_stage < NBUF ? n_stage : NBUF);
-    const size_t out_tile = (size_t)TBM * (BN + 8) * 2;
+    const size_t out_tile = (size_t)TBM * (BN + 8) * 2 * (a.out_s3 ? 2 : 1);
     if (out_tile > lds) lds = out_tile;
     const long M = (long)a.N * a.Ho * a.Wo;
     const long m_tiles = (M + TBM - 1) / TBM;
@@ -644,12 +704,14 @@ static void launch_glds_t(const ConvArgs& a, hipStream_t st) {
         ConvArgs b = a;
         b.pair_chunks = chunks;
         b.pair_tiles = (int)m_tiles;
-        hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW>), dim3((unsigned)((m_tiles + 7) / 8 * 8 * chunks)),
-                           dim3(NW * 64), lds, st, b);
+        const dim3 grid1((unsigned)((m_tiles + 7) / 8 * 8 * chunks));
+        if (a.out_s3) hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW, true>), grid1, dim3(NW * 64), lds, st, b);
+        else hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW>), grid1, dim3(NW * 64), lds, st, b);
         return;
     }
     dim3 grid((unsigned)m_tiles, (unsigned)chunks);
-    hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW>), grid, dim3(NW * 64), lds, st, a);
+    if (a.out_s3) hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW, true>), grid, dim3(NW * 64), lds, st, a);
+    else hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW>), grid, dim3(NW * 64), lds, st, a);
 }
 
 // =====================================================================================================
@@ -678,7 +740,7 @@ struct TileRows {                                           // tile row -> outpu
 
 // CK: input channels per chunk (64, or 32 for layers whose channel count is not a multiple of 64: rows of 64 bytes,
 // four 16-byte chunks swizzled by (row >> 2) & 3, two K steps per tap)
-template <int BN, int NBW, bool UNROLL_TAPS, int CK = 64>
+template <int BN, int NBW, bool UNROLL_TAPS, int CK = 64, bool S3 = false>
 __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     constexpr int TBM = 256, NW = 8;
     constexpr int NT = BN >= 128 ? 2 : 1;                  // 32-channel tiles per wave
@@ -851,7 +913,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
         __syncthreads();
         const long M = (long)p.N * p.H * p.W;
         const TileRows rows{((long)n * p.H + oh0) * p.W + ow0, tw_shift, p.W};
-        conv_epilogue<TBM, BN, false, MT, NT, NT, NW * 64, TileRows>(acc, p, smem, M, (long)tile_id * TBM, co0, wm, wn, r, h, tid, rows);
+        conv_epilogue<TBM, BN, false, MT, NT, NT, NW * 64, TileRows, S3>(acc, p, smem, M, (long)tile_id * TBM, co0, wm, wn, r, h, tid, rows);
         return;
     }
     // ---- prologue: whole patch of chunk 0, weights of the first NBW - 1 stages
@@ -910,7 +972,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     __syncthreads();                                       // all MFMAs done: LDS is free for the output tile
     const long M = (long)p.N * p.H * p.W;
     const TileRows rows{((long)n * p.H + oh0) * p.W + ow0, tw_shift, p.W};
-    conv_epilogue<TBM, BN, false, MT, NT, NT, NW * 64, TileRows>(acc, p, smem, M, (long)tile_id * TBM, co0, wm, wn, r, h, tid, rows);
+    conv_epilogue<TBM, BN, false, MT, NT, NT, NW * 64, TileRows, S3>(acc, p, smem, M, (long)tile_id * TBM, co0, wm, wn, r, h, tid, rows);
 }
 
 static int g_patch_min_wgs = 256;
@@ -987,7 +1049,7 @@ static void launch_patch_t(const ConvArgs& a, hipStream_t st) {
         const int nb = a.Cin / CK > 1 ? 2 : 1;
         lds = (size_t)nb * ((size_t)PI * 8 * 1024 + 9 * (size_t)BN * ROWB);
     }
-    const size_t out_tile = (size_t)256 * (BN + 8) * 2;
+    const size_t out_tile = (size_t)256 * (BN + 8) * 2 * (a.out_s3 ? 2 : 1);
     if (out_tile > lds) lds = out_tile;
     const int tw = (a.W % 32 == 0) ? 32 : 16, th = 256 / tw;
     const long tiles = (long)a.N * (a.H / th) * (a.W / tw);
@@ -996,12 +1058,14 @@ static void launch_patch_t(const ConvArgs& a, hipStream_t st) {
         ConvArgs b = a;
         b.pair_chunks = chunks;
         b.pair_tiles = (int)tiles;
-        hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK>), dim3((unsigned)((tiles + 7) / 8 * 8 * chunks)), dim3(512),
-                           lds, st, b);
+        const dim3 grid1((unsigned)((tiles + 7) / 8 * 8 * chunks));
+        if (a.out_s3) hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK, true>), grid1, dim3(512), lds, st, b);
+        else hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK>), grid1, dim3(512), lds, st, b);
         return;
     }
     dim3 grid((unsigned)tiles, (unsigned)chunks);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK>), grid, dim3(512), lds, st, a);
+    if (a.out_s3) hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK, true>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK>), grid, dim3(512), lds, st, a);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1036,6 +1100,31 @@ __global__ __launch_bounds__(256) void conv_pack_weights(const float* __restrict
     }
 }
 
+// split-3 image for activations stored as [hi | lo | hi] (per concat segment): [Cout][KH][KW][3 * Cin] bf16 with the channel
+// order [w_hi(seg) | w_hi(seg) | w_lo(seg)] for seg = the first C1 channels, then the remaining Cin - C1, so that the plain bf16
+// contraction over the 3 * Cin channels is  x_hi w_hi + x_lo w_hi + x_hi w_lo  (the three products of the precise mode)
+__global__ __launch_bounds__(256) void conv_pack_weights_s3(const float* __restrict__ w, int Cout, int Cin, int C1, int KH, int KW,
+                                                            unsigned short* __restrict__ out) {
+    const int C3 = 3 * Cin;
+    const long total = (long)Cout * KH * KW * C3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int j = (int)(i % C3);
+        long t = i / C3;
+        const int kw = (int)(t % KW);
+        t /= KW;
+        const int kh = (int)(t % KH);
+        const int co = (int)(t / KH);
+        const bool second = j >= 3 * C1;
+        const int cs = second ? Cin - C1 : C1;
+        if (second) j -= 3 * C1;
+        const int part = j / cs, c = (second ? C1 : 0) + (j - part * cs);
+        const float v = w[(((long)co * Cin + c) * KH + kh) * KW + kw];
+        const __bf16 bh = (__bf16)v;
+        const __bf16 o = part == 2 ? (__bf16)(v - (float)bh) : bh;
+        out[i] = __builtin_bit_cast(unsigned short, o);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // host-side launch
 // ------------------------------------------------------------------------------------
@@ -1047,6 +1136,14 @@ static void launch_t(const ConvArgs& a, hipStream_t st) {
     if (out_tile > lds) lds = out_tile;
     const long M = (long)a.N * a.Ho * a.Wo;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN));
+    if constexpr (!PRECISE) {
+        if (a.out_s3) {
+            const size_t s3_tile = (size_t)BM * (BN + 8) * 2 * 2;
+            if (s3_tile > lds) lds = s3_tile;
+            hipLaunchKernelGGL((conv_igemm_kernel<BN, PRECISE, BK, true>), grid, dim3(256), lds, st, a);
+            return;
+        }
+    }
     hipLaunchKernelGGL((conv_igemm_kernel<BN, PRECISE, BK>), grid, dim3(256), lds, st, a);
 }
 
@@ -1103,6 +1200,14 @@ hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
 size_t packed_elems(int Cout, int Cin, int KH, int KW, int transpose_flip) {
     const int R = transpose_flip ? Cin : Cout, Cc = transpose_flip ? Cout : Cin;
     return (size_t)R * KH * KW * ((Cc + 31) / 32 * 32);
+}
+
+hipError_t launch_pack_weights_s3(const float* w, int Cout, int Cin, int C1, int KH, int KW, unsigned short* out, hipStream_t st) {
+    const long total = (long)Cout * KH * KW * 3 * Cin;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_pack_weights_s3, dim3((unsigned)blocks), dim3(256), 0, st, w, Cout, Cin, C1, KH, KW, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_pack_weights(const float* w, int Cout, int Cin, int KH, int KW, int transpose_flip, unsigned short* hi,

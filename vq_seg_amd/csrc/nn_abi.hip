@@ -83,6 +83,25 @@ int vqseg_conv2d_affine_f(const void* x, const void* x2, int c1, const void* w_h
                           int kw, int stride, int pad, int reflect, int ho, int wo, int precise, void* stream) {
     if (!scale || !shift) return bad("conv2d_affine: null scale / shift");
     if (res && !a16(res)) return bad("conv2d_affine: pointers must be 16-byte aligned");
+    if (precise == 2) {
+        // split-3: x / x2 / res / y are [hi | lo | hi] bf16 tensors of 3 * C channels, w_hi the matching image
+        // (vqseg_conv_pack_weights_s3_f32); the bf16 kernels contract over 3 * cin plain channels
+        if (cin % 32 || cout % 8 || c1 % 32 || c1 <= 0 || c1 > cin) return bad("conv2d_affine (split-3): needs Cin, C1 % 32 == 0 and Cout % 8 == 0");
+        if (!x || !w_hi || !y || (c1 < cin && !x2)) return bad("conv2d: null pointer");
+        if (n <= 0 || h <= 0 || w <= 0 || ho <= 0 || wo <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return bad("conv2d: non-positive dimension");
+        if (!a16(x) || !a16(x2) || !a16(w_hi) || !a16(y)) return bad("conv2d: pointers must be 16-byte aligned");
+        if (reflect && (pad >= h || pad >= w)) return bad("conv2d: reflect padding needs pad < size");
+        vqseg::ConvArgs a;
+        a.x = x; a.x2 = x2; a.C1 = 3 * c1;
+        a.w_hi = static_cast<const unsigned short*>(w_hi); a.w_lo = nullptr;
+        a.y = y; a.stat_partial = nullptr;
+        a.N = n; a.H = h; a.W = w; a.Cin = 3 * cin; a.Ho = ho; a.Wo = wo; a.Cout = cout; a.KH = kh; a.KW = kw;
+        a.stride = stride; a.pad = pad; a.reflect = reflect; a.up = 1;
+        a.ep_scale = scale; a.ep_shift = shift; a.ep_res = res; a.ep_relu = relu;
+        a.out_s3 = 1;
+        hipError_t e = vqseg::launch_conv(a, 0, static_cast<hipStream_t>(stream));
+        return e == hipSuccess ? 0 : hipfail(e, "conv kernel (split-3)");
+    }
     return conv2d_impl(x, x2, c1, w_hi, w_lo, y, nullptr, scale, shift, res, relu, n, h, w, cin, cout, kh, kw, stride, pad, reflect, 1,
                        ho, wo, precise, stream);
 }
@@ -208,6 +227,37 @@ int vqseg_im2col_f(int out_bf16, const float* x, int n, int h, int w, int cin, i
     hipError_t e = vqseg::launch_im2col_stem(out_bf16, x, n, h, w, cin, kh, kw, stride, pad, reflect, ho, wo, kp, out,
                                              static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hipfail(e, "im2col_stem_kernel");
+}
+
+int vqseg_conv_pack_weights_s3_f32(const float* w, int cout, int cin, int c1, int kh, int kw, void* out, void* stream) {
+    if (!w || !out || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || c1 <= 0 || c1 > cin || cin % 32 || c1 % 32)
+        return bad("conv_pack_weights_s3: bad argument (Cin and the concat split must be multiples of 32)");
+    hipError_t e = vqseg::launch_pack_weights_s3(w, cout, cin, c1, kh, kw, static_cast<unsigned short*>(out), static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "conv_pack_weights_s3");
+}
+
+int vqseg_s3_split_f(const float* x, int64_t rows, int c, void* y, void* stream) {
+    if (!x || !y || rows <= 0 || c <= 0 || c % 8 || !a16(x) || !a16(y)) return bad("s3_split: bad argument (channels % 8, 16-byte aligned)");
+    hipError_t e = vqseg::launch_s3_split(x, rows, c, y, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "s3_split_kernel");
+}
+
+int vqseg_s3_merge_f(const void* x, int64_t rows, int c, float* y, void* stream) {
+    if (!x || !y || rows <= 0 || c <= 0 || c % 8 || !a16(x) || !a16(y)) return bad("s3_merge: bad argument (channels % 8, 16-byte aligned)");
+    hipError_t e = vqseg::launch_s3_merge(x, rows, c, y, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "s3_merge_kernel");
+}
+
+int vqseg_s3_maxpool3x3s2_f(const void* x, int n, int h, int w, int c, void* y, void* stream) {
+    if (!x || !y || n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 8 || !a16(x) || !a16(y)) return bad("s3_maxpool: bad argument");
+    hipError_t e = vqseg::launch_s3_maxpool(x, n, h, w, c, y, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "s3_maxpool_kernel");
+}
+
+int vqseg_s3_bilinear_f(const void* x, int n, int h, int w, int c, int ho, int wo, int align_corners, void* y, void* stream) {
+    if (!x || !y || n <= 0 || h <= 0 || w <= 0 || ho <= 0 || wo <= 0 || c <= 0 || c % 8 || !a16(x) || !a16(y)) return bad("s3_bilinear: bad argument");
+    hipError_t e = vqseg::launch_s3_bilinear(x, n, h, w, c, ho, wo, align_corners, y, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "s3_bilinear_kernel");
 }
 
 int vqseg_reflect_fold_f(int bf16, const void* gp, int n, int h, int w, int c, void* gx, void* stream) {

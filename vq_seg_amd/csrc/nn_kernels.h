@@ -29,6 +29,10 @@ hipError_t launch_head_bwd(int bf16, const void* x, const float* w, const float*
 hipError_t launch_reduce_partials(const float* partial, long n_blocks, long n, float* out, int accumulate, hipStream_t st);
 hipError_t launch_im2col_stem(int out_bf16, const float* x, int N, int H, int W, int Cin, int KH, int KW, int stride, int pad,
                               int reflect, int Ho, int Wo, int Kp, void* out, hipStream_t st);
+hipError_t launch_s3_split(const float* x, long rows, int C, void* y, hipStream_t st);
+hipError_t launch_s3_merge(const void* x, long rows, int C, float* y, hipStream_t st);
+hipError_t launch_s3_maxpool(const void* x, int N, int H, int W, int C, void* y, hipStream_t st);
+hipError_t launch_s3_bilinear(const void* x, int N, int H, int W, int C, int Ho, int Wo, int align, void* y, hipStream_t st);
 hipError_t launch_reflect_fold(int bf16, const void* gp, int N, int H, int W, int C, void* gx, hipStream_t st);
 hipError_t launch_cast(int to_bf16, const void* x, long n, void* y, hipStream_t st);
 

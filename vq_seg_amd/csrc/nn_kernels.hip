@@ -847,6 +847,9 @@ __global__ __launch_bounds__(256) void im2col_stem_kernel(const TI* __restrict__
     }
 }
 
+struct S3Out { unsigned short raw; };                      // output tag of im2col_stem7_kernel: split-3 rows (see s3_* below)
+__device__ __forceinline__ void s3_store8(unsigned short* row, int C, int c, const float (&v)[8]);
+
 // the stem's own shape (7x7x3, compile-time divisors), 8 columns = one 16-byte (bf16) / two 16-byte (f32) stores per thread
 template <typename TO>
 __global__ __launch_bounds__(256) void im2col_stem7_kernel(const float* __restrict__ x, int N, int H, int W, int stride, int pad,
@@ -878,6 +881,10 @@ __global__ __launch_bounds__(256) void im2col_stem7_kernel(const float* __restri
                 if (ih >= 0 && ih < H && iw >= 0 && iw < W) v[e] = x[(((long)n * H + ih) * W + iw) * CIN + ci];
             }
         }
+        if constexpr (__is_same(TO, S3Out)) {              // split-3 rows [3 * Kp]: chunk ch of hi | lo | hi
+            const size_t row = (size_t)(i / cpr);
+            s3_store8(reinterpret_cast<unsigned short*>(out) + row * 3 * Kp, Kp, ch * 8, v);
+        } else {
         TO* dst = out + (size_t)i * 8;
         if constexpr (sizeof(TO) == 2) {
             u32x4 r;
@@ -891,6 +898,117 @@ __global__ __launch_bounds__(256) void im2col_stem7_kernel(const float* __restri
             *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
         }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// "split-3" activations (the fp32-precision eval forward on the bf16 kernels): a logical fp32 tensor [rows][C] is stored as
+// [rows][3C] bf16 = [hi | lo | hi], hi = bf16(v), lo = bf16(v - hi).  A plain bf16 convolution over the 3C channels with
+// weights [w_hi | w_hi | w_lo] computes x_hi w_hi + x_lo w_hi + x_hi w_lo -- the three products of the precise mode.
+// Elementwise ops on such tensors work on v = hi + lo (exact in fp32) and re-split.  8 logical channels per thread.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void s3_load8(const unsigned short* row, int C, int c, float (&v)[8]) {
+    const u32x4 h = *reinterpret_cast<const u32x4*>(row + c), l = *reinterpret_cast<const u32x4*>(row + C + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[2 * e] = __builtin_bit_cast(float, h[e] << 16) + __builtin_bit_cast(float, l[e] << 16);
+        v[2 * e + 1] = __builtin_bit_cast(float, h[e] & 0xFFFF0000u) + __builtin_bit_cast(float, l[e] & 0xFFFF0000u);
+    }
+}
+__device__ __forceinline__ unsigned s3_pack2(float a, float b) {
+    const __bf16 x = (__bf16)a, y = (__bf16)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ void s3_store8(unsigned short* row, int C, int c, const float (&v)[8]) {
+    u32x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = s3_pack2(v[2 * e], v[2 * e + 1]);
+        const float h0 = __builtin_bit_cast(float, h[e] << 16), h1 = __builtin_bit_cast(float, h[e] & 0xFFFF0000u);
+        l[e] = s3_pack2(v[2 * e] - h0, v[2 * e + 1] - h1);
+    }
+    *reinterpret_cast<u32x4*>(row + c) = h;
+    *reinterpret_cast<u32x4*>(row + C + c) = l;
+    *reinterpret_cast<u32x4*>(row + 2 * C + c) = h;
+}
+
+__global__ __launch_bounds__(256) void s3_split_kernel(const float* __restrict__ x, long rows, int C, unsigned short* __restrict__ y) {
+    const int cv = C / 8;
+    const long total = rows * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / cv;
+        const int c = (int)(i - r * cv) * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * C + c), b = *reinterpret_cast<const f32x4*>(x + r * C + c + 4);
+        const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        s3_store8(y + r * 3 * C, C, c, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void s3_merge_kernel(const unsigned short* __restrict__ x, long rows, int C, float* __restrict__ y) {
+    const int cv = C / 8;
+    const long total = rows * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / cv;
+        const int c = (int)(i - r * cv) * 8;
+        float v[8];
+        s3_load8(x + r * 3 * C, C, c, v);
+        *reinterpret_cast<f32x4*>(y + r * C + c) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(y + r * C + c + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+// nn.MaxPool2d(3, 2, 1) forward (no window positions: the split-3 path never runs a backward)
+__global__ __launch_bounds__(256) void s3_maxpool_kernel(const unsigned short* __restrict__ x, int N, int H, int W, int C, int Ho, int Wo,
+                                                         unsigned short* __restrict__ y) {
+    const int cv = C / 8;
+    const long total = (long)N * Ho * Wo * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c, ow, oh, n;
+        split_nhwc(i, cv, Wo, Ho, c, ow, oh, n);
+        c *= 8;
+        float best[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) best[e] = -__builtin_inff();
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            if (ih < 0 || ih >= H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                if (iw < 0 || iw >= W) continue;
+                float v[8];
+                s3_load8(x + (((long)n * H + ih) * W + iw) * 3 * C, C, c, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (v[e] > best[e] || v[e] != v[e]) best[e] = v[e];
+            }
+        }
+        s3_store8(y + (((long)n * Ho + oh) * Wo + ow) * 3 * C, C, c, best);
+    }
+}
+
+__global__ __launch_bounds__(256) void s3_bilinear_kernel(const unsigned short* __restrict__ x, int N, int H, int W, int C, int Ho, int Wo,
+                                                          int align, unsigned short* __restrict__ y) {
+    const int cv = C / 8;
+    const long total = (long)N * Ho * Wo * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c, ow, oh, n;
+        split_nhwc(i, cv, Wo, Ho, c, ow, oh, n);
+        c *= 8;
+        int h0, h1, w0, w1;
+        float lh, lw;
+        bil_src(oh, H, Ho, align, h0, h1, lh);
+        bil_src(ow, W, Wo, align, w0, w1, lw);
+        const long b = (long)n * H;
+        float v00[8], v01[8], v10[8], v11[8], o[8];
+        s3_load8(x + ((b + h0) * W + w0) * 3 * C, C, c, v00);
+        s3_load8(x + ((b + h0) * W + w1) * 3 * C, C, c, v01);
+        s3_load8(x + ((b + h1) * W + w0) * 3 * C, C, c, v10);
+        s3_load8(x + ((b + h1) * W + w1) * 3 * C, C, c, v11);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            o[e] = (1.0f - lh) * ((1.0f - lw) * v00[e] + lw * v01[e]) + lh * ((1.0f - lw) * v10[e] + lw * v11[e]);
+        s3_store8(y + (((long)n * Ho + oh) * Wo + ow) * 3 * C, C, c, o);
     }
 }
 
@@ -1095,11 +1213,34 @@ hipError_t launch_reduce_partials(const float* partial, long n_blocks, long n, f
     return hipGetLastError();
 }
 
+hipError_t launch_s3_split(const float* x, long rows, int C, void* y, hipStream_t st_) {
+    hipLaunchKernelGGL(s3_split_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, st_, x, rows, C, (unsigned short*)y);
+    return hipGetLastError();
+}
+hipError_t launch_s3_merge(const void* x, long rows, int C, float* y, hipStream_t st_) {
+    hipLaunchKernelGGL(s3_merge_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, st_, (const unsigned short*)x, rows, C, y);
+    return hipGetLastError();
+}
+hipError_t launch_s3_maxpool(const void* x, int N, int H, int W, int C, void* y, hipStream_t st_) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(s3_maxpool_kernel, dim3(grid_for((long)N * Ho * Wo * (C / 8))), dim3(256), 0, st_, (const unsigned short*)x, N, H, W,
+                       C, Ho, Wo, (unsigned short*)y);
+    return hipGetLastError();
+}
+hipError_t launch_s3_bilinear(const void* x, int N, int H, int W, int C, int Ho, int Wo, int align, void* y, hipStream_t st_) {
+    hipLaunchKernelGGL(s3_bilinear_kernel, dim3(grid_for((long)N * Ho * Wo * (C / 8))), dim3(256), 0, st_, (const unsigned short*)x, N, H,
+                       W, C, Ho, Wo, align, (unsigned short*)y);
+    return hipGetLastError();
+}
+
 hipError_t launch_im2col_stem(int out_bf16, const float* x, int N, int H, int W, int Cin, int KH, int KW, int stride, int pad,
                               int reflect, int Ho, int Wo, int Kp, void* out, hipStream_t st_) {
     if (KH == 7 && KW == 7 && Cin == 3 && Kp % 8 == 0 && (long)N * Ho * Wo * (Kp / 8) < (1L << 31)) {
         const unsigned g8 = grid_for((long)N * Ho * Wo * (Kp / 8));
-        if (out_bf16)
+        if (out_bf16 == 2)
+            hipLaunchKernelGGL((im2col_stem7_kernel<S3Out>), dim3(g8), dim3(256), 0, st_, x, N, H, W, stride, pad, reflect, Ho, Wo, Kp,
+                               (S3Out*)out);
+        else if (out_bf16)
             hipLaunchKernelGGL((im2col_stem7_kernel<__bf16>), dim3(g8), dim3(256), 0, st_, x, N, H, W, stride, pad, reflect, Ho, Wo, Kp,
                                (__bf16*)out);
         else
@@ -1107,6 +1248,7 @@ hipError_t launch_im2col_stem(int out_bf16, const float* x, int N, int H, int W,
                                (float*)out);
         return hipGetLastError();
     }
+    if (out_bf16 == 2) return hipErrorInvalidValue;          // split-3 patches: the 7x7x3 stem shape only
     const unsigned gr = grid_for((long)N * Ho * Wo * Kp);
     if (out_bf16)
         hipLaunchKernelGGL((im2col_stem_kernel<float, __bf16>), dim3(gr), dim3(256), 0, st_, x, N, H, W, Cin, KH, KW, stride, pad,

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from .... import nnf
-from ....vector_quantizer import make_vq_module
+from ....vector_quantizer import make_vq_module, Identity as _IdentityVQ
 from ...encoders import make_encoder
 from ...modules.prototype import ReliablePrototypeLoss, ReliablePrototypeLossv2
 from ..unet.decoder import UnetDecoder
@@ -62,7 +62,9 @@ class _VQRePTUnet1x1Base(nn.Module):
     def encode(self, x):
         if self.device is None:
             self.device = x.device
-        feats = self.encoder(_to_device_layout(x))[1:]
+        # a no-grad eval-mode fp32 forward (the trainers' pseudo-label passes) runs in split-3 form on the bf16 kernels (nnf.S3)
+        with nnf.s3_scope(not self.training and not torch.is_grad_enabled()):
+            feats = self.encoder(_to_device_layout(x))[1:]
         if len(feats) != len(self.codebook):
             raise NotImplementedError
         return feats
@@ -71,6 +73,8 @@ class _VQRePTUnet1x1Base(nn.Module):
         loss = torch.zeros(1, device=feats[0].device)
         usage = []
         for i, vq in enumerate(self.codebook):
+            if isinstance(feats[i], nnf.S3) and not isinstance(vq, _IdentityVQ):  # VQ layers take fp32 rows; Identity passes through
+                feats[i] = feats[i].float()
             quantize, _idx, commitment, dead = vq(feats[i])
             feats[i] = quantize
             if commitment is not None:

@@ -43,6 +43,8 @@ class UnetDecoder(nn.Module):
     def forward(self, *features):
         dt = features[0].dtype                                      # activation dtype of the un-quantised skips
         feats = [_nnf.cast_act(f, dt) for f in features[::-1]]      # (the VQ layer always returns fp32, vq_img.py:229)
+        if any(isinstance(f, _nnf.S3) for f in feats):              # split-3 eval forward: the quantised levels join it
+            feats = [_nnf.to_s3(f) for f in feats]
         out = self.blocks[0][1](self.blocks[0][0](feats[0]))
         for i in range(1, len(self.blocks)):
             up = _nnf.upsample_bilinear(out, size=feats[i].shape[-2:], align_corners=False)

@@ -150,6 +150,134 @@ def _sink_done(p) -> None:
 
 
 # ------------------------------------------------------------------------------------------------
+# "Split-3" activations: the fp32-precision no-grad eval forward on the bf16 kernels (include/vqseg.h, "Split-3").
+# The reference trainers run their two pseudo-label forwards in fp32, OUTSIDE autocast (train_vqreptunet1x1v2.py:143-149).
+# The "precise" kernels do that with on-the-fly bf16 hi/lo splits inside a register-staged kernel; here the SAME three products
+# run on the LDS-DMA / patch-reuse bf16 kernels by keeping every activation of such a forward as [hi | lo | hi] bf16.
+# An `S3` object stands in for the logical (N, C, H, W) fp32 tensor between the layers of ONE model forward; it never leaves
+# the model (the model's `encode` opens the scope, the 1x1 head / the VQ layers merge back to fp32).
+# ------------------------------------------------------------------------------------------------
+class S3:
+    """rows: (N, H, W, 3C) bf16 contiguous = [hi | lo | hi] of the logical fp32 tensor (N, C, H, W)."""
+    __slots__ = ("rows", "c")
+
+    def __init__(self, rows: torch.Tensor, c: int):
+        self.rows, self.c = rows, c
+
+    @property
+    def shape(self):
+        n, h, w, _ = self.rows.shape
+        return torch.Size((n, self.c, h, w))
+
+    dtype = torch.float32                                    # what the tensor logically is
+    is_cuda = True
+    requires_grad = False
+
+    @property
+    def device(self):
+        return self.rows.device
+
+    def float(self) -> torch.Tensor:
+        """merge back: logical (N, C, H, W) fp32 tensor (channels_last in memory)"""
+        n, h, w, _ = self.rows.shape
+        out = torch.empty((n, h, w, self.c), dtype=torch.float32, device=self.rows.device)
+        with torch.cuda.device(out.device):
+            _check(lib().vqseg_s3_merge_f(self.rows.data_ptr(), n * h * w, self.c, out.data_ptr(), _stream()), "vqseg_s3_merge_f")
+        return _nchw(out)
+
+
+_S3_SCOPE = False
+
+
+class s3_scope:
+    """Inside this scope a no-grad, eval-mode, fp32 (not autocast) stem starts a split-3 forward (opened by the VQ-UNet's own
+    `encode`; a bare `model.encoder(x)` call therefore keeps returning plain fp32 tensors).  VQSEG_OPTS=py_s3_eval=0 disables."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = bool(enabled) and py_opt("py_s3_eval", 1) == 1
+
+    def __enter__(self):
+        global _S3_SCOPE
+        self.prev = _S3_SCOPE
+        _S3_SCOPE = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _S3_SCOPE
+        _S3_SCOPE = self.prev
+        return False
+
+
+def to_s3(x) -> "S3":
+    """logical (N, C, H, W) fp32 (or bf16) tensor -> split-3"""
+    if isinstance(x, S3):
+        return x
+    xr = _rows(x.float())
+    n, h, w, c = xr.shape
+    out = torch.empty((n, h, w, 3 * c), dtype=torch.bfloat16, device=xr.device)
+    with torch.cuda.device(xr.device):
+        _check(lib().vqseg_s3_split_f(xr.data_ptr(), n * h * w, c, out.data_ptr(), _stream()), "vqseg_s3_split_f")
+    return S3(out, c)
+
+
+def from_s3(x):
+    return x.float() if isinstance(x, S3) else x
+
+
+def _s3_weights(weight: torch.Tensor, c1: int, as_1x1_cols: int = 0) -> torch.Tensor:
+    """[w_hi | w_hi | w_lo] image per concat segment (vqseg_conv_pack_weights_s3_f32), cached on the Parameter."""
+    cache = _cache_of(weight)
+    k = ("s3", c1, as_1x1_cols)
+    if k not in cache:
+        w = weight.detach()
+        if as_1x1_cols:                                      # the stem: [64][3][7][7] as a 1x1 convolution over kp patch columns
+            cout, cin, kh, kw = w.shape
+            w2 = torch.zeros(cout, as_1x1_cols, 1, 1, dtype=torch.float32, device=w.device)
+            w2[:, :kh * kw * cin, 0, 0] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw * cin)
+            w = w2
+        w = w if w.is_contiguous() else w.contiguous()
+        cout, cin, kh, kw = w.shape
+        out = torch.empty(cout * kh * kw * 3 * cin, dtype=torch.int16, device=w.device)
+        with torch.cuda.device(w.device):
+            _check(lib().vqseg_conv_pack_weights_s3_f32(_dev(w, torch.float32, "weight"), cout, cin, c1, kh, kw, out.data_ptr(), _stream()),
+                   "vqseg_conv_pack_weights_s3_f32")
+        cache[k] = out
+    return cache[k]
+
+
+def _conv_bn_act_s3(x: "S3", x2, residual, conv, bn, relu, kernel_1x1_cols: int = 0) -> "S3":
+    """eval-mode Conv -> BN -> [+ residual] -> [ReLU] on split-3 tensors: the convolution's fused epilogue (precise = 2)."""
+    n, h, w, c3 = x.rows.shape
+    c1 = x.c
+    x2s = to_s3(x2) if x2 is not None else None
+    cin = c1 + (x2s.c if x2s is not None else 0)
+    cout = conv.weight.shape[0]
+    if kernel_1x1_cols:
+        kh = kw = 1
+        stride, pad, reflect = 1, 0, False
+    else:
+        kh, kw = conv.weight.shape[2], conv.weight.shape[3]
+        stride, pad = conv.stride[0], conv.padding[0]
+        reflect = conv.padding_mode == "reflect" and pad > 0
+    ho, wo = _out_size(h, kh, stride, pad), _out_size(w, kw, stride, pad)
+    dev = x.rows.device
+    L = lib()
+    wimg = _s3_weights(conv.weight, c1, kernel_1x1_cols)
+    res = to_s3(residual) if residual is not None else None
+    coef = torch.empty(4, cout, dtype=torch.float32, device=dev)
+    out = torch.empty((n, ho, wo, 3 * cout), dtype=torch.bfloat16, device=dev)
+    with torch.cuda.device(dev):
+        _check(L.vqseg_bn_finalize_f(None, n * ho * wo, cout, _dev(bn.weight, torch.float32, "bn.weight"), _dev(bn.bias, torch.float32, "bn.bias"),
+                                     _p(bn.running_mean), _p(bn.running_var), float(bn.momentum), float(bn.eps), 0, coef[0].data_ptr(),
+                                     coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), None, _stream()), "vqseg_bn_finalize_f")
+        _check(L.vqseg_conv2d_affine_f(x.rows.data_ptr(), x2s.rows.data_ptr() if x2s is not None else None, c1, wimg.data_ptr(), None,
+                                       coef[0].data_ptr(), coef[1].data_ptr(), res.rows.data_ptr() if res is not None else None, int(relu),
+                                       out.data_ptr(), n, h, w, cin, cout, kh, kw, stride, pad, int(reflect), ho, wo, 2, _stream()),
+               "vqseg_conv2d_affine_f (split-3)")
+    return S3(out, cout)
+
+
+# ------------------------------------------------------------------------------------------------
 # Conv (no bias) -> BatchNorm -> [+ residual] -> [ReLU], optional channel concat of two inputs
 # ------------------------------------------------------------------------------------------------
 class _ConvBNAct(torch.autograd.Function):
@@ -342,6 +470,10 @@ def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None, l
     BatchNorm module's own mode decides (nn.BatchNorm2d semantics)."""
     if conv.bias is not None:
         raise NotImplementedError("conv_bn_act: the reference's fused blocks have no conv bias")
+    if isinstance(x, S3) or isinstance(x2, S3) or isinstance(residual, S3):
+        if not bn.training and not torch.is_grad_enabled():
+            return _conv_bn_act_s3(to_s3(x), x2, residual, conv, bn, relu)
+        x, x2, residual = from_s3(x), (from_s3(x2) if x2 is not None else None), (from_s3(residual) if residual is not None else None)
     if not x.is_cuda:
         raise _hip.HipLibraryError(f"the HIP path needs 'cuda' (ROCm) tensors, got {x.device}; there is no CPU fallback")
     pad = conv.padding[0]
@@ -398,6 +530,19 @@ def stem_conv_bn_act(x, conv, bn):
     ho, wo = _out_size(h, kh, s, p), _out_size(w, kw, s, p)
     kp = (kh * kw * cin + 31) // 32 * 32
     dt = act_dtype()
+    if _S3_SCOPE and dt == torch.float32 and not bn.training and not torch.is_grad_enabled() and (kh, kw, cin) == (7, 7, 3):
+        # fp32-precision eval forward: split-3 patch rows (64-column multiple: the LDS-DMA kernels), then everything stays split-3
+        kp3 = (kh * kw * cin + 63) // 64 * 64
+
+        def make3():
+            out = torch.empty((n, ho, wo, 3 * kp3), dtype=torch.bfloat16, device=x.device)
+            with torch.cuda.device(x.device):
+                _check(lib().vqseg_im2col_f(2, xr.data_ptr(), n, h, w, cin, kh, kw, s, p, int(reflect), ho, wo, kp3, out.data_ptr(), _stream()),
+                       "vqseg_im2col_f (split-3)")
+            return out
+
+        patches = _shared_stem_patches(x, ("s3", kh, kw, s, p, reflect), make3)
+        return _conv_bn_act_s3(S3(patches, kp3), None, None, conv, bn, True, kernel_1x1_cols=kp3)
 
     def make():
         out = torch.empty((n, ho, wo, kp), dtype=dt, device=x.device)
@@ -441,6 +586,13 @@ class _MaxPool(torch.autograd.Function):
 
 
 def max_pool_3x3_s2(x):
+    if isinstance(x, S3):
+        n, h, w, _ = x.rows.shape
+        ho, wo = _out_size(h, 3, 2, 1), _out_size(w, 3, 2, 1)
+        y = torch.empty((n, ho, wo, 3 * x.c), dtype=torch.bfloat16, device=x.rows.device)
+        with torch.cuda.device(y.device):
+            _check(lib().vqseg_s3_maxpool3x3s2_f(x.rows.data_ptr(), n, h, w, x.c, y.data_ptr(), _stream()), "vqseg_s3_maxpool3x3s2_f")
+        return S3(y, x.c)
     return _MaxPool.apply(x)
 
 
@@ -470,6 +622,13 @@ class _Bilinear(torch.autograd.Function):
 def upsample_bilinear(x, size=None, scale_factor=None, align_corners=False):
     if size is None:
         size = (int(x.shape[-2] * scale_factor), int(x.shape[-1] * scale_factor))
+    if isinstance(x, S3):
+        n, h, w, _ = x.rows.shape
+        y = torch.empty((n, int(size[0]), int(size[1]), 3 * x.c), dtype=torch.bfloat16, device=x.rows.device)
+        with torch.cuda.device(y.device):
+            _check(lib().vqseg_s3_bilinear_f(x.rows.data_ptr(), n, h, w, x.c, int(size[0]), int(size[1]), int(bool(align_corners)),
+                                             y.data_ptr(), _stream()), "vqseg_s3_bilinear_f")
+        return S3(y, x.c)
     return _Bilinear.apply(x, int(size[0]), int(size[1]), bool(align_corners))
 
 
@@ -506,7 +665,7 @@ class _Head1x1(torch.autograd.Function):
 
 
 def head_conv1x1(x, weight):
-    return _Head1x1.apply(x, weight)
+    return _Head1x1.apply(from_s3(x), weight)
 
 
 class _Cast(torch.autograd.Function):
@@ -528,6 +687,8 @@ class _Cast(torch.autograd.Function):
 
 def cast_act(x, dtype):
     """f32 <-> bf16 activation cast (NHWC), differentiable."""
+    if isinstance(x, S3):
+        return x if dtype == torch.float32 else cast_act(x.float(), dtype)
     if x.dtype == dtype:
         return x
     if {x.dtype, dtype} != {torch.float32, torch.bfloat16}:
