@@ -337,12 +337,30 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const TX* __restr
     }
 }
 
+// keys -> int64 code indices (+ the winning distance), and the code histogram of the dead-code statistic (vq_img.py:173-175):
+// counted per workgroup in LDS (few codes win most rows -- thousands of rows per address: global atomics would serialise in the
+// L2 atomic units; round 1 did that from the gather kernel and sat at ~1 TB/s), then one global add per NON-EMPTY bin and
+// workgroup.  Integer adds: order independent, deterministic.
 __global__ __launch_bounds__(256) void vq_unpack_keys(const unsigned long long* __restrict__ keys, long N,
-                                                      long long* __restrict__ idx, float* __restrict__ dmin) {
+                                                      long long* __restrict__ idx, float* __restrict__ dmin,
+                                                      int* __restrict__ hist, int K) {
+    extern __shared__ int lh[];
+    if (hist)
+        for (int k = threadIdx.x; k < K; k += 256) lh[k] = 0;
+    __syncthreads();
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) {
         const unsigned long long k = keys[i];
-        idx[i] = (long long)(k & 0xffffffffull);
+        const unsigned code = (unsigned)(k & 0xffffffffull);
+        idx[i] = (long long)code;
         if (dmin) dmin[i] = __uint_as_float((unsigned int)(k >> 32));
+        if (hist && code < (unsigned)K) atomicAdd(lh + code, 1);
+    }
+    if (hist) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < K; k += 256) {
+            const int c = lh[k];
+            if (c) atomicAdd(hist + k, c);
+        }
     }
 }
 
@@ -381,7 +399,7 @@ template <typename TA>
 __global__ __launch_bounds__(256) void vq_gather_kernel(const TA* __restrict__ x, const float* __restrict__ W,
                                                         const long long* __restrict__ idx, long N, int C,
                                                         int training, TA* __restrict__ quant,
-                                                        int* __restrict__ hist, float* __restrict__ partial) {
+                                                        float* __restrict__ partial) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4 = C >> 2;
     float sq = 0.0f;
@@ -392,7 +410,6 @@ __global__ __launch_bounds__(256) void vq_gather_kernel(const TA* __restrict__ x
         long long k[RG];
 #pragma unroll
         for (int j = 0; j < RG; ++j) k[j] = row0 + j < N ? idx[row0 + j] : 0;
-        if (lane < RG && row0 + lane < N) atomicAdd(hist + idx[row0 + lane], 1);
         for (int v = lane; v < c4; v += 64) {
             f32x4 e[RG], xv[RG];
 #pragma unroll
@@ -827,10 +844,14 @@ hipError_t launch_assign(const void* x, int x_bf16, int64_t N, int C, int K, con
     }
 #undef VQ_ASSIGN
     if (rec) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
-    long blocks = (N + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(vq_unpack_keys, dim3((unsigned)blocks), dim3(256), 0, st, keys, (long)N,
-                       reinterpret_cast<long long*>(idx), dmin);
+    int* hist = reinterpret_cast<int*>(ws + p.off_hist);
+    e = hipMemsetAsync(hist, 0, (size_t)p.Kp * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    long blocks = (N + 1023) / 1024;                            // >= 1024 rows per workgroup: the LDS histogram pays
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(vq_unpack_keys, dim3((unsigned)blocks), dim3(256), (size_t)K * sizeof(int), st, keys, (long)N,
+                       reinterpret_cast<long long*>(idx), dmin, hist, K);
     return hipGetLastError();
 }
 
@@ -838,14 +859,13 @@ hipError_t launch_gather(const void* x, int bf16, const float* W, const int64_t*
                          float cw, const VqPlan& p, char* ws, void* quant, float* loss, float* dead, hipStream_t st) {
     int* hist = reinterpret_cast<int*>(ws + p.off_hist);
     float* partial = reinterpret_cast<float*>(ws + p.off_partial);
-    hipError_t e = hipMemsetAsync(hist, 0, (size_t)p.Kp * sizeof(int), st);
-    if (e != hipSuccess) return e;
+    // hist: filled by launch_assign (vq_unpack_keys), which every forward runs first on the same workspace
     if (bf16)
         hipLaunchKernelGGL(vq_gather_kernel<__bf16>, dim3(p.gather_blocks), dim3(256), 0, st, static_cast<const __bf16*>(x), W,
-                           reinterpret_cast<const long long*>(idx), (long)N, C, training, static_cast<__bf16*>(quant), hist, partial);
+                           reinterpret_cast<const long long*>(idx), (long)N, C, training, static_cast<__bf16*>(quant), partial);
     else
         hipLaunchKernelGGL(vq_gather_kernel<float>, dim3(p.gather_blocks), dim3(256), 0, st, static_cast<const float*>(x), W,
-                           reinterpret_cast<const long long*>(idx), (long)N, C, training, static_cast<float*>(quant), hist, partial);
+                           reinterpret_cast<const long long*>(idx), (long)N, C, training, static_cast<float*>(quant), partial);
     hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, partial, p.gather_blocks, hist, K, training, cw,
                        (double)N * (double)C, loss, dead);
     return hipGetLastError();
