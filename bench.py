@@ -191,7 +191,14 @@ def main():
             names = [f"model{i}.{k}" for i, m in enumerate(trainer.models) for k, _ in m.named_parameters()]
             bad = [names[j] for j in range(len(names)) if any(g[j] != gathered[0][j] for g in gathered)]
             raise AssertionError(f"ranks diverged in {len(bad)} of {len(names)} parameters, e.g. {bad[:6]} ... {bad[-3:]}")
-        note(f"rank {rank}: parameter checksums identical on all {world} ranks")
+        trainer.sync_buffers()                                # BatchNorm statistics are per-rank by design; after the sync they agree too
+        chk = torch.stack([b.detach().double().sum() for m in trainer.models for b in m.buffers()]).cpu()
+        gathered = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(gathered, chk)
+        assert all(torch.equal(g, gathered[0]) for g in gathered), "buffers differ after sync_buffers()"
+        in_bwd = [sum(b.launched_in_backward) for b in trainer.buckets]
+        note(f"rank {rank}: parameter and (synced) buffer checksums identical on all {world} ranks; buckets reduced inside backward: "
+             f"{in_bwd} of {[len(b.buckets) for b in trainer.buckets]}")
 
     recs = _hip.profile_collect(64 * args.steps) if rank == 0 else []
     # next to the CPS figure, plain forward + backward + Adam of ONE network on the B labelled images

@@ -49,10 +49,16 @@ def _grad_job(rank, world):
     buckets = GradBuckets(params, bucket_mb=0.0003)          # tiny buckets -> several all-reduces
     assert len(buckets.buckets) >= 3
     x = torch.arange(8.0).repeat(3, 1) * (rank + 1)
-    for _ in range(2):                                       # second iteration checks zero() / re-arming
+    in_bwd = []
+    for _ in range(3):                                       # later iterations check zero() / re-arming
         buckets.zero()
         net(x).pow(2).sum().backward()
         buckets.finish()
+        in_bwd.append(list(buckets.launched_in_backward))
+    # step 1: the bucket holding the gradient-free parameter cannot complete inside backward; once it has been learnt
+    # (finish() of step 1) every bucket is reduced from inside backward
+    assert not all(in_bwd[0]) and all(in_bwd[1]) and all(in_bwd[2]), in_bwd
+    assert buckets._silent == {id(frozen)}
     return [p.grad.clone() for p in params]
 
 

@@ -64,6 +64,14 @@ class GradBuckets:
         self._launched = [False] * len(groups)
         self._handles = []
         self._reported = set()
+        # parameters that never report a gradient (the frozen codebooks -- vq_img.py:236-239 -- and, in the v1 model, the prototypes
+        # that enter through `.data`, prototype.py:556) would keep their buckets from ever completing inside backward: they are
+        # learnt on the first step (whoever has not reported by finish()) and left out of the count from then on
+        self._silent = None
+        self._names = {}
+        self.launched_in_backward = []                     # per step: which buckets were reduced from inside backward (tests)
+        # RCCL has an averaging reduction; gloo (CPU tests, rehearsal) does not: sum, then scale
+        self._avg = dist.ReduceOp.AVG if (self.world > 1 and dist.get_backend() == "nccl") else None
         self.producer_streams = []          # set by CPSTrainer: the side stream(s) the gradient kernels of these params run on
         for p in self.params:
             # the HIP weight-gradient kernels add straight into the bucket views (nnf grad sinks) and report here;
@@ -78,6 +86,9 @@ class GradBuckets:
         for p in self.params:
             p._vq_uses = 0
         self._pending = list(self._sizes)
+        if self._silent:
+            for pid in self._silent:
+                self._pending[self.owner[pid]] -= 1
         self._launched = [False] * len(self.buckets)
         self._handles = []
         self._reported = set()
@@ -92,7 +103,7 @@ class GradBuckets:
             for s in self.producer_streams:
                 if s != cur:
                     cur.wait_stream(s)
-        self._handles.append(dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, async_op=True))
+        self._handles.append(dist.all_reduce(self.buckets[bi], op=self._avg or dist.ReduceOp.SUM, async_op=True))
 
     def _on_grad(self, p):
         # A sunk parameter reports through its sink (last contribution) AND, later, through the post-accumulate hook
@@ -101,6 +112,12 @@ class GradBuckets:
             return
         self._reported.add(id(p))
         bi = self.owner[id(p)]
+        if self._silent and id(p) in self._silent:
+            if self._launched[bi]:
+                raise RuntimeError("a parameter classified as gradient-free on the first step produced a gradient after its bucket had "
+                                   "been reduced; call GradBuckets.relearn() when the set of trained parameters changes")
+            self._silent.discard(id(p))                    # it does report after all: count it again from the next step on
+            return
         self._pending[bi] -= 1
         if self._pending[bi] == 0 and not self._launched[bi]:
             self._launch(bi)
@@ -110,13 +127,21 @@ class GradBuckets:
         their bucket from completing), wait, average."""
         if self.world == 1:
             return
+        self.launched_in_backward = list(self._launched)
+        if self._silent is None:
+            self._silent = {id(p) for p in self.params if id(p) not in self._reported}
         for bi in range(len(self.buckets)):
             if not self._launched[bi]:
                 self._launch(bi)
         for h in self._handles:
             h.wait()
-        for b in self.buckets:
-            b.mul_(1.0 / self.world)
+        if self._avg is None:                              # gloo: no averaging reduction
+            for b in self.buckets:
+                b.mul_(1.0 / self.world)
+
+    def relearn(self):
+        """forget which parameters are gradient-free (after freezing / unfreezing parts of the model)"""
+        self._silent = None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -389,6 +414,22 @@ class CPSTrainer:
         return {"loss": loss.detach(), "sup_loss_1": sup_1.detach(), "sup_loss_2": sup_2.detach(), "cps_loss": cps.detach(),
                 "commitment_loss": commitment.detach().sum(), "prototype_loss": prototype.detach(), "miou": miou,
                 "lr": torch.tensor(lr)}
+
+    def sync_buffers(self):
+        """Data parallel: BatchNorm running statistics are per-rank (each rank normalises with its own batch statistics -- the
+        reference's single-device semantics per rank; parameters and codebooks ARE identical on all ranks).  This broadcasts
+        rank 0's buffers so that every rank holds the state a checkpoint written by rank 0 contains."""
+        if vdist.world_size() > 1:
+            for m in self.models:
+                for b in m.buffers():
+                    dist.broadcast(b.data, src=0)
+
+    def state_dicts(self, sync: bool = True):
+        """(model_1, model_2, optimizer_1, optimizer_2) state_dicts for utils.ckpoints.save_ckpoints; `sync` first makes the
+        BatchNorm buffers rank 0's on every rank (see sync_buffers), so that any rank may write the file."""
+        if sync:
+            self.sync_buffers()
+        return (self.models[0].state_dict(), self.models[1].state_dict(), self.opts[0].state_dict(), self.opts[1].state_dict())
 
     def _ce_dice(self, pred, target):
         """0.5 * CE(ignore 255) + criterion (train_vqreptunet1x1v2.py:165-187); with the Dice criterion both terms come from
