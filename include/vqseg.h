@@ -89,6 +89,16 @@ int vqseg_vq_forward_f32(const float* x, const float* codebook, const void* prep
                          float* dead_pct, float* dmin, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* The same forward for up to 4 independent layers ("levels") in ONE distance + argmin launch: the three VQ layers of a
+ * VQ-UNet forward (net.py:1183-1191 calls them one after the other; they are independent).  Arrays of n_levels entries;
+ * every level with its own workspace (vqseg_vq_workspace_bytes of ITS shape); one row type per call (bf16 != 0: bf16 rows /
+ * quantised rows).  Results are bit-identical to n_levels single calls. */
+int vqseg_vq_forward_group(int n_levels, int bf16, const void* const* x, const float* const* codebook,
+                           const void* const* prepared, const int64_t* n_rows, const int* channels, const int* n_codes,
+                           int training, const float* commitment_weight, void* const* quant, int64_t* const* idx,
+                           float* const* loss, float* const* dead_pct, void* const* workspace,
+                           const size_t* workspace_bytes, void* stream);
+
 /* Assignment only (no gather): used by k-means and by tests. */
 int vqseg_vq_assign_f32(const float* x, const float* codebook, const void* prepared,
                         int64_t n_rows, int channels, int n_codes, int64_t* idx, float* dmin,

@@ -306,3 +306,50 @@ def test_ema_module_updates_after_quantising_and_keeps_the_gradient(amp):
     rows_d = x.permute(0, 2, 3, 1).reshape(-1, 64).contiguous()
     from vq_seg_amd import _hip
     assert torch.equal(idx2.reshape(-1), _hip.vq_assign(rows_d, w1))         # ... and the NEW codebook is the one in use
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("training", [False, True])
+def test_grouped_forward_is_bit_identical_to_single_launches(dtype, training):
+    """vqseg_vq_forward_group (one distance + argmin launch for the three levels of a forward, longest workgroups first) against
+    three vqseg_vq_forward_* calls: every output bit for bit, at the levels' real channel counts, ragged row counts included."""
+    from vq_seg_amd import _hip
+    shapes = [(1000, 512, 512), (520, 1024, 512), (136, 2048, 256)]
+    rows, books = [], []
+    for i, (n, c, k) in enumerate(shapes):
+        rows.append(synth.relu_features(40 + i, (n, c)).to(dev()).to(dtype))
+        books.append(synth.relu_features(50 + i, (k, c), sparsity=0.3, scale=1.5).to(dev()))
+    preps = [_hip.vq_prepare(w) for w in books]
+    single = [_hip.vq_forward(r, w, training, 0.25 * (i + 1), prepared=p) for i, (r, w, p) in enumerate(zip(rows, books, preps))]
+    group = _hip.vq_forward_group(rows, books, preps, training, [0.25 * (i + 1) for i in range(3)])
+    for s, g in zip(single, group):
+        for a, b in zip(s, g):
+            assert torch.equal(a, b)
+
+
+def test_model_quantize_uses_the_grouped_launch_and_matches_per_level_calls():
+    from vq_seg_amd import _hip
+    from vq_seg_amd.vector_quantizer import make_vq_module
+    enc = (3, 64, 256, 512, 1024, 2048)
+    mods = make_vq_module({"num_embeddings": [0, 0, 64, 64, 32], "distance": "euclidean", "kmeans_init": False}, enc, 5).to(dev())
+    feats = [synth.relu_features(60 + i, (2, enc[i + 1], 64 >> i, 64 >> i)).to(dev()).contiguous(memory_format=torch.channels_last)
+             for i in range(5)]
+    from vq_seg_amd.vector_quantizer import quantize_group
+    for training in (False, True):
+        mods.train(training)
+        xs = [f.clone().requires_grad_(True) for f in feats[2:]]
+        grouped = quantize_group(list(mods[2:]), xs)
+        assert grouped is not None
+        ys = [f.clone().requires_grad_(True) for f in feats[2:]]
+        single = [m(y) for m, y in zip(mods[2:], ys)]
+        for g, s_ in zip(grouped, single):
+            for a, b in zip(g, s_):
+                assert torch.equal(a, b)
+        if training:
+            sum((q * 0.5).sum() + l.sum() for q, _i, l, _d in grouped).backward()
+            sum((q * 0.5).sum() + l.sum() for q, _i, l, _d in single).backward()
+            for x, y in zip(xs, ys):
+                assert torch.equal(x.grad, y.grad)
+    mods[2].codebook.kmeans_init, mods[2].codebook.initted = True, False           # k-means pending -> not groupable
+    mods.train(True)
+    assert quantize_group(list(mods[2:]), feats[2:]) is None

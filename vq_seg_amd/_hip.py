@@ -29,6 +29,7 @@ SYMBOLS = {
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vqseg_vq_forward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vqseg_vq_forward_group": (c_int, [c_int, c_int] + [c_void_p] * 6 + [c_int, c_void_p] + [c_void_p] * 6 + [c_void_p]),
     "vqseg_vq_backward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "vqseg_vq_assign_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_size_t, c_void_p]),
@@ -192,6 +193,40 @@ def vq_forward(rows: torch.Tensor, codebook: torch.Tensor, training: bool, commi
     _check(rc, "vqseg_vq_forward_f32")
     out = (quant, idx, scal[0:1], scal[1])
     return out + (dmin,) if want_dmin else out
+
+
+def vq_forward_group(rows_list, codebooks, prepared_list, training: bool, commitment_weights):
+    """vq_forward for several independent layers with ONE distance + argmin launch (vqseg_vq_forward_group).
+    -> list of (quant, idx, loss (1,), dead_pct ()) per level; bit-identical to per-level vq_forward calls."""
+    import numpy as np
+    L = lib()
+    nl = len(rows_list)
+    bf16 = rows_list[0].dtype == torch.bfloat16
+    dev = rows_list[0].device
+    outs, keep = [], []
+    ptr = lambda ts: (c_void_p * nl)(*[t.data_ptr() for t in ts])
+    ns = np.array([r.shape[0] for r in rows_list], dtype=np.int64)
+    cs = np.array([r.shape[1] for r in rows_list], dtype=np.int32)
+    ks = np.array([w.shape[0] for w in codebooks], dtype=np.int32)
+    cw = np.array([float(w) for w in commitment_weights], dtype=np.float32)
+    quants, idxs, scals, wss = [], [], [], []
+    for r, w in zip(rows_list, codebooks):
+        if r.dtype != rows_list[0].dtype:
+            raise HipLibraryError("vq_forward_group: one row type per call")
+        _dev(r, r.dtype if bf16 else torch.float32, "rows"), _dev(w, torch.float32, "codebook")
+        quants.append(torch.empty_like(r))
+        idxs.append(torch.empty(r.shape[0], dtype=torch.int64, device=dev))
+        scals.append(torch.empty(2, dtype=torch.float32, device=dev))
+        wss.append(_workspace(L.vqseg_vq_workspace_bytes(r.shape[0], r.shape[1], w.shape[0]), dev))
+    wsb = (c_size_t * nl)(*[w.numel() for w in wss])
+    loss_p = (c_void_p * nl)(*[s.data_ptr() for s in scals])
+    dead_p = (c_void_p * nl)(*[s.data_ptr() + 4 for s in scals])
+    with torch.cuda.device(dev):
+        rc = L.vqseg_vq_forward_group(nl, int(bf16), ptr(rows_list), ptr(codebooks), ptr(prepared_list), ns.ctypes.data, cs.ctypes.data,
+                                      ks.ctypes.data, int(bool(training)), cw.ctypes.data, ptr(quants), ptr(idxs), loss_p, dead_p,
+                                      ptr(wss), ctypes.cast(wsb, c_void_p), _stream())
+    _check(rc, "vqseg_vq_forward_group")
+    return [(q, i, s[0:1], s[1]) for q, i, s in zip(quants, idxs, scals)]
 
 
 def vq_assign(rows: torch.Tensor, codebook: torch.Tensor, want_dmin: bool = False,

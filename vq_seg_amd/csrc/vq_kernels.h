@@ -24,6 +24,22 @@ struct KmPlan {
 struct ProfShape {
     int64_t n;
     int c, k;
+    int slot, group;            // first record of the launch this level ran in (its event pair), number of levels in that launch
+};
+
+constexpr int VQ_MAX_LEVELS = 4;
+struct VqLevel {
+    const void* x;              // pixel rows [N][C] (f32 or bf16: one type per launch)
+    const float* E4;            // prepared codebook
+    const float* enorm;
+    unsigned long long* keys;   // [N] (distance bits << 32 | code), pre-set to ~0
+    long N;
+    int C, Kp;
+    unsigned wg_end;            // exclusive end of this level's workgroup ids in the launch
+};
+struct VqGroup {
+    VqLevel lv[VQ_MAX_LEVELS];
+    int n;
 };
 struct Profile {
     bool enabled = false;
@@ -42,6 +58,10 @@ size_t prepared_bytes(int C, int K);
 hipError_t launch_prepare(const float* W, int K, int C, void* prepared, hipStream_t st);
 hipError_t launch_assign(const void* x, int x_bf16, int64_t N, int C, int K, const void* prepared, const VqPlan& p, char* ws,
                          int64_t* idx, float* dmin, hipStream_t st);
+int vq_group_tiles(int n, const int64_t* N, const int* K);
+hipError_t launch_assign_group(int n, const void* const* x, int x_bf16, const int64_t* N, const int* C, const int* K,
+                               const void* const* prepared, const VqPlan* plans, char* const* ws, int64_t* const* idx,
+                               float* const* dmin, int T, hipStream_t st);
 hipError_t launch_gather(const void* x, int bf16, const float* W, const int64_t* idx, int64_t N, int C, int K, int training,
                          float cw, const VqPlan& p, char* ws, void* quant, float* loss, float* dead, hipStream_t st);
 hipError_t launch_backward(const float* gq, const float* gloss, const float* x, const float* q, int64_t N, int C,

@@ -116,12 +116,20 @@ template <typename TX> struct RawFrag { typedef f32x4 type; };
 template <> struct RawFrag<__bf16> { typedef u32x2 type; };
 
 // TX: storage type of the pixel rows (float, or __bf16 -- every bf16 value is an exact float, the arithmetic is the same)
+// One launch serves up to VQ_MAX_LEVELS independent quantisation problems ("levels": the three VQ layers of one forward).
+// Workgroup ids [wg_end of the previous level, wg_end) belong to a level; the host orders the levels longest workgroup
+// first (most channels), so that the short workgroups of the last level fill the tail of the launch.
 template <int T, typename TX = float>
-__global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const TX* __restrict__ x,
-                                                               const float* __restrict__ E4,
-                                                               const float* __restrict__ enorm, long N,
-                                                               int C, int Cp, int Kp,
-                                                               unsigned long long* __restrict__ keys) {
+__global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const VqGroup g) {
+    int lvl = 0;
+    while (lvl + 1 < g.n && blockIdx.x >= g.lv[lvl].wg_end) ++lvl;                 // uniform (scalar) search
+    const unsigned bid = blockIdx.x - (lvl ? g.lv[lvl - 1].wg_end : 0u);           // level offsets are multiples of 8 (XCD pairing below)
+    const TX* __restrict__ x = static_cast<const TX*>(g.lv[lvl].x);
+    const float* __restrict__ E4 = g.lv[lvl].E4;
+    const float* __restrict__ enorm = g.lv[lvl].enorm;
+    unsigned long long* __restrict__ keys = g.lv[lvl].keys;
+    const long N = g.lv[lvl].N;
+    const int C = g.lv[lvl].C, Cp = g.lv[lvl].C, Kp = g.lv[lvl].Kp;
     constexpr int CODES = 32 * T;                // codes per workgroup
     constexpr int STAGE_FLOATS = stage_floats(T);
     constexpr int BK = STAGE_FLOATS / (32 * T);  // channels per stage
@@ -139,8 +147,8 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const TX* __restr
     // dispatcher deals consecutive ids round-robin over the 8 XCDs, so they land on the SAME XCD at about the same time and
     // the second reader of the rows hits that XCD's L2 instead of HBM (HBM fetch 435 -> ~300 MB per launch at K = 512).
     const int chunks = Kp / CODES;
-    const unsigned within = blockIdx.x % (8u * chunks);
-    const long row_tile = (long)(blockIdx.x / (8u * chunks)) * 8 + (within & 7u);
+    const unsigned within = bid % (8u * chunks);
+    const long row_tile = (long)(bid / (8u * chunks)) * 8 + (within & 7u);
     if (row_tile * ROWS_PER_WG >= N) return;                     // padding of the last group of 8 (whole workgroup exits)
     const int code0 = (int)(within >> 3) * CODES;
     const long row0 = row_tile * ROWS_PER_WG + wave * ROWS_PER_WAVE;
@@ -796,13 +804,16 @@ int profile_collect(int max_records, int64_t* n, int* c, int* k, float* ms) {
     const int cnt = (int)g_prof.shape.size();
     int out = 0;
     for (int i = 0; i < cnt && out < max_records; ++i) {
-        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) break;
+        const ProfShape& sh = g_prof.shape[i];
+        if (hipEventSynchronize(g_prof.ev[2 * sh.slot + 1]) != hipSuccess) break;
         float t = 0.f;
-        if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) break;
-        n[out] = g_prof.shape[i].n;
-        c[out] = g_prof.shape[i].c;
-        k[out] = g_prof.shape[i].k;
-        ms[out] = t;
+        if (hipEventElapsedTime(&t, g_prof.ev[2 * sh.slot], g_prof.ev[2 * sh.slot + 1]) != hipSuccess) break;
+        double mine = 2.0 * (double)sh.n * sh.c * sh.k, all = 0.0;   // a grouped launch: this level's share of the flops
+        for (int j = sh.slot; j < sh.slot + sh.group && j < cnt; ++j) all += 2.0 * (double)g_prof.shape[j].n * g_prof.shape[j].c * g_prof.shape[j].k;
+        n[out] = sh.n;
+        c[out] = sh.c;
+        k[out] = sh.k;
+        ms[out] = (float)(t * (all > 0 ? mine / all : 1.0));
         ++out;
     }
     profile_release();
@@ -810,33 +821,67 @@ int profile_collect(int max_records, int64_t* n, int* c, int* k, float* ms) {
 }
 
 template <int T, typename TX>
-static void launch_assign_t(const TX* x, const float* E4, const float* en, int64_t N, int C, int Kp,
-                            unsigned long long* keys, hipStream_t st) {
+static void launch_assign_t(const VqGroup& g, hipStream_t st) {
     constexpr int STAGE_FLOATS = stage_floats(T);
     static_assert((size_t)WAVES * 32 * 33 * sizeof(unsigned long long) <= (2 * STAGE_FLOATS + 256) * sizeof(float), "key scratch aliases the B stages");
     const size_t lds = (size_t)(2 * STAGE_FLOATS + 256 + WAVES * 32) * sizeof(float);
-    const long row_tiles = (N + ROWS_PER_WG - 1) / ROWS_PER_WG;
-    const dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * (Kp / (32 * T))));      // see the id mapping in the kernel
-    hipLaunchKernelGGL((vq_assign_f32_kernel<T, TX>), grid, dim3(256), lds, st, x, E4, en, (long)N, C, C, Kp, keys);
+    hipLaunchKernelGGL((vq_assign_f32_kernel<T, TX>), dim3(g.lv[g.n - 1].wg_end), dim3(256), lds, st, g);
 }
 
-hipError_t launch_assign(const void* x, int x_bf16, int64_t N, int C, int K, const void* prepared, const VqPlan& p, char* ws,
-                         int64_t* idx, float* dmin, hipStream_t st) {
-    const float* E4 = reinterpret_cast<const float*>(prepared);
-    const float* en = E4 + (size_t)C * p.Kp;
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws + p.off_keys);
-    hipError_t e = hipMemsetAsync(keys, 0xff, (size_t)N * sizeof(unsigned long long), st);
-    if (e != hipSuccess) return e;
-    const bool rec = g_prof.enabled && (int)g_prof.shape.size() < g_prof.capacity;
+static unsigned assign_workgroups(int64_t N, int Kp, int T) {
+    const long row_tiles = (N + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    return (unsigned)((row_tiles + 7) / 8 * 8 * (Kp / (32 * T)));               // see the id mapping in the kernel
+}
+
+// tiles per wave for a group of levels: the largest T in {8,4,2,1} that divides every level's tile count and still yields
+// >= 2 workgroups per CU over the whole launch; if none does, the smallest.
+int vq_group_tiles(int n, const int64_t* N, const int* K) {
+    for (int t = g_vq_max_tiles; t >= 1; t >>= 1) {
+        bool ok = true;
+        long wgs = 0;
+        for (int i = 0; i < n; ++i) {
+            const int tiles = round_up(K[i], 32) / 32;
+            if (tiles % t) ok = false;
+            else wgs += ((N[i] + ROWS_PER_WG - 1) / ROWS_PER_WG) * (tiles / t);
+        }
+        if (ok && (wgs >= 512 || t == 1)) return t;
+    }
+    return 1;
+}
+
+// the distance + argmin pass of n <= VQ_MAX_LEVELS levels in ONE launch (keys pre-set, unpack per level afterwards)
+hipError_t launch_assign_group(int n, const void* const* x, int x_bf16, const int64_t* N, const int* C, const int* K,
+                               const void* const* prepared, const VqPlan* plans, char* const* ws, int64_t* const* idx,
+                               float* const* dmin, int T, hipStream_t st) {
+    if (n < 1 || n > VQ_MAX_LEVELS) return hipErrorInvalidValue;
+    int order[VQ_MAX_LEVELS];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 0; i < n; ++i)                                  // longest workgroups (most channels) first
+        for (int j = i + 1; j < n; ++j)
+            if (C[order[j]] > C[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    VqGroup g;
+    g.n = n;
+    unsigned end = 0;
+    for (int q = 0; q < n; ++q) {
+        const int i = order[q];
+        const float* E4 = reinterpret_cast<const float*>(prepared[i]);
+        unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws[i] + plans[i].off_keys);
+        hipError_t e = hipMemsetAsync(keys, 0xff, (size_t)N[i] * sizeof(unsigned long long), st);
+        if (e != hipSuccess) return e;
+        end += assign_workgroups(N[i], plans[i].Kp, T);
+        g.lv[q] = VqLevel{x[i], E4, E4 + (size_t)C[i] * plans[i].Kp, keys, (long)N[i], C[i], plans[i].Kp, end};
+    }
+    const bool rec = g_prof.enabled && (int)g_prof.shape.size() + n <= g_prof.capacity;
     const size_t slot = g_prof.shape.size();
     if (rec) {
-        g_prof.shape.push_back({N, C, K});
+        // one event pair for the launch; its time is apportioned to the levels by their flops (2 N K C) when collected
+        for (int i = 0; i < n; ++i) g_prof.shape.push_back({N[i], C[i], K[i], (int)slot, n});
         (void)hipEventRecord(g_prof.ev[2 * slot], st);
     }
-#define VQ_ASSIGN(T_)                                                                             \
-    if (x_bf16) launch_assign_t<T_, __bf16>(static_cast<const __bf16*>(x), E4, en, N, C, p.Kp, keys, st); \
-    else launch_assign_t<T_, float>(static_cast<const float*>(x), E4, en, N, C, p.Kp, keys, st)
-    switch (p.T) {
+#define VQ_ASSIGN(T_)                                                 \
+    if (x_bf16) launch_assign_t<T_, __bf16>(g, st);                   \
+    else launch_assign_t<T_, float>(g, st)
+    switch (T) {
         case 8: VQ_ASSIGN(8); break;
         case 4: VQ_ASSIGN(4); break;
         case 2: VQ_ASSIGN(2); break;
@@ -844,15 +889,25 @@ hipError_t launch_assign(const void* x, int x_bf16, int64_t N, int C, int K, con
     }
 #undef VQ_ASSIGN
     if (rec) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
-    int* hist = reinterpret_cast<int*>(ws + p.off_hist);
-    e = hipMemsetAsync(hist, 0, (size_t)p.Kp * sizeof(int), st);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    long blocks = (N + 1023) / 1024;                            // >= 1024 rows per workgroup: the LDS histogram pays
-    if (blocks > 512) blocks = 512;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(vq_unpack_keys, dim3((unsigned)blocks), dim3(256), (size_t)K * sizeof(int), st, keys, (long)N,
-                       reinterpret_cast<long long*>(idx), dmin, hist, K);
+    for (int i = 0; i < n; ++i) {
+        int* hist = reinterpret_cast<int*>(ws[i] + plans[i].off_hist);
+        e = hipMemsetAsync(hist, 0, (size_t)plans[i].Kp * sizeof(int), st);
+        if (e != hipSuccess) return e;
+        long blocks = (N[i] + 1023) / 1024;                      // >= 1024 rows per workgroup: the LDS histogram pays
+        if (blocks > 512) blocks = 512;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(vq_unpack_keys, dim3((unsigned)blocks), dim3(256), (size_t)K[i] * sizeof(int), st,
+                           reinterpret_cast<unsigned long long*>(ws[i] + plans[i].off_keys), (long)N[i],
+                           reinterpret_cast<long long*>(idx[i]), dmin ? dmin[i] : nullptr, hist, K[i]);
+    }
     return hipGetLastError();
+}
+
+hipError_t launch_assign(const void* x, int x_bf16, int64_t N, int C, int K, const void* prepared, const VqPlan& p, char* ws,
+                         int64_t* idx, float* dmin, hipStream_t st) {
+    return launch_assign_group(1, &x, x_bf16, &N, &C, &K, &prepared, &p, &ws, &idx, &dmin, p.T, st);
 }
 
 hipError_t launch_gather(const void* x, int bf16, const float* W, const int64_t* idx, int64_t N, int C, int K, int training,

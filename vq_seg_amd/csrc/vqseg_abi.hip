@@ -143,6 +143,44 @@ int vqseg_vq_forward_bf16(const void* x, const float* codebook, const void* prep
     return vq_forward_any(x, 1, codebook, prepared, n, c, k, training, cw, quant, idx, loss, dead_pct, dmin, ws, ws_bytes, stream);
 }
 
+int vqseg_vq_forward_group(int n_levels, int bf16, const void* const* x, const float* const* codebook, const void* const* prepared,
+                           const int64_t* n, const int* c, const int* k, int training, const float* cw, void* const* quant,
+                           int64_t* const* idx, float* const* loss, float* const* dead_pct, void* const* ws, const size_t* ws_bytes,
+                           void* stream) {
+    if (n_levels < 1 || n_levels > vqseg::VQ_MAX_LEVELS) return fail(VQSEG_EINVAL, "1 .. %d levels per grouped launch", vqseg::VQ_MAX_LEVELS);
+    if (!x || !codebook || !n || !c || !k || !cw || !quant || !idx || !loss || !dead_pct || !ws || !ws_bytes)
+        return fail(VQSEG_EINVAL, "null pointer argument");
+    vqseg::VqPlan plans[vqseg::VQ_MAX_LEVELS];
+    const void* prep[vqseg::VQ_MAX_LEVELS];
+    char* wsp[vqseg::VQ_MAX_LEVELS];
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int i = 0; i < n_levels; ++i) {
+        if (int rc = check_shape(n[i], c[i], k[i])) return rc;
+        if (bf16 && c[i] % 8) return fail(VQSEG_EINVAL, "bf16 rows need channels %% 8 == 0");
+        if (!x[i] || !codebook[i] || !quant[i] || !idx[i] || !loss[i] || !dead_pct[i] || !ws[i]) return fail(VQSEG_EINVAL, "null pointer argument");
+        if (!aligned16(x[i]) || !aligned16(ws[i]) || !aligned16(codebook[i]) || !aligned16(quant[i]) || (prepared && !aligned16(prepared[i])))
+            return fail(VQSEG_EINVAL, "x, codebook, prepared, quant and workspace must be 16-byte aligned");
+        plans[i] = vqseg::vq_plan(n[i], c[i], k[i]);
+        if (ws_bytes[i] < plans[i].bytes) return fail(VQSEG_ENOSPC, "workspace %zu < %zu bytes", ws_bytes[i], plans[i].bytes);
+        wsp[i] = static_cast<char*>(ws[i]);
+        prep[i] = prepared ? prepared[i] : nullptr;
+        if (!prep[i]) {
+            hipError_t e = vqseg::launch_prepare(codebook[i], k[i], c[i], wsp[i] + plans[i].off_prepared, st);
+            if (e != hipSuccess) return hip_fail(e, "vq codebook prepare");
+            prep[i] = wsp[i] + plans[i].off_prepared;
+        }
+    }
+    const int T = vqseg::vq_group_tiles(n_levels, n, k);
+    hipError_t e = vqseg::launch_assign_group(n_levels, x, bf16, n, c, k, prep, plans, wsp, idx, nullptr, T, st);
+    if (e != hipSuccess) return hip_fail(e, "vq_assign_f32_kernel (grouped)");
+    for (int i = 0; i < n_levels; ++i) {
+        e = vqseg::launch_gather(x[i], bf16, codebook[i], idx[i], n[i], c[i], k[i], training, cw[i], plans[i], wsp[i], quant[i], loss[i],
+                                 dead_pct[i], st);
+        if (e != hipSuccess) return hip_fail(e, "vq_gather_kernel");
+    }
+    return 0;
+}
+
 int vqseg_vq_backward_bf16(const void* gq, const float* gloss, const void* x, const int64_t* idx, const float* codebook,
                            int64_t n, int c, float cw, void* gx, void* stream) {
     if (int rc = check_shape(n, c, 1)) return rc;

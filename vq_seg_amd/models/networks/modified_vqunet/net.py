@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from .... import nnf
-from ....vector_quantizer import make_vq_module, Identity as _IdentityVQ
+from ....vector_quantizer import make_vq_module, Identity as _IdentityVQ, quantize_group as _quantize_group
 from ...encoders import make_encoder
 from ...modules.prototype import ReliablePrototypeLoss, ReliablePrototypeLossv2
 from ..unet.decoder import UnetDecoder
@@ -72,10 +72,15 @@ class _VQRePTUnet1x1Base(nn.Module):
     def quantize(self, feats):
         loss = torch.zeros(1, device=feats[0].device)
         usage = []
-        for i, vq in enumerate(self.codebook):
-            if isinstance(feats[i], nnf.S3) and not isinstance(vq, _IdentityVQ):  # VQ layers take fp32 rows; Identity passes through
+        levels = [i for i, vq in enumerate(self.codebook) if not isinstance(vq, _IdentityVQ)]
+        for i in levels:                                     # VQ layers take fp32 rows (Identity levels pass split-3 tensors through)
+            if isinstance(feats[i], nnf.S3):
                 feats[i] = feats[i].float()
-            quantize, _idx, commitment, dead = vq(feats[i])
+        # the quantised levels are independent: their distance passes share ONE launch when they can (vq_img.quantize_group)
+        grouped = _quantize_group([self.codebook[i] for i in levels], [feats[i] for i in levels]) if nnf.py_opt("py_vq_group", 1) else None
+        grouped = dict(zip(levels, grouped)) if grouped is not None else {}
+        for i, vq in enumerate(self.codebook):
+            quantize, _idx, commitment, dead = grouped[i] if i in grouped else vq(feats[i])
             feats[i] = quantize
             if commitment is not None:
                 loss = loss + commitment

@@ -3,7 +3,7 @@ import copy
 
 from torch import nn
 
-from .vq_img import VectorQuantizer, EuclideanCodebook, kmeans  # noqa: F401
+from .vq_img import VectorQuantizer, EuclideanCodebook, kmeans, quantize_group  # noqa: F401
 
 
 def _get(cfg, key):

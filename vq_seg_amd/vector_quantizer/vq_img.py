@@ -57,6 +57,76 @@ class _VQFunction(torch.autograd.Function):
         return gx, None, None, None, None                   # the codebook receives no gradient (vq_img.py:236-239)
 
 
+class _VQGroupFunction(torch.autograd.Function):
+    """The forward of several independent VectorQuantizer layers with ONE distance + argmin launch (vqseg_vq_forward_group);
+    per level exactly _VQFunction's outputs and gradient."""
+
+    @staticmethod
+    def forward(ctx, training, weights, n, *tensors):
+        rows, codebooks, prepared = tensors[:n], tensors[n:2 * n], tensors[2 * n:3 * n]
+        outs = _hip.vq_forward_group(list(rows), list(codebooks), list(prepared), training, weights)
+        ctx.n, ctx.training, ctx.weights = n, bool(training), [float(w) for w in weights]
+        ctx.bf16 = rows[0].dtype == torch.bfloat16
+        if training:
+            saved = []
+            for r, cb, (q, idx, _l, _d) in zip(rows, codebooks, outs):
+                saved += [r, idx, cb] if ctx.bf16 else [r, q]
+            ctx.save_for_backward(*saved)
+        flat = []
+        for q, idx, loss, dead in outs:
+            ctx.mark_non_differentiable(idx, dead)
+            flat += [q, idx, loss, dead]
+        return tuple(flat)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = ctx.n
+        none = (None, None, None) + (None,) * (3 * n)
+        if not ctx.training:
+            return none
+        saved = ctx.saved_tensors
+        gxs = []
+        for i in range(n):
+            g_quant, g_loss = grads[4 * i], grads[4 * i + 2]
+            w = ctx.weights[i]
+            gl = g_loss.contiguous() if (g_loss is not None and w > 0) else None
+            if ctx.bf16:
+                rows, idx, codebook = saved[3 * i:3 * i + 3]
+                g_quant = torch.zeros_like(rows) if g_quant is None else g_quant.to(torch.bfloat16).contiguous()
+                gxs.append(_hip.vq_backward_bf16(g_quant, gl, rows, idx, codebook, w))
+            else:
+                rows, quant = saved[2 * i:2 * i + 2]
+                g_quant = torch.zeros_like(rows) if g_quant is None else g_quant.contiguous()
+                gxs.append(_hip.vq_backward(g_quant, gl, rows, quant, w))
+        return (None, None, None) + tuple(gxs) + (None,) * (2 * n)
+
+
+def quantize_group(vqs, feats):
+    """[vq(f) for vq, f in zip(vqs, feats)] for VectorQuantizer layers whose codebooks are ready, with their distance passes in
+    one launch; None if the layers cannot be grouped (first training forward with k-means pending, the EMA extension, mixed row
+    types, CPU tensors) -- the caller then runs them one by one."""
+    if len(vqs) < 2 or len(vqs) > 4:
+        return None
+    rows = []
+    for vq, f in zip(vqs, feats):
+        cb = vq.codebook
+        if not torch.is_tensor(f) or not f.is_cuda or cb.ema_update or (cb.kmeans_init and vq.training and not cb.initted):
+            return None
+        rows.append(_rows_of(f))
+    if len({r.dtype for r in rows}) != 1 or len({vq.training for vq in vqs}) != 1:
+        return None
+    n = len(vqs)
+    weights = [float(vq.commitment_weight) for vq in vqs]
+    flat = _VQGroupFunction.apply(vqs[0].training, weights, n, *rows, *[vq.codebook.embedding.weight.detach() for vq in vqs],
+                                  *[vq.codebook.prepared() for vq in vqs])
+    outs = []
+    for i, f in enumerate(feats):
+        b, c, h, w = f.shape
+        quant, idx, loss, dead = flat[4 * i:4 * i + 4]
+        outs.append((quant.reshape(b, h, w, c).permute(0, 3, 1, 2), idx.reshape(b, h, w), loss, dead))
+    return outs
+
+
 def _rows_of(x: torch.Tensor):
     """(B, C, H, W) -> contiguous (B*H*W, C) rows (free for channels_last input).  Under torch.autocast bf16 activations
     stay bf16 (the kernels up-cast on load: x.float() of vq_img.py:229 without the pass over memory, and the quantised
