@@ -34,6 +34,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 SIZE, K_CODES = 512, 512
 
 
@@ -240,6 +241,24 @@ def main():
         all_bf16_s = float(tt.item())
         trainer.cfg.eval_amp = False
 
+    # roofline_conv: two more steps of the SAME configuration with every convolution launch bracketed by HIP events, on ONE
+    # stream (with two streams a launch's in-stream time would include the other network's kernels sharing the chip).  Outside
+    # the timed region: ~700 event pairs per step would perturb the headline.
+    conv_recs = []
+    if rank == 0:
+        was_two = trainer._two_streams
+        trainer._two_streams = False
+        one(0)
+        torch.cuda.synchronize()
+        _hip.conv_profile_begin(1 << 16)
+        for i in range(2):
+            one(i)
+        torch.cuda.synchronize()
+        conv_recs = _hip.conv_profile_collect(1 << 16)
+        trainer._two_streams = was_two
+    if world > 1:
+        dist.barrier()
+
     if rank == 0:
         flops = sum(2.0 * n * c * k for n, c, k, _ in recs)
         ms = sum(r[3] for r in recs)
@@ -284,11 +303,32 @@ def main():
                                            "tflops": round(v[2] / (v[1] / v[0] * 1e-3) / 1e12, 2)}
                                        for s, v in per_shape.items()},
                          "note": "algorithmic flops 2*N*K*C per launch / HIP-event time on the launch stream, "
-                                 "all launches inside the timed region; peak = fp32 MFMA (MI355X_MICROARCH.md)"},
+                                 "all launches inside the timed region; peak = fp32 MFMA (MI355X_MICROARCH.md); the three levels of "
+                                 "a forward share ONE launch (longest workgroups first): its time is apportioned to the levels by flops"},
         }
         line["supervised_step"] = {"images_per_sec": round(args.batch * world / sup_s, 2), "ms_per_step": round(sup_s * 1e3, 2),
                                    "what": "forward + backward + Adam of ONE network on the labelled half of the batch "
                                            "(0.5 CE + Dice + commitment + prototype loss), 3 steps after the timed region"}
+        if conv_recs:
+            def rate(sel):
+                fl = sum(f for f, kd, m in conv_recs if sel(kd))
+                ms_ = sum(m for f, kd, m in conv_recs if sel(kd))
+                n_ = sum(1 for f, kd, m in conv_recs if sel(kd))
+                return {"launches_per_step": n_ // 2, "tflop_per_step": round(fl / 2 / 1e12, 3), "ms_per_step": round(ms_ / 2, 3),
+                        "tflops": round(fl / ms_ / 1e9, 1) if ms_ > 0 else 0.0}
+            k3 = rate(lambda kd: kd == 300)
+            line["roofline_conv"] = {
+                "kernel": "conv3x3_patch_kernel / conv_igemm_glds_kernel (every 3x3 bf16 launch: forward + data gradient)",
+                "bound": "mfma", "achieved": k3["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(k3["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "traffic_source": "profiles/r01_conv_patch_pmc.md (PMC passes of the patch kernel)",
+                "by_kind": {"3x3 bf16": k3, "1x1 bf16": rate(lambda kd: kd == 100), "3x3 split-3 (fp32-precision eval)": rate(lambda kd: kd == 302),
+                            "1x1 split-3": rate(lambda kd: kd == 102), "precise (fp32 activations)": rate(lambda kd: kd % 100 == 1)},
+                "whole_step_delivered_tflops": round(sum(f for f, _k, _m in conv_recs) / 2 / (elapsed / args.steps) / 1e12, 1),
+                "note": "algorithmic flops 2*KH*KW*Cin*Cout*pixels per launch / in-stream HIP-event time, two extra steps after the timed "
+                        "region with both networks on ONE stream (kernels alone on the chip); split-3 launches are counted at the LOGICAL "
+                        "convolution's flops (they execute 3x that on the MFMA pipes); weight-gradient kernels are not in this object; "
+                        "whole_step_delivered = all convolution forward/data-gradient flops of a step / the headline's step time"}
         if all_bf16_s is not None:
             line["all_bf16_step"] = {"images_per_sec": round(images / all_bf16_s, 3), "ms_per_step": round(all_bf16_s / args.steps * 1e3, 3),
                                      "what": "the same step with the two pseudo-label forwards under bf16 autocast too (CPSConfig.eval_amp=True); "

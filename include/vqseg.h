@@ -65,6 +65,13 @@ int vqseg_profile_begin(int capacity);
 int vqseg_profile_collect(int max_records, int64_t* n_rows_host, int* channels_host,
                           int* n_codes_host, float* ms_host);
 
+/* The same for the convolution kernels (forward, data gradient, fused-epilogue and split-3 launches of vqseg_conv2d_*): per launch
+ * the ALGORITHMIC flops 2 * KH * KW * Cin * Cout * output pixels (logical channels for split-3; forward-layer pixels for the
+ * data gradient of a strided layer), kind = KH * 100 + {0 bf16, 1 precise, 2 split-3}, the in-stream milliseconds and the shape. */
+int vqseg_conv_profile_begin(int capacity);
+int vqseg_conv_profile_collect(int max_records, double* flops_host, int* kind_host, float* ms_host,
+                               int* shape_host /* optional [4] per record: output pixels / 1024, Cin, Cout, stride * 10 + up */);
+
 /* ---------------------------------------------------------------------------------- *
  * Vector quantiser forward.
  * Replaces EuclideanCodebook.forward (vector_quantizer/vq_img.py:160-177: cdist ->

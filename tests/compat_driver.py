@@ -50,6 +50,34 @@ if what in ("iter_v1", "iter_v2"):
                 arrays[f"it{i}/{k}"] = v.numpy()
 elif what == "curve":
     arrays = cps_loop.run_curve(ns, dev, to_cfg=EasyDict, prepare=prepare)
+elif what == "train_main":
+    # train() of train_vqreptunet1x1v2.py:48-218 as far as the hot path goes: datasets + loaders (:86-93), models + init_weight
+    # (:70-80, random init, k-means codebook / prototype init in the first training forward), optimisers + schedule + AMP region
+    # (:102-114; fp16 -> bf16), the iteration (:129-211) -- all through the flat names, on a synthetic CWFID-shaped folder
+    import itertools, tempfile
+    import torch.nn as nn
+    from torch.utils.data import DataLoader
+    from data.dataset import BaseDataset, write_synthetic_dataset
+    from utils.seg_tools import img_to_label
+    from utils.seed import seed_everything
+    seed_everything()
+    root = tempfile.mkdtemp()
+    write_synthetic_dataset(os.path.join(root, "train"), n_labelled=6, n_unlabelled=10, size=64, seed=1)
+    sup_loader = DataLoader(BaseDataset(os.path.join(root, "train"), split="labelled", batch_size=4, resize=64), batch_size=4, shuffle=True)
+    unsup_loader = DataLoader(BaseDataset(os.path.join(root, "train"), split="unlabelled", batch_size=4, resize=64), batch_size=4, shuffle=True)
+    cfg = EasyDict(cps_loop.model_cfg(2, (0, 0, 32, 32, 32)))
+    model_1, model_2 = models.networks.make_model(cfg).to(dev), models.networks.make_model(cfg).to(dev)
+    for m in (model_1, model_2):
+        models.init_weight([m.decoder, m.segmentation_head], nn.init.kaiming_normal_, nn.BatchNorm2d, 1e-5, 0.1, mode="fan_in", nonlinearity="relu")
+    loop = cps_loop.Loop(ns, 2, model_1, model_2, total_iters=len(unsup_loader) * 2, half=True, amp_dtype=torch.bfloat16)
+    losses, mious = [], []
+    for epoch in range(2):
+        for sup_dict, unsup_dict in zip(itertools.cycle(sup_loader), unsup_loader):
+            l_target = img_to_label(sup_dict["target"], {"0": 0, "128": 1, "255": 2})
+            out = loop.iteration(sup_dict["img"].to(dev), l_target.to(dev), unsup_dict["img"].to(dev))
+            losses.append(out["loss"]), mious.append(out["step_miou"])
+    arrays = dict(losses=np.array(losses), mious=np.array(mious), initted=np.array([bool(model_1.codebook[i].codebook.initted) for i in (2, 3, 4)]),
+                  iters=np.array(len(losses)))
 else:
     raise SystemExit(f"unknown job {what}")
 arrays["module_of_model"] = np.array(type(models.networks.make_model(EasyDict(cps_loop.model_cfg(1, (0, 0, 8, 8, 8))))).__module__)

@@ -10,7 +10,7 @@ import textwrap
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # train_vqreptunet1x1v2.py:13-26 minus the out-of-scope lines (utils.logger: wandb; utils.visualize: cv2 / matplotlib;
-# utils.processing; data.dataset: image folders), then :70-80 as the trainer does them
+# utils.processing), then :70-80 as the trainer does them
 SCRIPT = textwrap.dedent('''
     import json, sys
     sys.path.insert(0, sys.argv[1])                 # the ONE line a maintainer adds: <repo>/compat
@@ -24,6 +24,8 @@ SCRIPT = textwrap.dedent('''
     from utils.seg_tools import img_to_label
     from utils.lr_schedulers import WarmUpPolyLR, CosineAnnealingLR
     from utils.seed import seed_everything
+
+    from data.dataset import BaseDataset
 
     from loss import make_loss
     from measurement import Measurement
@@ -53,7 +55,7 @@ SCRIPT = textwrap.dedent('''
         "n_params": sum(p.numel() for p in model_1.parameters()),
         "bn_mom": model_1.decoder.blocks[0][0][1].momentum, "lr0": sched.get_lr(0),
         "label": img_to_label(torch.tensor([0, 128, 255]), cfg.pixel_to_label).tolist(),
-        "dice": type(dice_loss).__name__, "vq": type(model_1.codebook[2]).__module__,
+        "dice": type(dice_loss).__name__, "vq": type(model_1.codebook[2]).__module__, "dataset": BaseDataset.__module__,
         "paths": [p for p in sys.path if "repo" in p]}))
 ''')
 
@@ -76,9 +78,10 @@ def test_reference_trainer_import_block_binds(tmp_path):
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads(res.stdout.strip().splitlines()[-1])
     assert out["models"] == "vq_seg_amd.models" and out["same"] is True
-    assert out["cls"] == "VQRePTUnet1x1v2" and out["keys"] == 383 and out["n_params"] == 69212224 + 0 or out["n_params"] > 69e6
+    assert out["cls"] == "VQRePTUnet1x1v2" and out["keys"] == 383 and 69.2e6 < out["n_params"] < 69.3e6
     assert out["bn_mom"] == 0.1 and abs(out["lr0"] - 1e-4) < 1e-18
     assert out["label"] == [0, 1, 2] and out["dice"] == "DiceLoss" and out["vq"].startswith("vq_seg_amd.vector_quantizer")
+    assert out["dataset"] == "vq_seg_amd.data.dataset"
 
 
 def test_checkpoint_reference_layout_round_trip(tmp_path):

@@ -116,3 +116,12 @@ def test_miou_parity_run(tmp_path):
     assert np.abs(a - b).max() <= 0.03, (a, b)                       # and never far apart on the way (steep phase: 0.05 per step)
     assert b[-1] > b[0] + 0.1                                        # the run learns (so the comparison means something)
     assert np.allclose(got["sup_loss_1"][:3], fx["sup_loss_1"].numpy()[:3], rtol=1e-3)
+
+
+def test_trainer_main_flow_on_a_synthetic_folder(tmp_path):
+    """train() of train_vqreptunet1x1v2.py as far as the hot path goes -- BaseDataset folders and loaders, make_model + init_weight
+    from random init (k-means codebook / prototype initialisation in the first training forward), Adam + cosine schedule, the bf16
+    autocast region -- through the flat names for two epochs: every loss finite, codebooks initialised, six iterations."""
+    got = drive(tmp_path, "train_main")
+    assert int(got["iters"]) == 6 and np.isfinite(got["losses"]).all() and got["initted"].all()
+    assert ((got["mious"] >= 0) & (got["mious"] <= 1)).all()

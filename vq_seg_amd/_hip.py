@@ -24,6 +24,8 @@ SYMBOLS = {
     "vqseg_set_option": (c_int, [c_char_p, c_int]),
     "vqseg_profile_begin": (c_int, [c_int]),
     "vqseg_profile_collect": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vqseg_conv_profile_begin": (c_int, [c_int]),
+    "vqseg_conv_profile_collect": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqseg_vq_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "vqseg_vq_forward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -359,6 +361,25 @@ def vq_ema_update(cluster_size: torch.Tensor, embed_avg: torch.Tensor, codebook:
 
 def profile_begin(capacity: int = 4096) -> None:
     _check(lib().vqseg_profile_begin(int(capacity)), "vqseg_profile_begin")
+
+
+def conv_profile_begin(capacity: int = 65536) -> None:
+    _check(lib().vqseg_conv_profile_begin(int(capacity)), "vqseg_conv_profile_begin")
+
+
+def conv_profile_collect(capacity: int = 65536, with_shape: bool = False):
+    """-> list of (algorithmic flops, kind = KH * 100 + {0 bf16, 1 precise, 2 split-3}, milliseconds) per convolution launch"""
+    import numpy as np
+    fl = np.zeros(capacity, dtype=np.float64)
+    kd = np.zeros(capacity, dtype=np.int32)
+    ms = np.zeros(capacity, dtype=np.float32)
+    sh = np.zeros((capacity, 4), dtype=np.int32)
+    cnt = lib().vqseg_conv_profile_collect(capacity, fl.ctypes.data, kd.ctypes.data, ms.ctypes.data, sh.ctypes.data if with_shape else None)
+    if cnt < 0:
+        _check(cnt, "vqseg_conv_profile_collect")
+    if with_shape:
+        return [(float(fl[i]), int(kd[i]), float(ms[i]), tuple(int(v) for v in sh[i])) for i in range(cnt)]
+    return [(float(fl[i]), int(kd[i]), float(ms[i])) for i in range(cnt)]
 
 
 def profile_collect(capacity: int = 4096):

@@ -37,6 +37,9 @@ struct WgradArgs {
 };
 
 hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st);
+hipError_t conv_profile_begin(int capacity);
+void conv_profile_release();
+int conv_profile_collect(int max_records, double* flops, int* kind, float* ms, int* shape);
 int conv_set_option(const char* key, int value);   // previous value, or -1 (unknown key)
 int wgrad_slabs(const WgradArgs& a, int precise);   // slabs launch_wgrad will write
 int wgrad_slabs_max(const WgradArgs& a);           // upper bound from the shape alone (workspace sizing)

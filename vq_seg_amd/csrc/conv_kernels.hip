@@ -1147,7 +1147,88 @@ static void launch_t(const ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((conv_igemm_kernel<BN, PRECISE, BK>), grid, dim3(256), lds, st, a);
 }
 
+// ---- optional per-launch timing of the convolution kernels (bench.py's roofline_conv leg): event pairs on the launch stream
+struct ConvProfile {
+    bool enabled = false;
+    int capacity = 0, count = 0;
+    hipEvent_t* ev = nullptr;
+    double* flops = nullptr;
+    int* kind = nullptr;                                    // KH * 100 + precision tag (0 bf16, 1 precise, 2 split-3)
+    int* shape = nullptr;                                   // [4]: output pixels / 1024, Cin (logical), Cout, stride * 10 + up
+};
+static ConvProfile g_cprof;
+
+hipError_t conv_profile_begin(int capacity) {
+    conv_profile_release();
+    g_cprof.ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * (size_t)capacity);
+    g_cprof.flops = (double*)malloc(sizeof(double) * (size_t)capacity);
+    g_cprof.kind = (int*)malloc(sizeof(int) * (size_t)capacity);
+    g_cprof.shape = (int*)malloc(sizeof(int) * 4 * (size_t)capacity);
+    if (!g_cprof.ev || !g_cprof.flops || !g_cprof.kind || !g_cprof.shape) return hipErrorOutOfMemory;
+    for (int i = 0; i < 2 * capacity; ++i) {
+        hipError_t rc = hipEventCreate(&g_cprof.ev[i]);
+        if (rc != hipSuccess) return rc;
+    }
+    g_cprof.capacity = capacity;
+    g_cprof.count = 0;
+    g_cprof.enabled = true;
+    return hipSuccess;
+}
+
+void conv_profile_release() {
+    if (g_cprof.ev)
+        for (int i = 0; i < 2 * g_cprof.capacity; ++i) (void)hipEventDestroy(g_cprof.ev[i]);
+    free(g_cprof.ev);
+    free(g_cprof.flops);
+    free(g_cprof.kind);
+    free(g_cprof.shape);
+    g_cprof = ConvProfile{};
+}
+
+int conv_profile_collect(int max_records, double* flops, int* kind, float* ms, int* shape) {
+    g_cprof.enabled = false;
+    int out = 0;
+    for (int i = 0; i < g_cprof.count && out < max_records; ++i) {
+        if (hipEventSynchronize(g_cprof.ev[2 * i + 1]) != hipSuccess) break;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_cprof.ev[2 * i], g_cprof.ev[2 * i + 1]) != hipSuccess) break;
+        flops[out] = g_cprof.flops[i];
+        kind[out] = g_cprof.kind[i];
+        if (shape)
+            for (int e = 0; e < 4; ++e) shape[4 * out + e] = g_cprof.shape[4 * i + e];
+        ms[out] = t;
+        ++out;
+    }
+    conv_profile_release();
+    return out;
+}
+
+static hipError_t launch_conv_impl(const ConvArgs& a, int precise, hipStream_t st);
+
 hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
+    const bool rec = g_cprof.enabled && g_cprof.count < g_cprof.capacity;
+    const int slot = g_cprof.count;
+    if (rec) {
+        // algorithmic flops: 2 * taps * Cin * Cout per output pixel (a split-3 launch contracts over 3 x the logical channels:
+        // its algorithmic work is the logical convolution's; `up` launches are data gradients of strided layers: the
+        // up-sampled grid's zero rows are not work, so count the forward layer's pixels = input pixels of this launch)
+        const double cin = a.out_s3 ? a.Cin / 3.0 : (double)a.Cin;
+        const double px = a.up == 2 ? (double)a.N * a.H * a.W : (double)a.N * a.Ho * a.Wo;
+        g_cprof.flops[slot] = 2.0 * a.KH * a.KW * cin * a.Cout * px;
+        g_cprof.kind[slot] = a.KH * 100 + (a.out_s3 ? 2 : (precise ? 1 : 0));
+        g_cprof.shape[4 * slot + 0] = (int)(((long)a.N * a.Ho * a.Wo) >> 10);
+        g_cprof.shape[4 * slot + 1] = (int)cin;
+        g_cprof.shape[4 * slot + 2] = a.Cout;
+        g_cprof.shape[4 * slot + 3] = a.stride * 10 + a.up;
+        ++g_cprof.count;
+        (void)hipEventRecord(g_cprof.ev[2 * slot], st);
+    }
+    const hipError_t e = launch_conv_impl(a, precise, st);
+    if (rec) (void)hipEventRecord(g_cprof.ev[2 * slot + 1], st);
+    return e;
+}
+
+static hipError_t launch_conv_impl(const ConvArgs& a, int precise, hipStream_t st) {
     const int bn = a.Cout >= 128 ? 128 : (a.Cout >= 64 ? 64 : 32);
     const bool k64 = !precise && a.Cin % 64 == 0 && (a.C1 == a.Cin || a.C1 % 64 == 0);
     if (precise) {

@@ -106,6 +106,17 @@ int vqseg_conv2d_affine_f(const void* x, const void* x2, int c1, const void* w_h
                        ho, wo, precise, stream);
 }
 
+int vqseg_conv_profile_begin(int capacity) {
+    if (capacity <= 0 || capacity > (1 << 20)) return bad("conv_profile_begin: capacity out of range");
+    hipError_t e = vqseg::conv_profile_begin(capacity);
+    return e == hipSuccess ? 0 : hipfail(e, "conv_profile_begin");
+}
+
+int vqseg_conv_profile_collect(int max_records, double* flops_host, int* kind_host, float* ms_host, int* shape_host) {
+    if (max_records <= 0 || !flops_host || !kind_host || !ms_host) return bad("conv_profile_collect: bad argument");
+    return vqseg::conv_profile_collect(max_records, flops_host, kind_host, ms_host, shape_host);
+}
+
 int vqseg_set_option(const char* key, int value) {
     if (!key || value < 0) return bad("set_option: null key or negative value");
     int prev = vqseg::conv_set_option(key, value);
