@@ -271,7 +271,8 @@ int vqseg_maxpool3x3s2_f(int bf16, int backward, const void* x, const void* g, i
 int vqseg_bilinear_f(int bf16, int backward, const void* src, int n, int h, int w, int c, int ho, int wo,
                      int align_corners, void* dst, void* stream);
 
-/* 1x1 segmentation head, nn.Conv2d(32, num_classes, 1, bias=False) (net.py:1169): logits f32. */
+/* 1x1 segmentation head, nn.Conv2d(32, num_classes, 1, bias=False) (net.py:1169): logits f32.  Cin % 8 == 0, Cin <= 64, Cout <= 4.
+ * Row type `bf16`: 0 f32, 1 bf16, 2 (forward only) split-3 rows [3 * Cin] (see "Split-3" below). */
 int vqseg_head1x1_forward_f(int bf16, const void* x, const float* w, int64_t m_rows, int cin, int cout,
                             float* y, void* stream);
 size_t vqseg_head1x1_backward_workspace_floats(int64_t m_rows, int cin, int cout);

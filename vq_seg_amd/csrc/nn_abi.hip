@@ -216,7 +216,9 @@ int vqseg_bilinear_f(int bf16, int backward, const void* src, int n, int h, int 
 }
 
 int vqseg_head1x1_forward_f(int bf16, const void* x, const float* w, int64_t m_rows, int cin, int cout, float* y, void* stream) {
-    if (!x || !w || !y || cout > 4 || cout <= 0 || cin <= 0) return bad("head1x1: bad argument (Cout <= 4)");
+    if (!x || !w || !y || cout > 4 || cout <= 0 || cin <= 0 || cin % 8 || cin > 64 || !a16(x))
+        return bad("head1x1: bad argument (Cout <= 4, Cin % 8 == 0, Cin <= 64, 16-byte aligned rows)");
+    if (bf16 < 0 || bf16 > 2) return bad("head1x1: row type must be 0 (f32), 1 (bf16) or 2 (split-3)");
     hipError_t e = vqseg::launch_head_fwd(bf16, x, w, m_rows, cin, cout, y, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hipfail(e, "head_fwd_kernel");
 }
@@ -227,7 +229,8 @@ size_t vqseg_head1x1_backward_workspace_floats(int64_t m_rows, int cin, int cout
 
 int vqseg_head1x1_backward_f(int bf16, const void* x, const float* w, const float* g, int64_t m_rows, int cin, int cout, void* gx,
                              float* gw, float* workspace, void* stream) {
-    if (!x || !w || !g || !gx || !gw || !workspace || cout > 4 || cin * cout > 256) return bad("head1x1 backward: bad argument");
+    if (!x || !w || !g || !gx || !gw || !workspace || cout > 4 || cout <= 0 || cin <= 0 || cin * cout > 256 || cin % 8 || cin > 64 || !a16(x) || !a16(gx))
+        return bad("head1x1 backward: bad argument (Cout <= 4, Cin % 8 == 0, Cin <= 64, 16-byte aligned rows)");
     hipError_t e = vqseg::launch_head_bwd(bf16, x, w, g, m_rows, cin, cout, gx, gw, workspace, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hipfail(e, "head_bwd");
 }

@@ -704,60 +704,131 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
 // ---------------------------------------------------------------------------------------------
 // 1x1 segmentation head (Cin <= 64 -> Cout <= 4, no bias): forward, data gradient, weight gradient
 // ---------------------------------------------------------------------------------------------
+// 8 consecutive channels of row `row` (Cin per row) as floats: T = float / __bf16 rows, or split-3 rows (S3Row tag: [hi | lo | hi])
+struct S3Row { unsigned short raw; };
+template <typename T>
+__device__ __forceinline__ void ld8(const T* __restrict__ x, long row, int Cin, int c, float (&v)[8]) {
+    if constexpr (__is_same(T, S3Row)) {
+        const unsigned short* r = reinterpret_cast<const unsigned short*>(x) + row * 3 * Cin;
+        const u32x4 h = *reinterpret_cast<const u32x4*>(r + c), l = *reinterpret_cast<const u32x4*>(r + Cin + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = __builtin_bit_cast(float, h[e] << 16) + __builtin_bit_cast(float, l[e] << 16);
+            v[2 * e + 1] = __builtin_bit_cast(float, h[e] & 0xFFFF0000u) + __builtin_bit_cast(float, l[e] & 0xFFFF0000u);
+        }
+    } else if constexpr (sizeof(T) == 2) {
+        const u32x4 h = *reinterpret_cast<const u32x4*>(x + row * Cin + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = __builtin_bit_cast(float, h[e] << 16);
+            v[2 * e + 1] = __builtin_bit_cast(float, h[e] & 0xFFFF0000u);
+        }
+    } else {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + row * Cin + c), b = *reinterpret_cast<const f32x4*>(x + row * Cin + c + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+}
+
+// forward: one pixel row per thread, 16-byte loads, the weights in LDS; the channel order of the fmaf chain is ascending (as the
+// scalar form it replaces: bit-identical results).  Cin % 8 == 0, Cin <= 64, Cout <= 4.
 template <typename T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, long M, int Cin,
                                                        int Cout, float* __restrict__ y) {
+    __shared__ float ws[4 * 64];
+    for (int i = threadIdx.x; i < Cout * Cin; i += 256) ws[i] = w[i];
+    __syncthreads();
     for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < Cin; ++c) {
-            const float v = ld(x, m * Cin + c);
-            for (int o = 0; o < Cout; ++o) acc[o] = __builtin_fmaf(v, w[o * Cin + c], acc[o]);
+        for (int c = 0; c < Cin; c += 8) {
+            float v[8];
+            ld8<T>(x, m, Cin, c, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (o < Cout) acc[o] = __builtin_fmaf(v[e], ws[o * Cin + c + e], acc[o]);
         }
         for (int o = 0; o < Cout; ++o) y[m * Cout + o] = acc[o];
     }
 }
 
+// data gradient: thread = (row, 8-channel chunk), one 16-byte (bf16) / two 16-byte (f32) stores
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restrict__ g, const float* __restrict__ w, long M,
                                                             int Cin, int Cout, T* __restrict__ gx) {
-    const long total = M * Cin;
+    __shared__ float ws[4 * 64];
+    for (int i = threadIdx.x; i < Cout * Cin; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int cv = Cin / 8;
+    const long total = M * cv;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % Cin);
-        const long m = i / Cin;
-        float acc = 0.0f;
-        for (int o = 0; o < Cout; ++o) acc = __builtin_fmaf(g[m * Cout + o], w[o * Cin + c], acc);
-        st(gx, i, acc);
+        const long m = i / cv;
+        const int c = (int)(i - m * cv) * 8;
+        float gv[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < Cout; ++o) gv[o] = g[m * Cout + o];
+        float out[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = 0.0f;
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (o < Cout) a = __builtin_fmaf(gv[o], ws[o * Cin + c + e], a);
+            out[e] = a;
+        }
+        if constexpr (sizeof(T) == 2) {
+            u32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const __bf16 lo = (__bf16)out[2 * e], hi = (__bf16)out[2 * e + 1];
+                r[e] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+            }
+            *reinterpret_cast<u32x4*>(gx + m * Cin + c) = r;
+        } else {
+            *reinterpret_cast<f32x4*>(gx + m * Cin + c) = f32x4{out[0], out[1], out[2], out[3]};
+            *reinterpret_cast<f32x4*>(gx + m * Cin + c + 4) = f32x4{out[4], out[5], out[6], out[7]};
+        }
     }
 }
 
-constexpr int HEAD_ROWS = 1024;
+constexpr int HEAD_ROWS = 2048;
+// weight gradient: block -> HEAD_ROWS rows; thread -> (row slot, 8-channel chunk): one 16-byte x load feeds 8 x Cout accumulators;
+// the 256 / (Cin / 8) row slots are folded through LDS in slot order (deterministic); partial[blk][Cout * Cin]
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const T* __restrict__ x, const float* __restrict__ g, long M, int Cin,
                                                               int Cout, float* __restrict__ partial) {
-    // block -> HEAD_ROWS rows; thread -> (row slot, input channel c): one x load (coalesced along c) feeds Cout <= 4
-    // accumulators; the 256 / Cin row slots are folded through LDS in slot order; partial[blk][Cout * Cin]
-    __shared__ float sh[4][256];
-    const int slots = 256 / Cin > 0 ? 256 / Cin : 1;
-    const int c = threadIdx.x % Cin, sl = threadIdx.x / Cin;
+    extern __shared__ float sh[];                              // [slots][Cout * Cin]
+    const int cv = Cin / 8, slots = 256 / cv;
+    const int cc = threadIdx.x % cv, sl = threadIdx.x / cv;
     const long row0 = (long)blockIdx.x * HEAD_ROWS;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[4][8];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[o][e] = 0.0f;
     if (sl < slots) {
         long end = row0 + HEAD_ROWS;
         if (end > M) end = M;
         for (long m = row0 + sl; m < end; m += slots) {
-            const float xv = ld(x, m * Cin + c);
+            float v[8];
+            ld8<T>(x, m, Cin, cc * 8, v);
 #pragma unroll
             for (int o = 0; o < 4; ++o)
-                if (o < Cout) acc[o] = __builtin_fmaf(g[m * Cout + o], xv, acc[o]);
-        }
-    }
+                if (o < Cout) {
+                    const float gv = g[m * Cout + o];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) sh[o][threadIdx.x] = acc[o];
+                    for (int e = 0; e < 8; ++e) acc[o][e] = __builtin_fmaf(gv, v[e], acc[o][e]);
+                }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (o < Cout)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sh[(sl * Cout + o) * Cin + cc * 8 + e] = acc[o][e];
+    }
     __syncthreads();
     if ((int)threadIdx.x < Cin * Cout) {
-        const int o = threadIdx.x / Cin, cc = threadIdx.x % Cin;
         float s = 0.0f;
-        for (int l = 0; l < slots; ++l) s += sh[o][l * Cin + cc];
+        for (int l = 0; l < slots; ++l) s += sh[l * Cout * Cin + threadIdx.x];
         partial[(long)blockIdx.x * Cin * Cout + threadIdx.x] = s;
     }
 }
@@ -1188,9 +1259,11 @@ hipError_t launch_bilinear(int bf16, int backward, const void* src, int N, int H
 }
 
 hipError_t launch_head_fwd(int bf16, const void* x, const float* w, long M, int Cin, int Cout, float* y, hipStream_t st_) {
+    // bf16: 0 f32 rows, 1 bf16 rows, 2 split-3 rows
     const unsigned gr = grid_for(M);
-    DISPATCH_T(bf16, hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(gr), dim3(256), 0, st_, (const float*)x, w, M, Cin, Cout, y),
-               hipLaunchKernelGGL(head_fwd_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, (const __bf16*)x, w, M, Cin, Cout, y));
+    if (bf16 == 2) hipLaunchKernelGGL(head_fwd_kernel<S3Row>, dim3(gr), dim3(256), 0, st_, (const S3Row*)x, w, M, Cin, Cout, y);
+    else if (bf16) hipLaunchKernelGGL(head_fwd_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, (const __bf16*)x, w, M, Cin, Cout, y);
+    else hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(gr), dim3(256), 0, st_, (const float*)x, w, M, Cin, Cout, y);
     return hipGetLastError();
 }
 
@@ -1198,12 +1271,13 @@ long head_bwd_blocks(long M) { return (M + HEAD_ROWS - 1) / HEAD_ROWS; }
 
 hipError_t launch_head_bwd(int bf16, const void* x, const float* w, const float* g, long M, int Cin, int Cout, void* gx,
                            float* gw, float* partial, hipStream_t st_) {
-    const unsigned gr = grid_for(M * Cin);
+    const unsigned gr = grid_for(M * (Cin / 8));
     DISPATCH_T(bf16, hipLaunchKernelGGL(head_bwd_data_kernel<float>, dim3(gr), dim3(256), 0, st_, g, w, M, Cin, Cout, (float*)gx),
                hipLaunchKernelGGL(head_bwd_data_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, g, w, M, Cin, Cout, (__bf16*)gx));
     const long nb = head_bwd_blocks(M);
-    DISPATCH_T(bf16, hipLaunchKernelGGL(head_bwd_weight_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st_, (const float*)x, g, M, Cin, Cout, partial),
-               hipLaunchKernelGGL(head_bwd_weight_kernel<__bf16>, dim3((unsigned)nb), dim3(256), 0, st_, (const __bf16*)x, g, M, Cin, Cout, partial));
+    const size_t lds = (size_t)(256 / (Cin / 8)) * Cout * Cin * sizeof(float);
+    DISPATCH_T(bf16, hipLaunchKernelGGL(head_bwd_weight_kernel<float>, dim3((unsigned)nb), dim3(256), lds, st_, (const float*)x, g, M, Cin, Cout, partial),
+               hipLaunchKernelGGL(head_bwd_weight_kernel<__bf16>, dim3((unsigned)nb), dim3(256), lds, st_, (const __bf16*)x, g, M, Cin, Cout, partial));
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, st_, partial, nb, (long)Cin * Cout, gw, 0);
     return hipGetLastError();
 }

@@ -665,6 +665,15 @@ class _Head1x1(torch.autograd.Function):
 
 
 def head_conv1x1(x, weight):
+    if isinstance(x, S3) and not torch.is_grad_enabled():    # split-3 eval forward: the head reads hi + lo itself
+        n, h, w, _ = x.rows.shape
+        cout = weight.shape[0]
+        wt = weight.detach().reshape(cout, x.c).contiguous()
+        y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.rows.device)
+        with torch.cuda.device(y.device):
+            _check(lib().vqseg_head1x1_forward_f(2, x.rows.data_ptr(), _dev(wt, torch.float32, "head weight"), n * h * w, x.c, cout, y.data_ptr(),
+                                                 _stream()), "vqseg_head1x1_forward_f")
+        return _nchw(y)
     return _Head1x1.apply(from_s3(x), weight)
 
 
