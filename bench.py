@@ -91,24 +91,24 @@ def cpu_baseline():
                       f"labelled + {NB} unlabelled images = 2*eval + 4*train = {dt:.1f}s per {2 * NB} images"}
 
 
-def pmc_traffic(per_shape):
-    """HBM bytes per launch of the distance+argmin kernel (launch-weighted over this run's shapes) from the committed
-    rocprofv3 --pmc summary of this same command (profiles/*_vq_assign_pmc.json: FETCH_SIZE x 2 + WRITE_SIZE, corrected
-    as MI355X_MICROARCH.md prescribes).  PMC passes serialise kernels, so they cannot run inside the timed bench."""
+def pmc_traffic(shapes):
+    """HBM bytes per launch of the distance+argmin kernel from the committed rocprofv3 --pmc summary of this same command
+    (profiles/*_vq_assign_pmc.json: FETCH_SIZE x 2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), looked up by the
+    launch's grid: one launch serves the levels `shapes` = [(N, C, K), ...] of a forward.  PMC passes serialise kernels, so they
+    cannot run inside the timed bench."""
     import glob
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_vq_assign_pmc.json")))
     if not files:
         return None, None
-    shapes = json.load(open(files[-1]))["shapes"]
-    total, launches = 0.0, 0
-    for name, (n_launch, _ms, _fl) in per_shape.items():
-        rows = name.split("x")[0]                                      # "N131072"
-        cands = [(int(k.split("_T")[1]), v) for k, v in shapes.items() if k.split("_T")[0] == rows]
-        if not cands:
-            return None, None
-        total += max(cands)[1]["hbm_bytes"] * n_launch               # the forward's plan is the widest tile count
-        launches += n_launch
-    return (round(total / launches) if launches else None), os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
+    table = json.load(open(files[-1]))["shapes"]
+    for t in (8, 4, 2, 1):                                             # vq_group_tiles (csrc/vq_kernels.hip)
+        if any(((k + 31) // 32) % t for _n, _c, k in shapes):
+            continue
+        wgs = sum(((n + 127) // 128 + 7) // 8 * 8 * (((k + 31) // 32) // t) for n, _c, k in shapes)
+        if wgs >= 512 or t == 1:
+            e = table.get(f"WG{wgs}_T{t}")
+            return (round(e["hbm_bytes"]) if e else None), os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
+    return None, None
 
 
 def main():
@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="labelled images per GPU per step (+ as many unlabelled)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="timed region only: skip the all-bf16 step, the supervised step and the roofline_conv steps (profiler passes)")
     ap.add_argument("--eval-amp", action="store_true",
                     help="run the two no-grad pseudo-label forwards under autocast too (all-bf16 step; NOT the reference's "
                          "precision: its trainers run them in fp32, outside autocast)")
@@ -205,25 +207,27 @@ def main():
     # next to the CPS figure, plain forward + backward + Adam of ONE network on the B labelled images
     # (ordinary supervised training throughput) -- measured after, and outside of, the timed region
     (l_in, l_tg), _ul = batches[0]
-    trainer.supervised_step(l_in, l_tg)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    ts = time.perf_counter()
-    for _ in range(3):
+    sup_s = None
+    if not args.no_extras:
         trainer.supervised_step(l_in, l_tg)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    tsup = torch.tensor([(time.perf_counter() - ts) / 3], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tsup, op=dist.ReduceOp.MAX)
-    sup_s = float(tsup.item())
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ts = time.perf_counter()
+        for _ in range(3):
+            trainer.supervised_step(l_in, l_tg)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tsup = torch.tensor([(time.perf_counter() - ts) / 3], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tsup, op=dist.ReduceOp.MAX)
+        sup_s = float(tsup.item())
 
     # the all-bf16 variant of the step (pseudo-label forwards under autocast as well), reported NEXT to the headline: a build-side
     # speed mode, not the reference's precision -- `value` above is the step whose every forward has the reference's precision
     all_bf16_s = None
-    if args.dtype == "bf16" and not args.eval_amp:
+    if args.dtype == "bf16" and not args.eval_amp and not args.no_extras:
         trainer.cfg.eval_amp = True
         one(0)
         torch.cuda.synchronize()
@@ -245,16 +249,16 @@ def main():
     # stream (with two streams a launch's in-stream time would include the other network's kernels sharing the chip).  Outside
     # the timed region: ~700 event pairs per step would perturb the headline.
     conv_recs = []
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         was_two = trainer._two_streams
         trainer._two_streams = False
         one(0)
         torch.cuda.synchronize()
-        _hip.conv_profile_begin(1 << 16)
+        _hip.conv_profile_begin(4096)
         for i in range(2):
             one(i)
         torch.cuda.synchronize()
-        conv_recs = _hip.conv_profile_collect(1 << 16)
+        conv_recs = _hip.conv_profile_collect(4096)
         trainer._two_streams = was_two
     if world > 1:
         dist.barrier()
@@ -272,7 +276,13 @@ def main():
         elem = 2 if args.dtype == "bf16" else 4
         alg_bytes = sum(n * (2.0 * c * elem + 8) for n, c, k, _ in recs)
         hbm_gbs = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(per_shape)
+        group = []                                               # the levels of one (grouped) launch: records until a shape repeats
+        for n, c, k, _ in recs:
+            if (n, c, k) in group:
+                break
+            group.append((n, c, k))
+        n_launch = len(recs) // max(len(group), 1)
+        traffic, traffic_src = pmc_traffic(group)
         images = 2 * args.batch * world * args.steps
         line = {
             "metric": "train images/sec @512x512 vqreptunet1x1 K=512",
@@ -298,7 +308,8 @@ def main():
                                         "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
                                         "note": "algorithmic bytes (rows in + quantised rows out + index) over the same launch times: "
                                                 "the fp32 distance contraction sits far on the MFMA side of the ridge"},
-                         "launches": len(recs), "avg_launch_us": round(ms / max(len(recs), 1) * 1e3, 2),
+                         "launches": n_launch, "levels_per_launch": len(group), "avg_launch_us": round(ms / max(n_launch, 1) * 1e3, 2),
+                         "algorithmic_bytes_per_launch": round(sum(n * (2.0 * c * elem + 8) for n, c, k in group)),
                          "per_shape": {s: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2),
                                            "tflops": round(v[2] / (v[1] / v[0] * 1e-3) / 1e12, 2)}
                                        for s, v in per_shape.items()},
@@ -306,9 +317,10 @@ def main():
                                  "all launches inside the timed region; peak = fp32 MFMA (MI355X_MICROARCH.md); the three levels of "
                                  "a forward share ONE launch (longest workgroups first): its time is apportioned to the levels by flops"},
         }
-        line["supervised_step"] = {"images_per_sec": round(args.batch * world / sup_s, 2), "ms_per_step": round(sup_s * 1e3, 2),
-                                   "what": "forward + backward + Adam of ONE network on the labelled half of the batch "
-                                           "(0.5 CE + Dice + commitment + prototype loss), 3 steps after the timed region"}
+        if sup_s is not None:
+            line["supervised_step"] = {"images_per_sec": round(args.batch * world / sup_s, 2), "ms_per_step": round(sup_s * 1e3, 2),
+                                       "what": "forward + backward + Adam of ONE network on the labelled half of the batch "
+                                               "(0.5 CE + Dice + commitment + prototype loss), 3 steps after the timed region"}
         if conv_recs:
             def rate(sel):
                 fl = sum(f for f, kd, m in conv_recs if sel(kd))

@@ -14,10 +14,10 @@ data = SyntheticCropWeed(512, B, dev, seed=42)
 tr._two_streams = False
 for _ in range(2): tr.step(l_in, l_tg, ul_in)
 torch.cuda.synchronize()
-_hip.conv_profile_begin(1 << 16)
+_hip.conv_profile_begin(4096)
 tr.step(l_in, l_tg, ul_in)
 torch.cuda.synchronize()
-recs = _hip.conv_profile_collect(1 << 16, with_shape=True)
+recs = _hip.conv_profile_collect(4096, with_shape=True)
 agg = collections.OrderedDict()
 for fl, kd, ms, sh in recs:
     a = agg.setdefault((kd, sh), [0, 0.0, 0.0])
