@@ -100,3 +100,41 @@ def test_ema_codebook_stays_identical_across_ranks():
     ref = vq.codebook.embedding.weight.detach().cpu()
     assert ((out[0][0] - ref).abs().max() / ref.abs().max()).item() < 1e-5
     assert torch.allclose(out[0][1], vq.codebook.cluster_size.cpu(), rtol=1e-6)
+
+
+# ---- the real trainer under data parallelism: which buckets are reduced from inside backward, identical replicas ----
+def _trainer_job(rank, world):
+    from vq_seg_amd.trainer import CPSConfig, CPSTrainer, SyntheticCropWeed
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    model = {"name": "vqreptunet1x1", "params": {"encoder_name": "resnet50", "num_classes": 3, "depth": 5,
+                                                 "vq_cfg": {"num_embeddings": [0, 0, 32, 32, 32], "distance": "euclidean", "kmeans_init": True},
+                                                 "margin": 0.0, "scale": 1.0, "use_feature": False, "encoder_weights": None}}
+    tr = CPSTrainer(CPSConfig(model=model, recipe="v1", total_iters=10, amp_dtype=torch.bfloat16, bucket_mb=16.0), dev)
+    data = SyntheticCropWeed(64, 2, dev, seed=5)             # seed * 1000 + rank: every rank its own shard
+    in_bwd = []
+    for _ in range(3):
+        (l_in, l_tg), ul_in = data.labelled(), data.unlabelled()
+        tr.step(l_in, l_tg, ul_in)
+        in_bwd.append([list(b.launched_in_backward) for b in tr.buckets])
+    silent = [sorted(n for n, p in m.named_parameters() if id(p) in b._silent) for m, b in zip(tr.models, tr.buckets)]
+    torch.cuda.synchronize()
+    chk = torch.stack([p.detach().double().sum() for m in tr.models for p in m.parameters()]).cpu()
+    tr.sync_buffers()
+    buf = torch.stack([b.detach().double().sum() for m in tr.models for b in m.buffers()]).cpu()
+    return in_bwd, silent, chk, buf, [len(b.buckets) for b in tr.buckets]
+
+
+def test_cps_trainer_two_ranks_buckets_launch_inside_backward():
+    """the codebooks (and v1's prototypes) never report a gradient; counted as pending they kept their buckets from
+    completing inside backward on the real model.  They are learnt on the first step: from step 2 on every bucket of both networks is
+    all-reduced from inside backward; replicas stay bit-identical; BatchNorm buffers agree after sync_buffers()."""
+    out = spawn(_trainer_job)
+    for in_bwd, silent, _chk, _buf, n_buckets in out:
+        assert all(n >= 3 for n in n_buckets)
+        for m in range(2):
+            assert not all(in_bwd[0][m]), "step 1 cannot complete the buckets that hold gradient-free parameters"
+            assert all(in_bwd[1][m]) and all(in_bwd[2][m]), in_bwd
+            assert silent[m] == sorted([f"codebook.{i}.codebook.embedding.weight" for i in (2, 3, 4)] + ["prototype_loss.embedding.weight"])
+    assert torch.equal(out[0][2], out[1][2]), "replicas diverged"
+    assert torch.equal(out[0][3], out[1][3]), "buffers differ after sync_buffers()"
