@@ -272,7 +272,7 @@ int vqseg_bilinear_f(int bf16, int backward, const void* src, int n, int h, int 
                      int align_corners, void* dst, void* stream);
 
 /* 1x1 segmentation head, nn.Conv2d(32, num_classes, 1, bias=False) (net.py:1169): logits f32.  Cin % 8 == 0, Cin <= 64, Cout <= 4.
- * Row type `bf16`: 0 f32, 1 bf16, 2 (forward only) split-3 rows [3 * Cin] (see "Split-3" below). */
+ * Row type `bf16`: 0 f32, 1 bf16, 2 (forward only) split-3 rows [2 * Cin] (see "Split-3" below). */
 int vqseg_head1x1_forward_f(int bf16, const void* x, const float* w, int64_t m_rows, int cin, int cout,
                             float* y, void* stream);
 size_t vqseg_head1x1_backward_workspace_floats(int64_t m_rows, int cin, int cout);
@@ -287,13 +287,14 @@ int vqseg_reflect_fold_f(int bf16, const void* gp, int n, int h, int w, int c, v
 
 /* ----------------------------------------------------------------------------------
  * "Split-3" activations: the fp32-precision NO-GRAD EVAL forward (the trainers' pseudo-label passes, outside autocast:
- * train_vqreptunet1x1v2.py:143-149) on the bf16 MFMA kernels.  A logical fp32 tensor [rows][C] is kept as [rows][3C] bf16 =
- * [hi | lo | hi] with hi = bf16(v), lo = bf16(v - hi) (v = hi + lo to ~2^-17).  A PLAIN bf16 convolution over the 3C channels
- * with the weight image [w_hi | w_hi | w_lo] computes x_hi w_hi + x_lo w_hi + x_hi w_lo: the same three products, fp32
- * accumulation, as the "precise" kernels (vqseg_conv2d_f precise = 1), on the LDS-DMA / patch-reuse kernels instead.
+ * train_vqreptunet1x1v2.py:143-149) on the bf16 MFMA kernels.  A logical fp32 tensor [rows][C] is kept as [rows][2C] bf16 =
+ * [hi | lo] with hi = bf16(v), lo = bf16(v - hi) (v = hi + lo to ~2^-17).  A bf16 convolution whose K loop runs over the logical
+ * channels [hi | lo | hi] (hi read twice) with the weight image [w_hi | w_hi | w_lo] computes x_hi w_hi + x_lo w_hi + x_hi w_lo:
+ * the same three products, fp32 accumulation, as the "precise" kernels (vqseg_conv2d_f precise = 1), on the LDS-DMA / patch-reuse
+ * kernels instead.
  *   vqseg_conv2d_affine_f(..., precise = 2): x / x2 / res / y are split-3 tensors, cin / c1 / cout LOGICAL channel counts
  *       (Cin, C1 % 32 == 0, Cout % 8 == 0), w_hi = vqseg_conv_pack_weights_s3_f32's image, w_lo unused.
- *   vqseg_im2col_f(out_bf16 = 2, ...): split-3 patch rows [3 * kp] (7x7x3 stem only).
+ *   vqseg_im2col_f(out_bf16 = 2, ...): split-3 patch rows [2 * kp] (7x7x3 stem only).
  *   split / merge: fp32 rows <-> split-3 rows;  maxpool / bilinear: the forward ops of vqseg_maxpool3x3s2_f /
  *       vqseg_bilinear_f on split-3 tensors (values hi + lo, re-split on the way out).  channels % 8 == 0.
  * ---------------------------------------------------------------------------------- */

@@ -24,10 +24,10 @@ def test_split_merge_round_trip_and_elementwise_ops():
     from vq_seg_amd import nnf
     x = (synth.uniform(1, (2, 64, 12, 10), -3, 3) * synth.uniform(2, (2, 64, 12, 10), 0, 1) ** 4).to(dev())     # wide dynamic range
     s = nnf.to_s3(x.contiguous(memory_format=torch.channels_last))
-    assert s.shape == x.shape and s.rows.shape == (2, 12, 10, 192) and s.rows.dtype == torch.bfloat16
+    assert s.shape == x.shape and s.rows.shape == (2, 12, 10, 128) and s.rows.dtype == torch.bfloat16      # [hi | lo]
     back = s.float()
     assert ((back - x).abs() <= 2.0 ** -16 * x.abs() + 1e-30).all()                       # hi + lo keeps ~17 bits
-    assert torch.equal(s.rows[..., :64], s.rows[..., 128:])                             # [hi | lo | hi]
+    assert torch.equal(s.rows[..., :64], x.permute(0, 2, 3, 1).to(torch.bfloat16))                 # hi = bf16(v)
     assert rel(nnf.max_pool_3x3_s2(s).float(), F.max_pool2d(back, 3, 2, 1)) < 1e-5
     for size, align in (((24, 20), False), ((17, 23), False), ((24, 20), True)):
         got = nnf.upsample_bilinear(s, size=size, align_corners=align).float()

@@ -21,9 +21,12 @@ struct ConvArgs {
     const void* ep_res;         // optional residual rows [N, Ho, Wo, Cout] of the activation type
     int ep_relu;
     int pair_chunks = 0, pair_tiles = 0;   // patch kernel, 1-D launch: Cout chunks per pixel tile / pixel tiles (0: 2-D grid)
-    // "split-3" output (fast kernels + fused epilogue only): y and ep_res rows are [3 * Cout] bf16 = [hi | lo | hi] of the fp32
-    // value (see vqseg.h, vqseg_conv2d_affine_f precise == 2); the input is such a tensor too, seen as 3 * C plain bf16 channels
+    // "split-3" output (fast kernels + fused epilogue only): y and ep_res rows are [2 * Cout] bf16 = [hi | lo] of the fp32
+    // value (see vqseg.h, vqseg_conv2d_affine_f precise == 2)
     int out_s3 = 0;
+    // split-3 INPUT: Cin / C1 above are the LOGICAL contraction lengths 3 * (C1s + C2s) / 3 * C1s of [hi | lo | hi] per concat
+    // segment, the tensors x / x2 store [hi | lo] (2 * C1s / 2 * C2s channels per pixel)
+    int s3_in = 0, s3_cs1 = 0, s3_cs2 = 0;
 };
 
 struct WgradArgs {

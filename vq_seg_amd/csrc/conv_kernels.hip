@@ -61,6 +61,27 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i;
 }
 
+// Which source tensor holds contraction channels [ci, ci + chunk): the concat fusion ([0, C1) -> x, [C1, Cin) -> x2), and for
+// split-3 INPUTS (p.s3_in) the fold of the logical [hi | lo | hi] segment (3 Cs channels) onto its stored [hi | lo] rows (2 Cs
+// channels per pixel): the third part re-reads hi (from L2 -- the bytes were fetched a few stages ago).
+struct ASource {
+    const char* src;
+    int csrc, cbase;                                        // channels per pixel row of the source, channel offset inside the row
+};
+__device__ __forceinline__ ASource a_source(const ConvArgs& p, int ci) {
+    const bool second = ci >= p.C1;
+    ASource a;
+    a.src = reinterpret_cast<const char*>(second ? p.x2 : p.x);
+    a.csrc = second ? (p.Cin - p.C1) : p.C1;
+    a.cbase = second ? (ci - p.C1) : ci;
+    if (p.s3_in) {
+        const int cs2 = 2 * (second ? p.s3_cs2 : p.s3_cs1);
+        a.csrc = cs2;
+        if (a.cbase >= cs2) a.cbase -= cs2;
+    }
+    return a;
+}
+
 // ---- shared epilogue: per-wave BN partials from the accumulators, then Y through LDS as 16-byte row segments
 struct LinearRows {                                          // tile row -> output pixel row (NHWC-flattened)
     long m0;
@@ -73,8 +94,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
     if constexpr (__is_same(RowMap, LinearRows)) row_to_m.m0 = m0;
     const long wrow0 = m0 + (long)wm * MT * 32;
     if constexpr (S3) {
-        // split-3 output: the fp32 result v = acc * scale + shift (+ residual, ReLU) leaves as [hi | lo | hi] bf16, hi = bf16(v),
-        // lo = bf16(v - hi): 3 * Cout channels per pixel row.  Staged through LDS as two bf16 tiles so that the stores (and the
+        // split-3 output: the fp32 result v = acc * scale + shift (+ residual, ReLU) leaves as [hi | lo] bf16, hi = bf16(v),
+        // lo = bf16(v - hi): 2 * Cout channels per pixel row (the consumer's K loop reads hi twice: a_source).  Staged through LDS as two bf16 tiles so that the stores (and the
         // residual loads) are whole 16-byte row segments.  Host side guarantees Cout % 8 == 0 and a fused epilogue.
         static_assert(!PRECISE, "split-3 output belongs to the bf16 kernels");
         constexpr int OS = BN + 8;
@@ -100,7 +121,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
         }
         __syncthreads();
         constexpr int CPR = BN / 8;
-        const long rs = 3L * p.Cout;                         // output (and residual) row stride in elements
+        const long rs = 2L * p.Cout;                         // output (and residual) row stride in elements: [hi | lo]
         for (int idx = tid; idx < TBM * CPR; idx += NTHR) {
             const int row = idx / CPR, ch = idx % CPR;
             const long m = row_to_m(row);
@@ -127,7 +148,6 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
                 unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + m * rs + co;
                 *reinterpret_cast<u32x4*>(yp) = vh;
                 *reinterpret_cast<u32x4*>(yp + p.Cout) = vl;
-                *reinterpret_cast<u32x4*>(yp + 2 * p.Cout) = vh;
             }
         }
         return;
@@ -360,10 +380,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         if (tap != cur_tap) set_tap(tap);
         // which source tensor holds this thread's 16-byte chunk (concat fusion): [0, C1) -> x, [C1, Cin) -> x2
         const int cg = ci0 + a_chunk * A_EPC;              // global input channel of the chunk
-        const bool second = cg >= p.C1;
-        const char* src = reinterpret_cast<const char*>(second ? p.x2 : p.x);
-        const int csrc = second ? (p.Cin - p.C1) : p.C1;
-        const int cbase = second ? (cg - p.C1) : cg;
+        const ASource as = a_source(p, cg);
+        const char* src = as.src;
+        const int csrc = as.csrc, cbase = as.cbase;
         const bool c_ok = cg < p.Cin;
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
@@ -606,10 +625,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
         const int tap = s / chunks_per_tap;
         const int ci0 = (s - tap * chunks_per_tap) * BK;
         if (tap != cur_tap) set_tap(tap);
-        const bool second = ci0 >= p.C1;                   // whole stage comes from one source (split % 64 == 0)
-        const char* src = reinterpret_cast<const char*>(second ? p.x2 : p.x);
-        const int csrc = second ? (p.Cin - p.C1) : p.C1;
-        const int cbase = second ? (ci0 - p.C1) : ci0;
+        const ASource as = a_source(p, ci0);               // whole stage comes from one source (split % 64 == 0)
+        const char* src = as.src;
+        const int csrc = as.csrc, cbase = as.cbase;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
             const long off = a_pix[i] * csrc + cbase + a_chunk[i] * 8;
@@ -841,10 +859,9 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
         ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
         const long pix = ((long)n * p.H + ih) * p.W + iw;
         const int ci0 = chunk * CK;
-        const bool second = ci0 >= p.C1;
-        const char* src = reinterpret_cast<const char*>(second ? p.x2 : p.x);
-        const int csrc = second ? (p.Cin - p.C1) : p.C1;
-        const int cbase = second ? (ci0 - p.C1) : ci0;
+        const ASource as = a_source(p, ci0);
+        const char* src = as.src;
+        const int csrc = as.csrc, cbase = as.cbase;
         const long off = pix * csrc + cbase + ((slot ^ swz(pp)) << 3);
         glds16(ok ? src + off * 2 : zero, patch0 + (chunk & 1) * PATCH_BYTES + (wave + NW * i) * 1024);
     };

@@ -84,8 +84,8 @@ int vqseg_conv2d_affine_f(const void* x, const void* x2, int c1, const void* w_h
     if (!scale || !shift) return bad("conv2d_affine: null scale / shift");
     if (res && !a16(res)) return bad("conv2d_affine: pointers must be 16-byte aligned");
     if (precise == 2) {
-        // split-3: x / x2 / res / y are [hi | lo | hi] bf16 tensors of 3 * C channels, w_hi the matching image
-        // (vqseg_conv_pack_weights_s3_f32); the bf16 kernels contract over 3 * cin plain channels
+        // split-3: x / x2 / res / y are [hi | lo] bf16 tensors of 2 * C channels, w_hi the [w_hi | w_hi | w_lo] image
+        // (vqseg_conv_pack_weights_s3_f32); the bf16 kernels contract over 3 * cin channels, the third part re-reading hi
         if (cin % 32 || cout % 8 || c1 % 32 || c1 <= 0 || c1 > cin) return bad("conv2d_affine (split-3): needs Cin, C1 % 32 == 0 and Cout % 8 == 0");
         if (!x || !w_hi || !y || (c1 < cin && !x2)) return bad("conv2d: null pointer");
         if (n <= 0 || h <= 0 || w <= 0 || ho <= 0 || wo <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return bad("conv2d: non-positive dimension");
@@ -99,6 +99,7 @@ int vqseg_conv2d_affine_f(const void* x, const void* x2, int c1, const void* w_h
         a.stride = stride; a.pad = pad; a.reflect = reflect; a.up = 1;
         a.ep_scale = scale; a.ep_shift = shift; a.ep_res = res; a.ep_relu = relu;
         a.out_s3 = 1;
+        a.s3_in = 1; a.s3_cs1 = c1; a.s3_cs2 = cin - c1;
         hipError_t e = vqseg::launch_conv(a, 0, static_cast<hipStream_t>(stream));
         return e == hipSuccess ? 0 : hipfail(e, "conv kernel (split-3)");
     }

@@ -704,12 +704,12 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
 // ---------------------------------------------------------------------------------------------
 // 1x1 segmentation head (Cin <= 64 -> Cout <= 4, no bias): forward, data gradient, weight gradient
 // ---------------------------------------------------------------------------------------------
-// 8 consecutive channels of row `row` (Cin per row) as floats: T = float / __bf16 rows, or split-3 rows (S3Row tag: [hi | lo | hi])
+// 8 consecutive channels of row `row` (Cin per row) as floats: T = float / __bf16 rows, or split-3 rows (S3Row tag: [hi | lo])
 struct S3Row { unsigned short raw; };
 template <typename T>
 __device__ __forceinline__ void ld8(const T* __restrict__ x, long row, int Cin, int c, float (&v)[8]) {
     if constexpr (__is_same(T, S3Row)) {
-        const unsigned short* r = reinterpret_cast<const unsigned short*>(x) + row * 3 * Cin;
+        const unsigned short* r = reinterpret_cast<const unsigned short*>(x) + row * 2 * Cin;
         const u32x4 h = *reinterpret_cast<const u32x4*>(r + c), l = *reinterpret_cast<const u32x4*>(r + Cin + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -952,9 +952,9 @@ __global__ __launch_bounds__(256) void im2col_stem7_kernel(const float* __restri
                 if (ih >= 0 && ih < H && iw >= 0 && iw < W) v[e] = x[(((long)n * H + ih) * W + iw) * CIN + ci];
             }
         }
-        if constexpr (__is_same(TO, S3Out)) {              // split-3 rows [3 * Kp]: chunk ch of hi | lo | hi
+        if constexpr (__is_same(TO, S3Out)) {              // split-3 rows [2 * Kp]: chunk ch of hi | lo
             const size_t row = (size_t)(i / cpr);
-            s3_store8(reinterpret_cast<unsigned short*>(out) + row * 3 * Kp, Kp, ch * 8, v);
+            s3_store8(reinterpret_cast<unsigned short*>(out) + row * 2 * Kp, Kp, ch * 8, v);
         } else {
         TO* dst = out + (size_t)i * 8;
         if constexpr (sizeof(TO) == 2) {
@@ -975,8 +975,9 @@ __global__ __launch_bounds__(256) void im2col_stem7_kernel(const float* __restri
 
 // ---------------------------------------------------------------------------------------------
 // "split-3" activations (the fp32-precision eval forward on the bf16 kernels): a logical fp32 tensor [rows][C] is stored as
-// [rows][3C] bf16 = [hi | lo | hi], hi = bf16(v), lo = bf16(v - hi).  A plain bf16 convolution over the 3C channels with
-// weights [w_hi | w_hi | w_lo] computes x_hi w_hi + x_lo w_hi + x_hi w_lo -- the three products of the precise mode.
+// [rows][2C] bf16 = [hi | lo], hi = bf16(v), lo = bf16(v - hi).  A bf16 convolution over the logical channels [hi | lo | hi]
+// (the K loop reads hi twice) with weights [w_hi | w_hi | w_lo] computes x_hi w_hi + x_lo w_hi + x_hi w_lo -- the three
+// products of the precise mode.
 // Elementwise ops on such tensors work on v = hi + lo (exact in fp32) and re-split.  8 logical channels per thread.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void s3_load8(const unsigned short* row, int C, int c, float (&v)[8]) {
@@ -1001,7 +1002,6 @@ __device__ __forceinline__ void s3_store8(unsigned short* row, int C, int c, con
     }
     *reinterpret_cast<u32x4*>(row + c) = h;
     *reinterpret_cast<u32x4*>(row + C + c) = l;
-    *reinterpret_cast<u32x4*>(row + 2 * C + c) = h;
 }
 
 __global__ __launch_bounds__(256) void s3_split_kernel(const float* __restrict__ x, long rows, int C, unsigned short* __restrict__ y) {
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(256) void s3_split_kernel(const float* __restrict__
         const int c = (int)(i - r * cv) * 8;
         const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * C + c), b = *reinterpret_cast<const f32x4*>(x + r * C + c + 4);
         const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-        s3_store8(y + r * 3 * C, C, c, v);
+        s3_store8(y + r * 2 * C, C, c, v);
     }
 }
 
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(256) void s3_merge_kernel(const unsigned short* __r
         const long r = i / cv;
         const int c = (int)(i - r * cv) * 8;
         float v[8];
-        s3_load8(x + r * 3 * C, C, c, v);
+        s3_load8(x + r * 2 * C, C, c, v);
         *reinterpret_cast<f32x4*>(y + r * C + c) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(y + r * C + c + 4) = f32x4{v[4], v[5], v[6], v[7]};
     }
@@ -1048,13 +1048,13 @@ __global__ __launch_bounds__(256) void s3_maxpool_kernel(const unsigned short* _
                 const int iw = ow * 2 - 1 + kw;
                 if (iw < 0 || iw >= W) continue;
                 float v[8];
-                s3_load8(x + (((long)n * H + ih) * W + iw) * 3 * C, C, c, v);
+                s3_load8(x + (((long)n * H + ih) * W + iw) * 2 * C, C, c, v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (v[e] > best[e] || v[e] != v[e]) best[e] = v[e];
             }
         }
-        s3_store8(y + (((long)n * Ho + oh) * Wo + ow) * 3 * C, C, c, best);
+        s3_store8(y + (((long)n * Ho + oh) * Wo + ow) * 2 * C, C, c, best);
     }
 }
 
@@ -1072,14 +1072,14 @@ __global__ __launch_bounds__(256) void s3_bilinear_kernel(const unsigned short* 
         bil_src(ow, W, Wo, align, w0, w1, lw);
         const long b = (long)n * H;
         float v00[8], v01[8], v10[8], v11[8], o[8];
-        s3_load8(x + ((b + h0) * W + w0) * 3 * C, C, c, v00);
-        s3_load8(x + ((b + h0) * W + w1) * 3 * C, C, c, v01);
-        s3_load8(x + ((b + h1) * W + w0) * 3 * C, C, c, v10);
-        s3_load8(x + ((b + h1) * W + w1) * 3 * C, C, c, v11);
+        s3_load8(x + ((b + h0) * W + w0) * 2 * C, C, c, v00);
+        s3_load8(x + ((b + h0) * W + w1) * 2 * C, C, c, v01);
+        s3_load8(x + ((b + h1) * W + w0) * 2 * C, C, c, v10);
+        s3_load8(x + ((b + h1) * W + w1) * 2 * C, C, c, v11);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             o[e] = (1.0f - lh) * ((1.0f - lw) * v00[e] + lw * v01[e]) + lh * ((1.0f - lw) * v10[e] + lw * v11[e]);
-        s3_store8(y + (((long)n * Ho + oh) * Wo + ow) * 3 * C, C, c, o);
+        s3_store8(y + (((long)n * Ho + oh) * Wo + ow) * 2 * C, C, c, o);
     }
 }
 

@@ -153,12 +153,13 @@ def _sink_done(p) -> None:
 # "Split-3" activations: the fp32-precision no-grad eval forward on the bf16 kernels (include/vqseg.h, "Split-3").
 # The reference trainers run their two pseudo-label forwards in fp32, OUTSIDE autocast (train_vqreptunet1x1v2.py:143-149).
 # The "precise" kernels do that with on-the-fly bf16 hi/lo splits inside a register-staged kernel; here the SAME three products
-# run on the LDS-DMA / patch-reuse bf16 kernels by keeping every activation of such a forward as [hi | lo | hi] bf16.
+# run on the LDS-DMA / patch-reuse bf16 kernels by keeping every activation of such a forward as [hi | lo] bf16 (the
+# convolution's K loop runs over [hi | lo | hi], reading hi twice, against weights [w_hi | w_hi | w_lo]).
 # An `S3` object stands in for the logical (N, C, H, W) fp32 tensor between the layers of ONE model forward; it never leaves
 # the model (the model's `encode` opens the scope, the 1x1 head / the VQ layers merge back to fp32).
 # ------------------------------------------------------------------------------------------------
 class S3:
-    """rows: (N, H, W, 3C) bf16 contiguous = [hi | lo | hi] of the logical fp32 tensor (N, C, H, W)."""
+    """rows: (N, H, W, 2C) bf16 contiguous = [hi | lo] of the logical fp32 tensor (N, C, H, W)."""
     __slots__ = ("rows", "c")
 
     def __init__(self, rows: torch.Tensor, c: int):
@@ -214,7 +215,7 @@ def to_s3(x) -> "S3":
         return x
     xr = _rows(x.float())
     n, h, w, c = xr.shape
-    out = torch.empty((n, h, w, 3 * c), dtype=torch.bfloat16, device=xr.device)
+    out = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=xr.device)
     with torch.cuda.device(xr.device):
         _check(lib().vqseg_s3_split_f(xr.data_ptr(), n * h * w, c, out.data_ptr(), _stream()), "vqseg_s3_split_f")
     return S3(out, c)
@@ -265,7 +266,7 @@ def _conv_bn_act_s3(x: "S3", x2, residual, conv, bn, relu, kernel_1x1_cols: int 
     wimg = _s3_weights(conv.weight, c1, kernel_1x1_cols)
     res = to_s3(residual) if residual is not None else None
     coef = torch.empty(4, cout, dtype=torch.float32, device=dev)
-    out = torch.empty((n, ho, wo, 3 * cout), dtype=torch.bfloat16, device=dev)
+    out = torch.empty((n, ho, wo, 2 * cout), dtype=torch.bfloat16, device=dev)
     with torch.cuda.device(dev):
         _check(L.vqseg_bn_finalize_f(None, n * ho * wo, cout, _dev(bn.weight, torch.float32, "bn.weight"), _dev(bn.bias, torch.float32, "bn.bias"),
                                      _p(bn.running_mean), _p(bn.running_var), float(bn.momentum), float(bn.eps), 0, coef[0].data_ptr(),
@@ -535,7 +536,7 @@ def stem_conv_bn_act(x, conv, bn):
         kp3 = (kh * kw * cin + 63) // 64 * 64
 
         def make3():
-            out = torch.empty((n, ho, wo, 3 * kp3), dtype=torch.bfloat16, device=x.device)
+            out = torch.empty((n, ho, wo, 2 * kp3), dtype=torch.bfloat16, device=x.device)
             with torch.cuda.device(x.device):
                 _check(lib().vqseg_im2col_f(2, xr.data_ptr(), n, h, w, cin, kh, kw, s, p, int(reflect), ho, wo, kp3, out.data_ptr(), _stream()),
                        "vqseg_im2col_f (split-3)")
@@ -589,7 +590,7 @@ def max_pool_3x3_s2(x):
     if isinstance(x, S3):
         n, h, w, _ = x.rows.shape
         ho, wo = _out_size(h, 3, 2, 1), _out_size(w, 3, 2, 1)
-        y = torch.empty((n, ho, wo, 3 * x.c), dtype=torch.bfloat16, device=x.rows.device)
+        y = torch.empty((n, ho, wo, 2 * x.c), dtype=torch.bfloat16, device=x.rows.device)
         with torch.cuda.device(y.device):
             _check(lib().vqseg_s3_maxpool3x3s2_f(x.rows.data_ptr(), n, h, w, x.c, y.data_ptr(), _stream()), "vqseg_s3_maxpool3x3s2_f")
         return S3(y, x.c)
@@ -624,7 +625,7 @@ def upsample_bilinear(x, size=None, scale_factor=None, align_corners=False):
         size = (int(x.shape[-2] * scale_factor), int(x.shape[-1] * scale_factor))
     if isinstance(x, S3):
         n, h, w, _ = x.rows.shape
-        y = torch.empty((n, int(size[0]), int(size[1]), 3 * x.c), dtype=torch.bfloat16, device=x.rows.device)
+        y = torch.empty((n, int(size[0]), int(size[1]), 2 * x.c), dtype=torch.bfloat16, device=x.rows.device)
         with torch.cuda.device(y.device):
             _check(lib().vqseg_s3_bilinear_f(x.rows.data_ptr(), n, h, w, x.c, int(size[0]), int(size[1]), int(bool(align_corners)),
                                              y.data_ptr(), _stream()), "vqseg_s3_bilinear_f")
