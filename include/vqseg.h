@@ -299,6 +299,17 @@ int vqseg_reflect_fold_f(int bf16, const void* gp, int n, int h, int w, int c, v
  *       vqseg_bilinear_f on split-3 tensors (values hi + lo, re-split on the way out).  channels % 8 == 0.
  * ---------------------------------------------------------------------------------- */
 int vqseg_conv_pack_weights_s3_f32(const float* w, int cout, int cin, int c1, int kh, int kw, void* out, void* stream);
+
+/* Data gradient of a STRIDE-2 convolution (encoder: the 3x3 conv2 of a stage's first bottleneck and its 1x1 projection shortcut,
+ * resnet.py:117-190 on torchvision's Bottleneck) without the 4x wasted work of an up-sampled ("dilated") gradient grid: the
+ * output pixels split into parity classes, each a small stride-1 convolution over gy (k = 3: 2x2, 2x1, 1x2, 1x1 taps; k = 1:
+ * one class, the other pixels are zero).  gx is (n, oh, ow, cin): for k = 3 the PADDED input grid (oh = h + 2; fold reflect /
+ * crop zero padding afterwards), for k = 1 the input grid.  Weights: vqseg_conv_pack_weights_s2_f32's sub-images
+ * (vqseg_conv_packed_s2_elems elements each for hi / lo; lo only in precise mode). */
+size_t vqseg_conv_packed_s2_elems(int cout, int cin, int k);
+int vqseg_conv_pack_weights_s2_f32(const float* w, int cout, int cin, int k, void* hi, void* lo, void* stream);
+int vqseg_conv2d_dgrad_s2_f(const void* gy, const void* w_hi, const void* w_lo, void* gx, int n, int ho, int wo, int cout, int cin,
+                            int k, int oh, int ow, int precise, void* stream);
 int vqseg_s3_split_f(const float* x, int64_t rows, int channels, void* y, void* stream);
 int vqseg_s3_merge_f(const void* x, int64_t rows, int channels, float* y, void* stream);
 int vqseg_s3_maxpool3x3s2_f(const void* x, int n, int h, int w, int c, void* y, void* stream);

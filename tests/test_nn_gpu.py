@@ -32,6 +32,10 @@ CONV_CASES = [
     (2, 64, 128, 17, 13, 3, 1, 1, True, 0, False),          # reflect, ragged spatial size
     (1, 128, 256, 16, 16, 3, 2, 1, True, 0, False),         # stride-2 reflect (bottleneck conv2 of a stage's first block)
     (2, 256, 512, 8, 8, 1, 2, 0, False, 0, False),          # 1x1 stride-2 projection shortcut
+    (2, 64, 64, 15, 19, 3, 2, 1, True, 0, False),           # stride-2 data gradient by parity classes: odd sizes, reflect
+    (1, 64, 128, 14, 10, 3, 2, 1, False, 0, False),         # ... zero padding (plain UNet's encoder)
+    (2, 64, 128, 9, 7, 1, 2, 0, False, 0, False),           # ... 1x1, odd sizes
+    (1, 24, 40, 12, 12, 3, 2, 1, True, 0, False),           # ... channel counts that are not multiples of 32
     (2, 64, 256, 12, 12, 1, 1, 0, False, 0, True),          # conv3 + residual + relu
     (2, 128, 32, 24, 24, 3, 1, 1, False, 64, False),        # decoder concat 128 + 64 -> 32
     (1, 32, 32, 40, 40, 3, 1, 1, False, 0, False),

@@ -27,6 +27,10 @@ struct ConvArgs {
     // split-3 INPUT: Cin / C1 above are the LOGICAL contraction lengths 3 * (C1s + C2s) / 3 * C1s of [hi | lo | hi] per concat
     // segment, the tensors x / x2 store [hi | lo] (2 * C1s / 2 * C2s channels per pixel)
     int s3_in = 0, s3_cs1 = 0, s3_cs2 = 0;
+    int pad_w = -1;             // column padding when it differs from `pad` (-1: same); set by launch_conv
+    // strided output placement: GEMM row (n, oh, ow) -> pixel (n, 2 oh + omap_ph, 2 ow + omap_pw) of an omap_h x omap_w grid
+    int omap = 0, omap_h = 0, omap_w = 0, omap_ph = 0, omap_pw = 0;
+    int prof_k = 0;             // kernel size the launch is filed under by the convolution profile (0: KH)
 };
 
 struct WgradArgs {
@@ -52,6 +56,9 @@ hipError_t launch_wgrad_reduce(const float* partial, int slabs, int Cout, int Ci
 size_t packed_elems(int Cout, int Cin, int KH, int KW, int transpose_flip);
 hipError_t launch_pack_weights(const float* w, int Cout, int Cin, int KH, int KW, int transpose_flip, unsigned short* hi,
                                unsigned short* lo, hipStream_t st);
+hipError_t launch_pack_weights_s2(const float* w, int Cout, int Cin, int K, unsigned short* hi, unsigned short* lo, hipStream_t st);
+hipError_t launch_dgrad_s2(const void* gy, const unsigned short* w_hi, const unsigned short* w_lo, void* gx, int N, int Ho, int Wo,
+                           int Cout, int Cin, int K, int OH, int OW, int precise, hipStream_t st);
 hipError_t launch_pack_weights_s3(const float* w, int Cout, int Cin, int C1, int KH, int KW, unsigned short* out, hipStream_t st);
 
 }  // namespace vqseg

@@ -82,6 +82,16 @@ __device__ __forceinline__ ASource a_source(const ConvArgs& p, int ci) {
     return a;
 }
 
+// Strided output placement (p.omap): GEMM row m = (n, oh, ow) of the Ho x Wo problem lands on pixel (n, 2 oh + ph, 2 ow + pw) of
+// an OH x OW grid -- the parity classes of a stride-2 data gradient (launch_dgrad_s2).  Two 32-bit divisions per written row.
+__device__ __forceinline__ long out_row(const ConvArgs& p, long m) {
+    if (!p.omap) return m;
+    const unsigned hw = (unsigned)(p.Ho * p.Wo), um = (unsigned)m;
+    const unsigned n = um / hw, rem = um - n * hw;
+    const unsigned oh = rem / (unsigned)p.Wo, ow = rem - oh * (unsigned)p.Wo;
+    return ((long)n * p.omap_h + 2 * oh + p.omap_ph) * p.omap_w + 2 * ow + p.omap_pw;
+}
+
 // ---- shared epilogue: per-wave BN partials from the accumulators, then Y through LDS as 16-byte row segments
 struct LinearRows {                                          // tile row -> output pixel row (NHWC-flattened)
     long m0;
@@ -247,7 +257,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
                         }
                     }
                 }
-                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.y) + (m * p.Cout + co) * (PRECISE ? 4 : 2)) = v;
+                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.y) + (out_row(p, m) * p.Cout + co) * (PRECISE ? 4 : 2)) = v;
             }
         }
     } else {
@@ -271,8 +281,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
                             }
                             if (p.ep_relu && !(v > 0.0f)) v = 0.0f;
                         }
-                        if (PRECISE) reinterpret_cast<float*>(p.y)[m * p.Cout + co] = v;
-                        else reinterpret_cast<__bf16*>(p.y)[m * p.Cout + co] = (__bf16)v;
+                        const long mo = out_row(p, m);
+                        if (PRECISE) reinterpret_cast<float*>(p.y)[mo * p.Cout + co] = v;
+                        else reinterpret_cast<__bf16*>(p.y)[mo * p.Cout + co] = (__bf16)v;
                     }
                 }
         }
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             int ih = a_oh[i] * p.stride - p.pad + kh;
-            int iw = a_ow[i] * p.stride - p.pad + kw;
+            int iw = a_ow[i] * p.stride - p.pad_w + kw;
             bool ok = a_ok[i];
             if (p.reflect) {
                 ih = reflect_idx(ih, p.H * p.up);
@@ -602,7 +613,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
             int ih = a_oh[i] * p.stride - p.pad + kh;
-            int iw = a_ow[i] * p.stride - p.pad + kw;
+            int iw = a_ow[i] * p.stride - p.pad_w + kw;
             bool ok = a_ok[i];
             if (p.reflect) {
                 ih = reflect_idx(ih, p.H * p.up);
@@ -1048,6 +1059,7 @@ int conv_set_option(const char* key, int value) {
 }
 
 static bool conv3x3_patch_ok(const ConvArgs& a) {
+    if (a.omap || a.pad_w != a.pad) return false;
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.up != 1 || a.Ho != a.H || a.Wo != a.W) return false;
     const int ck = a.Cin % 64 == 0 && (a.C1 == a.Cin || a.C1 % 64 == 0) ? 64 : 32;
     if (a.Cin % ck || (a.C1 != a.Cin && a.C1 % ck) || (a.Cout % 128 && a.Cout != 64 && a.Cout != 32)) return false;
@@ -1142,6 +1154,57 @@ __global__ __launch_bounds__(256) void conv_pack_weights_s3(const float* __restr
     }
 }
 
+// Data gradient of a STRIDE-2 convolution without the dilated grid.  Forward: y[oh, ow] = sum_{kh, kw} Xp[2 oh + kh, 2 ow + kw] w[kh, kw]
+// (Xp: the padded input).  An input row ip receives only the taps with (ip - kh) even:
+//   3 taps:  ip = 2 i   <- kh = 2 from output row i - 1, kh = 0 from row i      (a 2-tap window starting at i - 1: "pad" 1)
+//            ip = 2 i + 1 <- kh = 1 from row i                                    (1 tap, pad 0)
+//   1 tap (1x1 layers):  ip = 2 i <- row i;  odd rows receive nothing (the output is zero-filled first).
+// So the gradient is 4 (or 1) small stride-1 convolutions over gy -- one per parity class (ph, pw) of the output pixel -- whose
+// results land on pixels (2 i + ph, 2 j + pw) (ConvArgs::omap): 9 taps of MFMA work per 4 output pixels instead of 36.
+// Sub-images, data-gradient form [Cin][KH'][KW'][Cout padded to 32] (contraction over Cout), in class order (0,0), (0,1), (1,0), (1,1):
+// class parity 0 holds the forward taps (2, 0) in window order, parity 1 the tap (1).
+__global__ __launch_bounds__(256) void conv_pack_weights_s2(const float* __restrict__ w, int Cout, int Cin, int K,
+                                                            unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+    const int Cp = (Cout + 31) / 32 * 32;
+    const long per_tap = (long)Cp;                          // elements per (ci, tap)
+    const int taps_total = K * K;                           // 9 (or 1): the classes partition the taps
+    const long total = (long)Cin * taps_total * per_tap;
+    // class (ph, pw): window sizes nh = (K == 3 ? (ph ? 1 : 2) : 1), same for nw; element order inside a class: [ci][th][tw][co]
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long t = i;
+        int ph = 0, pw = 0, nh = 1, nw = 1;
+        long base = 0;
+        if (K == 3) {
+            for (int cls = 0; cls < 4; ++cls) {
+                ph = cls >> 1;
+                pw = cls & 1;
+                nh = ph ? 1 : 2;
+                nw = pw ? 1 : 2;
+                const long sz = (long)Cin * nh * nw * per_tap;
+                if (t < base + sz) break;
+                base += sz;
+            }
+        }
+        t -= base;
+        const int co = (int)(t % Cp);
+        t /= Cp;
+        const int tw = (int)(t % nw);
+        t /= nw;
+        const int th = (int)(t % nh);
+        const int ci = (int)(t / nh);
+        const int kh = K == 3 ? (ph ? 1 : (th == 0 ? 2 : 0)) : 0;
+        const int kw = K == 3 ? (pw ? 1 : (tw == 0 ? 2 : 0)) : 0;
+        float v = 0.0f;
+        if (co < Cout) v = w[(((long)co * Cin + ci) * K + kh) * K + kw];
+        const __bf16 bh = (__bf16)v;
+        hi[i] = __builtin_bit_cast(unsigned short, bh);
+        if (lo) {
+            const __bf16 bl = (__bf16)(v - (float)bh);
+            lo[i] = __builtin_bit_cast(unsigned short, bl);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // host-side launch
 // ------------------------------------------------------------------------------------
@@ -1222,7 +1285,9 @@ int conv_profile_collect(int max_records, double* flops, int* kind, float* ms, i
 
 static hipError_t launch_conv_impl(const ConvArgs& a, int precise, hipStream_t st);
 
-hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
+hipError_t launch_conv(const ConvArgs& a_in, int precise, hipStream_t st) {
+    ConvArgs a = a_in;
+    if (a.pad_w < 0) a.pad_w = a.pad;
     const bool rec = g_cprof.enabled && g_cprof.count < g_cprof.capacity;
     const int slot = g_cprof.count;
     if (rec) {
@@ -1232,11 +1297,11 @@ hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st) {
         const double cin = a.out_s3 ? a.Cin / 3.0 : (double)a.Cin;
         const double px = a.up == 2 ? (double)a.N * a.H * a.W : (double)a.N * a.Ho * a.Wo;
         g_cprof.flops[slot] = 2.0 * a.KH * a.KW * cin * a.Cout * px;
-        g_cprof.kind[slot] = a.KH * 100 + (a.out_s3 ? 2 : (precise ? 1 : 0));
+        g_cprof.kind[slot] = (a.prof_k ? a.prof_k : a.KH) * 100 + (a.out_s3 ? 2 : (precise ? 1 : 0));
         g_cprof.shape[4 * slot + 0] = (int)(((long)a.N * a.Ho * a.Wo) >> 10);
         g_cprof.shape[4 * slot + 1] = (int)cin;
         g_cprof.shape[4 * slot + 2] = a.Cout;
-        g_cprof.shape[4 * slot + 3] = a.stride * 10 + a.up;
+        g_cprof.shape[4 * slot + 3] = a.stride * 10 + a.up + (a.omap ? 2 : 0);          // ..3: a parity class of a stride-2 data gradient
         ++g_cprof.count;
         (void)hipEventRecord(g_cprof.ev[2 * slot], st);
     }
@@ -1298,6 +1363,45 @@ static hipError_t launch_conv_impl(const ConvArgs& a, int precise, hipStream_t s
 size_t packed_elems(int Cout, int Cin, int KH, int KW, int transpose_flip) {
     const int R = transpose_flip ? Cin : Cout, Cc = transpose_flip ? Cout : Cin;
     return (size_t)R * KH * KW * ((Cc + 31) / 32 * 32);
+}
+
+hipError_t launch_pack_weights_s2(const float* w, int Cout, int Cin, int K, unsigned short* hi, unsigned short* lo, hipStream_t st) {
+    const long total = (long)Cin * K * K * ((Cout + 31) / 32 * 32);
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_pack_weights_s2, dim3((unsigned)blocks), dim3(256), 0, st, w, Cout, Cin, K, hi, lo);
+    return hipGetLastError();
+}
+
+// gx (n, OH, OW, Cin) = data gradient of a stride-2 K x K convolution (K = 3: padded-input grid OH = H + 2 with the reflect /
+// zero fold left to the caller; K = 1: the input grid itself) from gy (n, Ho, Wo, Cout) and conv_pack_weights_s2's sub-images
+hipError_t launch_dgrad_s2(const void* gy, const unsigned short* w_hi, const unsigned short* w_lo, void* gx, int N, int Ho, int Wo,
+                           int Cout, int Cin, int K, int OH, int OW, int precise, hipStream_t st) {
+    const int Cp = (Cout + 31) / 32 * 32;
+    if (K == 1) {
+        hipError_t e = hipMemsetAsync(gx, 0, (size_t)N * OH * OW * Cin * (precise ? 4 : 2), st);
+        if (e != hipSuccess) return e;
+    }
+    size_t off = 0;
+    for (int cls = 0; cls < (K == 3 ? 4 : 1); ++cls) {
+        const int ph = cls >> 1, pw = cls & 1;
+        const int nh = K == 3 ? (ph ? 1 : 2) : 1, nw = K == 3 ? (pw ? 1 : 2) : 1;
+        ConvArgs a;
+        a.x = gy; a.x2 = nullptr; a.C1 = Cout;
+        a.w_hi = w_hi + off; a.w_lo = w_lo ? w_lo + off : nullptr;
+        a.y = gx; a.stat_partial = nullptr;
+        a.N = N; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Cout = Cin; a.KH = nh; a.KW = nw;
+        a.Ho = (OH - ph + 1) / 2; a.Wo = (OW - pw + 1) / 2;              // output pixels of this parity class
+        a.stride = 1; a.pad = K == 3 ? (ph ? 0 : 1) : 0; a.pad_w = K == 3 ? (pw ? 0 : 1) : 0; a.reflect = 0; a.up = 1;
+        a.ep_scale = nullptr; a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_relu = 0;
+        a.omap = 1; a.omap_h = OH; a.omap_w = OW; a.omap_ph = ph; a.omap_pw = pw;
+        a.prof_k = K;
+        if ((long)a.N * a.Ho * a.Wo >= (1L << 31)) return hipErrorInvalidValue;
+        hipError_t e = launch_conv(a, precise, st);
+        if (e != hipSuccess) return e;
+        off += (size_t)Cin * nh * nw * Cp;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_pack_weights_s3(const float* w, int Cout, int Cin, int C1, int KH, int KW, unsigned short* out, hipStream_t st) {

@@ -244,6 +244,32 @@ int vqseg_im2col_f(int out_bf16, const float* x, int n, int h, int w, int cin, i
     return e == hipSuccess ? 0 : hipfail(e, "im2col_stem_kernel");
 }
 
+size_t vqseg_conv_packed_s2_elems(int cout, int cin, int k) {
+    if (cout <= 0 || cin <= 0 || (k != 1 && k != 3)) return 0;
+    return (size_t)cin * k * k * ((cout + 31) / 32 * 32);
+}
+
+int vqseg_conv_pack_weights_s2_f32(const float* w, int cout, int cin, int k, void* hi, void* lo, void* stream) {
+    if (!w || !hi || cout <= 0 || cin <= 0 || (k != 1 && k != 3)) return bad("conv_pack_weights_s2: bad argument (k = 1 or 3)");
+    hipError_t e = vqseg::launch_pack_weights_s2(w, cout, cin, k, static_cast<unsigned short*>(hi), static_cast<unsigned short*>(lo),
+                                                 static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "conv_pack_weights_s2");
+}
+
+int vqseg_conv2d_dgrad_s2_f(const void* gy, const void* w_hi, const void* w_lo, void* gx, int n, int ho, int wo, int cout, int cin, int k,
+                            int oh, int ow, int precise, void* stream) {
+    if (!gy || !w_hi || !gx || (precise && !w_lo)) return bad("conv2d_dgrad_s2: null pointer");
+    if (n <= 0 || ho <= 0 || wo <= 0 || cout <= 0 || cin <= 0 || oh <= 0 || ow <= 0 || (k != 1 && k != 3)) return bad("conv2d_dgrad_s2: bad dimension");
+    const int epc = precise ? 4 : 8;
+    if (cout % epc || cin % epc) return bad("conv2d_dgrad_s2: channels must be multiples of 4 (f32) / 8 (bf16)");
+    if (!a16(gy) || !a16(w_hi) || !a16(w_lo) || !a16(gx)) return bad("conv2d_dgrad_s2: pointers must be 16-byte aligned");
+    // the grid must be the one the forward layer's geometry implies: k = 3 -> padded input (2 ho + 1 or 2 ho + 2 rows), k = 1 -> 2 ho - 1 or 2 ho
+    if (oh < 2 * ho - 1 || oh > 2 * ho + 2 || ow < 2 * wo - 1 || ow > 2 * wo + 2) return bad("conv2d_dgrad_s2: output grid does not match a stride-2 layer");
+    hipError_t e = vqseg::launch_dgrad_s2(gy, static_cast<const unsigned short*>(w_hi), static_cast<const unsigned short*>(w_lo), gx, n, ho, wo,
+                                          cout, cin, k, oh, ow, precise, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "conv2d_dgrad_s2");
+}
+
 int vqseg_conv_pack_weights_s3_f32(const float* w, int cout, int cin, int c1, int kh, int kw, void* out, void* stream) {
     if (!w || !out || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || c1 <= 0 || c1 > cin || cin % 32 || c1 % 32)
         return bad("conv_pack_weights_s3: bad argument (Cin and the concat split must be multiples of 32)");

@@ -423,8 +423,19 @@ class _ConvBNAct(torch.autograd.Function):
                                                        kh, kw, 1, dpad, 0, hp, wp, int(precise), _stream()), "vqseg_conv2d_affine_f")
                     extra = None
                     return gp
-                gp = _conv_raw(g_y, None, cout, t_hi, t_lo, (n, hp, wp, c_cnt), None, n, ho, wo, cout, c_cnt, kh, kw, 1, dpad, False,
-                               stride, hp, wp, w_offset_elems=c_lo * taps * ((cout + 31) // 32 * 32))
+                if stride == 2 and x2r is None and kh == kw and ((kh == 1 and pad == 0) or (kh == 3 and pad == 1)) and py_opt("py_dgrad_s2", 1):
+                    # stride-2 layer: parity classes of the output pixel instead of a dilated gradient grid (vqseg_conv2d_dgrad_s2_f)
+                    s_hi, s_lo = _s2_weights(weight, precise)
+                    gh, gw_ = (h + 2, w + 2) if kh == 3 else (h, w)          # k = 3: the padded input's grid
+                    gp = torch.empty((n, gh, gw_, c_cnt), dtype=g_y.dtype, device=dev)
+                    with torch.cuda.device(dev):
+                        _check(L.vqseg_conv2d_dgrad_s2_f(g_y.data_ptr(), s_hi.data_ptr(), _p(s_lo), gp.data_ptr(), n, ho, wo, cout, c_cnt, kh,
+                                                         gh, gw_, int(precise), _stream()), "vqseg_conv2d_dgrad_s2_f")
+                    if kh == 3 and not reflect:                              # zero padding: the gradient of the padded border is dropped
+                        return gp[:, 1:h + 1, 1:w + 1, :].contiguous()
+                else:
+                    gp = _conv_raw(g_y, None, cout, t_hi, t_lo, (n, hp, wp, c_cnt), None, n, ho, wo, cout, c_cnt, kh, kw, 1, dpad, False,
+                                   stride, hp, wp, w_offset_elems=c_lo * taps * ((cout + 31) // 32 * 32))
                 if not reflect:
                     return gp
                 if pad != 1:
@@ -449,6 +460,24 @@ class _ConvBNAct(torch.autograd.Function):
         g_res_out = _nchw(g_res) if (has_res and link_out is None) else None
         return (gx, gx2, g_res_out, None if sink_w else gw, None if sink_bn else dgb[0],
                 None if sink_bn else dgb[1], None, None, None, None, None, None, None, None, None, None)
+
+
+def _s2_weights(weight, precise):
+    """parity-class sub-images of a stride-2 layer's weight for its data gradient (vqseg_conv_pack_weights_s2_f32)"""
+    cache = _cache_of(weight)
+    k = ("s2", precise)
+    if k not in cache:
+        w = weight.detach()
+        w = w if w.is_contiguous() else w.contiguous()
+        cout, cin, kh, _kw = w.shape
+        nel = lib().vqseg_conv_packed_s2_elems(cout, cin, kh)
+        hi = torch.empty(nel, dtype=torch.int16, device=w.device)
+        lo = torch.empty(nel, dtype=torch.int16, device=w.device) if precise else None
+        with torch.cuda.device(w.device):
+            _check(lib().vqseg_conv_pack_weights_s2_f32(_dev(w, torch.float32, "weight"), cout, cin, kh, hi.data_ptr(), _p(lo), _stream()),
+                   "vqseg_conv_pack_weights_s2_f32")
+        cache[k] = (hi, lo)
+    return cache[k]
 
 
 def _stem_weights(weight, precise, kp):
