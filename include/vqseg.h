@@ -306,6 +306,10 @@ int vqseg_conv_pack_weights_s3_f32(const float* w, int cout, int cin, int c1, in
  * one class, the other pixels are zero).  gx is (n, oh, ow, cin): for k = 3 the PADDED input grid (oh = h + 2; fold reflect /
  * crop zero padding afterwards), for k = 1 the input grid.  Weights: vqseg_conv_pack_weights_s2_f32's sub-images
  * (vqseg_conv_packed_s2_elems elements each for hi / lo; lo only in precise mode). */
+/* The forward (vqseg_conv_pack_weights_f32, transpose_flip = 0, hi), data-gradient (transpose_flip = 1, hi) and split-3
+ * (vqseg_conv_pack_weights_s3_f32) images of one k x k weight (k = 1 or 3) in ONE launch; any of the three outputs may be NULL.
+ * Bit-identical to the single-image entry points. */
+int vqseg_conv_pack_all_f32(const float* w, int cout, int cin, int k, int c1, void* fwd, void* tr, void* s3, void* stream);
 size_t vqseg_conv_packed_s2_elems(int cout, int cin, int k);
 int vqseg_conv_pack_weights_s2_f32(const float* w, int cout, int cin, int k, void* hi, void* lo, void* stream);
 int vqseg_conv2d_dgrad_s2_f(const void* gy, const void* w_hi, const void* w_lo, void* gx, int n, int ho, int wo, int cout, int cin,

@@ -82,3 +82,28 @@ def test_data_write_to_the_codebook_needs_invalidate_and_then_works():
     vq.load_state_dict(sd)                                   # copy_ on the parameter: version counter, nothing to call
     ref.load_state_dict(sd)
     assert torch.equal(vq(x)[1], ref(x)[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cout,cin,k,c1", [(64, 64, 3, 64), (128, 96, 3, 64), (40, 24, 3, 24), (256, 64, 1, 64), (32, 192, 3, 128), (1024, 2048, 3, 2048)])
+def test_pack_all_is_bit_identical_to_the_single_image_packers(cout, cin, k, c1):
+    """vqseg_conv_pack_all_f32 (one launch: forward, data-gradient and split-3 images) against the three single-image entry points."""
+    from vq_seg_amd import _hip
+    L = _hip.lib()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(cout + cin)
+    w = (torch.randn(cout, cin, k, k, device=dev) * 0.1).contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    n_f, n_t = L.vqseg_conv_packed_elems(cout, cin, k, k, 0), L.vqseg_conv_packed_elems(cout, cin, k, k, 1)
+    ref_f, ref_t = torch.full((n_f,), -1, dtype=torch.int16, device=dev), torch.full((n_t,), -1, dtype=torch.int16, device=dev)
+    assert L.vqseg_conv_pack_weights_f32(w.data_ptr(), cout, cin, k, k, 0, ref_f.data_ptr(), None, st) == 0
+    assert L.vqseg_conv_pack_weights_f32(w.data_ptr(), cout, cin, k, k, 1, ref_t.data_ptr(), None, st) == 0
+    s3_ok = cin % 32 == 0 and c1 % 32 == 0
+    ref_s = torch.full((cout * k * k * 3 * cin,), -1, dtype=torch.int16, device=dev)
+    if s3_ok:
+        assert L.vqseg_conv_pack_weights_s3_f32(w.data_ptr(), cout, cin, c1, k, k, ref_s.data_ptr(), st) == 0
+    got_f, got_t, got_s = torch.full_like(ref_f, -2), torch.full_like(ref_t, -2), torch.full_like(ref_s, -2)
+    assert L.vqseg_conv_pack_all_f32(w.data_ptr(), cout, cin, k, c1, got_f.data_ptr(), got_t.data_ptr(), got_s.data_ptr() if s3_ok else None, st) == 0
+    assert torch.equal(got_f, ref_f) and torch.equal(got_t, ref_t)
+    if s3_ok:
+        assert torch.equal(got_s, ref_s)

@@ -90,6 +90,7 @@ SYMBOLS = {
     "vqseg_im2col_f": (c_int, [c_int, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p]),
     "vqseg_reflect_fold_f": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vqseg_cast_f": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p]),
+    "vqseg_conv_pack_all_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqseg_conv_packed_s2_elems": (c_size_t, [c_int, c_int, c_int]),
     "vqseg_conv_pack_weights_s2_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vqseg_conv2d_dgrad_s2_f": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),

@@ -56,6 +56,8 @@ hipError_t launch_wgrad_reduce(const float* partial, int slabs, int Cout, int Ci
 size_t packed_elems(int Cout, int Cin, int KH, int KW, int transpose_flip);
 hipError_t launch_pack_weights(const float* w, int Cout, int Cin, int KH, int KW, int transpose_flip, unsigned short* hi,
                                unsigned short* lo, hipStream_t st);
+hipError_t launch_pack_all(const float* w, int Cout, int Cin, int K, int C1, unsigned short* fwd, unsigned short* tr, unsigned short* s3,
+                           hipStream_t st);
 hipError_t launch_pack_weights_s2(const float* w, int Cout, int Cin, int K, unsigned short* hi, unsigned short* lo, hipStream_t st);
 hipError_t launch_dgrad_s2(const void* gy, const unsigned short* w_hi, const unsigned short* w_lo, void* gx, int N, int Ho, int Wo,
                            int Cout, int Cin, int K, int OH, int OW, int precise, hipStream_t st);

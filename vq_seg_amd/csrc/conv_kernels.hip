@@ -1365,6 +1365,65 @@ size_t packed_elems(int Cout, int Cin, int KH, int KW, int transpose_flip) {
     return (size_t)R * KH * KW * ((Cc + 31) / 32 * 32);
 }
 
+// All kernel-side images of one K x K (K = 1 or 3) weight in ONE launch: a workgroup transposes a 32 (co) x 32 (ci) x K^2 tile
+// through LDS (the fp32 weight is read once, in whole contiguous runs) and writes 64-byte runs of
+//   fwd [Cout][K][K][Cin_p]            (bf16 hi; the forward image of conv_pack_weights)
+//   tr  [Cin][K][K][Cout_p], taps flipped (the data-gradient image)
+//   s3  [Cout][K][K][3 Cin]  = [w_hi | w_hi | w_lo] per concat segment (split-3, conv_pack_weights_s3)
+// -- each optional.  Replaces three launches per layer and step (the weights change with every optimiser step).
+__global__ __launch_bounds__(256) void conv_pack_all_kernel(const float* __restrict__ w, int Cout, int Cin, int K, int C1,
+                                                            unsigned short* __restrict__ fwd, unsigned short* __restrict__ tr,
+                                                            unsigned short* __restrict__ s3) {
+    __shared__ float tile[32][32 * 9 + 1];
+    const int KK = K * K;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int Cin_p = (Cin + 31) / 32 * 32, Cout_p = (Cout + 31) / 32 * 32;
+    const int run = 32 * KK;                                // floats per co row of the tile (contiguous in w when ci0 + 32 <= Cin)
+    for (int i = threadIdx.x; i < 32 * run; i += 256) {
+        const int cr = i / run, e = i - cr * run;           // e = ci_local * KK + tap
+        const int co = co0 + cr, ci = ci0 + e / KK;
+        tile[cr][e] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci0) * KK + e] : 0.0f;
+    }
+    __syncthreads();
+    // forward / split-3 images: (co, tap) rows, 32 ci contiguous
+    for (int i = threadIdx.x; i < 32 * KK * 32; i += 256) {
+        const int cl = i & 31, rt = i >> 5;                 // ci_local, (co_local, tap)
+        const int cr = rt / KK, tap = rt - cr * KK;
+        const int co = co0 + cr, ci = ci0 + cl;
+        if (co >= Cout) continue;
+        const float v = tile[cr][cl * KK + tap];
+        const __bf16 bh = (__bf16)v;
+        const unsigned short h16 = __builtin_bit_cast(unsigned short, bh);
+        if (fwd && ci < Cin_p) fwd[((long)co * KK + tap) * Cin_p + ci] = h16;
+        if (s3 && ci < Cin) {
+            const bool second = ci >= C1;
+            const int cs = second ? Cin - C1 : C1, cloc = second ? ci - C1 : ci;
+            unsigned short* row = s3 + ((long)co * KK + tap) * 3 * Cin + (second ? 3 * C1 : 0);
+            const __bf16 bl = (__bf16)(v - (float)bh);
+            row[cloc] = h16;
+            row[cs + cloc] = h16;
+            row[2 * cs + cloc] = __builtin_bit_cast(unsigned short, bl);
+        }
+    }
+    // data-gradient image: (ci, flipped tap) rows, 32 co contiguous
+    if (tr)
+        for (int i = threadIdx.x; i < 32 * KK * 32; i += 256) {
+            const int cr = i & 31, rt = i >> 5;             // co_local, (ci_local, tap)
+            const int cl = rt / KK, tap = rt - cl * KK;
+            const int co = co0 + cr, ci = ci0 + cl;
+            if (ci >= Cin || co >= Cout_p) continue;
+            const __bf16 bh = (__bf16)tile[cr][cl * KK + tap];     // rows co >= Cout of the tile are zero
+            tr[((long)ci * KK + (KK - 1 - tap)) * Cout_p + co] = __builtin_bit_cast(unsigned short, bh);
+        }
+}
+
+hipError_t launch_pack_all(const float* w, int Cout, int Cin, int K, int C1, unsigned short* fwd, unsigned short* tr, unsigned short* s3,
+                           hipStream_t st) {
+    dim3 grid((unsigned)((Cin + 31) / 32), (unsigned)((Cout + 31) / 32));
+    hipLaunchKernelGGL(conv_pack_all_kernel, grid, dim3(256), 0, st, w, Cout, Cin, K, C1, fwd, tr, s3);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_weights_s2(const float* w, int Cout, int Cin, int K, unsigned short* hi, unsigned short* lo, hipStream_t st) {
     const long total = (long)Cin * K * K * ((Cout + 31) / 32 * 32);
     long blocks = (total + 255) / 256;

@@ -244,6 +244,14 @@ int vqseg_im2col_f(int out_bf16, const float* x, int n, int h, int w, int cin, i
     return e == hipSuccess ? 0 : hipfail(e, "im2col_stem_kernel");
 }
 
+int vqseg_conv_pack_all_f32(const float* w, int cout, int cin, int k, int c1, void* fwd, void* tr, void* s3, void* stream) {
+    if (!w || cout <= 0 || cin <= 0 || (k != 1 && k != 3) || c1 <= 0 || c1 > cin || (!fwd && !tr && !s3)) return bad("conv_pack_all: bad argument (k = 1 or 3)");
+    if (s3 && (cin % 32 || c1 % 32)) return bad("conv_pack_all: the split-3 image needs Cin and the concat split to be multiples of 32");
+    hipError_t e = vqseg::launch_pack_all(w, cout, cin, k, c1, static_cast<unsigned short*>(fwd), static_cast<unsigned short*>(tr),
+                                          static_cast<unsigned short*>(s3), static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "conv_pack_all_kernel");
+}
+
 size_t vqseg_conv_packed_s2_elems(int cout, int cin, int k) {
     if (cout <= 0 || cin <= 0 || (k != 1 && k != 3)) return 0;
     return (size_t)cin * k * k * ((cout + 31) / 32 * 32);

@@ -52,9 +52,52 @@ def act_dtype() -> torch.dtype:
     return torch.float32
 
 
+def _pack_all(weight: torch.Tensor, kind):
+    """bf16-mode images of a k x k (k = 1 or 3) conv weight -- kind "fwd", "tr" (data gradient) or ("s3", c1) -- built together
+    in ONE launch (vqseg_conv_pack_all_f32) with every other kind this weight has been asked for before (the set survives the
+    invalidation after each optimiser step, so from the second step on a layer costs one pack launch per step instead of three).
+    None: not that kind of weight (the caller packs the single image)."""
+    if weight.dim() != 4 or weight.shape[2] != weight.shape[3] or weight.shape[2] not in (1, 3) or not py_opt("py_pack_all", 1):
+        return None
+    kinds = getattr(weight, "_vq_kinds", None)
+    if kinds is None:
+        kinds = weight._vq_kinds = set()
+    if kind not in kinds:
+        if isinstance(kind, tuple) and any(isinstance(k, tuple) and k != kind for k in kinds):
+            return None                                      # a second concat split for the same weight: single-image path
+        kinds.add(kind)
+    cache = _cache_of(weight)
+    imgs = cache.get("all")
+    if imgs is None or kind not in imgs:
+        w = weight.detach()
+        w = w if w.is_contiguous() else w.contiguous()
+        cout, cin, k, _ = w.shape
+        cin_p, cout_p = (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
+        s3k = next((kk for kk in kinds if isinstance(kk, tuple)), None)
+        if s3k is not None and (cin % 32 or s3k[1] % 32):
+            return None
+        imgs = {}
+        if "fwd" in kinds:
+            imgs["fwd"] = torch.empty(cout * k * k * cin_p, dtype=torch.int16, device=w.device)
+        if "tr" in kinds:
+            imgs["tr"] = torch.empty(cin * k * k * cout_p, dtype=torch.int16, device=w.device)
+        if s3k is not None:
+            imgs[s3k] = torch.empty(cout * k * k * 3 * cin, dtype=torch.int16, device=w.device)
+        with torch.cuda.device(w.device):
+            _check(lib().vqseg_conv_pack_all_f32(_dev(w, torch.float32, "weight"), cout, cin, k, s3k[1] if s3k is not None else cin,
+                                                 _p(imgs.get("fwd")), _p(imgs.get("tr")), _p(imgs.get(s3k)) if s3k is not None else None,
+                                                 _stream()), "vqseg_conv_pack_all_f32")
+        cache["all"] = imgs
+    return imgs[kind]
+
+
 def packed_weights(weight: torch.Tensor, precise: bool, transpose_flip: bool):
     """MFMA-side image of an nn.Conv2d weight, rebuilt only when the parameter changes (_wcache: version counter, storage,
     and every optimiser step)."""
+    if not precise:
+        img = _pack_all(weight, "tr" if transpose_flip else "fwd")
+        if img is not None:
+            return img, None
     cache = _cache_of(weight)
     k = (precise, transpose_flip)
     if k not in cache:
@@ -227,6 +270,10 @@ def from_s3(x):
 
 def _s3_weights(weight: torch.Tensor, c1: int, as_1x1_cols: int = 0) -> torch.Tensor:
     """[w_hi | w_hi | w_lo] image per concat segment (vqseg_conv_pack_weights_s3_f32), cached on the Parameter."""
+    if not as_1x1_cols:
+        img = _pack_all(weight, ("s3", c1))
+        if img is not None:
+            return img
     cache = _cache_of(weight)
     k = ("s3", c1, as_1x1_cols)
     if k not in cache:
