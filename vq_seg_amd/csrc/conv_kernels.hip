@@ -1385,35 +1385,47 @@ __global__ __launch_bounds__(256) void conv_pack_all_kernel(const float* __restr
         tile[cr][e] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci0) * KK + e] : 0.0f;
     }
     __syncthreads();
-    // forward / split-3 images: (co, tap) rows, 32 ci contiguous
-    for (int i = threadIdx.x; i < 32 * KK * 32; i += 256) {
-        const int cl = i & 31, rt = i >> 5;                 // ci_local, (co_local, tap)
+    // forward / split-3 images: (co, tap) rows, 32 ci contiguous = four 16-byte stores (8 bf16) per row
+    auto pack8 = [](const float (&v)[8], u32x4& hi, u32x4* lo) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = pack2(v[2 * e], v[2 * e + 1]);
+            if (lo) (*lo)[e] = pack2(v[2 * e] - bf16_round(v[2 * e]), v[2 * e + 1] - bf16_round(v[2 * e + 1]));
+        }
+    };
+    for (int i = threadIdx.x; i < 32 * KK * 4; i += 256) {
+        const int c8 = i & 3, rt = i >> 2;                  // 8-channel chunk of the ci run, (co_local, tap)
         const int cr = rt / KK, tap = rt - cr * KK;
-        const int co = co0 + cr, ci = ci0 + cl;
-        if (co >= Cout) continue;
-        const float v = tile[cr][cl * KK + tap];
-        const __bf16 bh = (__bf16)v;
-        const unsigned short h16 = __builtin_bit_cast(unsigned short, bh);
-        if (fwd && ci < Cin_p) fwd[((long)co * KK + tap) * Cin_p + ci] = h16;
-        if (s3 && ci < Cin) {
+        const int co = co0 + cr, ci = ci0 + c8 * 8;
+        if (co >= Cout || ci >= Cin_p) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[cr][(c8 * 8 + e) * KK + tap];
+        u32x4 h4, l4;
+        pack8(v, h4, &l4);
+        if (fwd) *reinterpret_cast<u32x4*>(fwd + ((long)co * KK + tap) * Cin_p + ci) = h4;
+        if (s3 && ci < Cin) {                               // Cin % 32 == 0 here: whole chunks
             const bool second = ci >= C1;
             const int cs = second ? Cin - C1 : C1, cloc = second ? ci - C1 : ci;
             unsigned short* row = s3 + ((long)co * KK + tap) * 3 * Cin + (second ? 3 * C1 : 0);
-            const __bf16 bl = (__bf16)(v - (float)bh);
-            row[cloc] = h16;
-            row[cs + cloc] = h16;
-            row[2 * cs + cloc] = __builtin_bit_cast(unsigned short, bl);
+            *reinterpret_cast<u32x4*>(row + cloc) = h4;
+            *reinterpret_cast<u32x4*>(row + cs + cloc) = h4;
+            *reinterpret_cast<u32x4*>(row + 2 * cs + cloc) = l4;
         }
     }
     // data-gradient image: (ci, flipped tap) rows, 32 co contiguous
     if (tr)
-        for (int i = threadIdx.x; i < 32 * KK * 32; i += 256) {
-            const int cr = i & 31, rt = i >> 5;             // co_local, (ci_local, tap)
+        for (int i = threadIdx.x; i < 32 * KK * 4; i += 256) {
+            const int c8 = i & 3, rt = i >> 2;              // 8-channel chunk of the co run, (ci_local, tap)
             const int cl = rt / KK, tap = rt - cl * KK;
-            const int co = co0 + cr, ci = ci0 + cl;
+            const int ci = ci0 + cl, co = co0 + c8 * 8;
             if (ci >= Cin || co >= Cout_p) continue;
-            const __bf16 bh = (__bf16)tile[cr][cl * KK + tap];     // rows co >= Cout of the tile are zero
-            tr[((long)ci * KK + (KK - 1 - tap)) * Cout_p + co] = __builtin_bit_cast(unsigned short, bh);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[c8 * 8 + e][cl * KK + tap];     // rows co >= Cout of the tile are zero
+            u32x4 h4;
+            pack8(v, h4, nullptr);
+            *reinterpret_cast<u32x4*>(tr + ((long)ci * KK + (KK - 1 - tap)) * Cout_p + co) = h4;
         }
 }
 
