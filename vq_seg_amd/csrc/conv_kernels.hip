@@ -1371,14 +1371,15 @@ size_t packed_elems(int Cout, int Cin, int KH, int KW, int transpose_flip) {
 //   tr  [Cin][K][K][Cout_p], taps flipped (the data-gradient image)
 //   s3  [Cout][K][K][3 Cin]  = [w_hi | w_hi | w_lo] per concat segment (split-3, conv_pack_weights_s3)
 // -- each optional.  Replaces three launches per layer and step (the weights change with every optimiser step).
-__global__ __launch_bounds__(256) void conv_pack_all_kernel(const float* __restrict__ w, int Cout, int Cin, int K, int C1,
+template <int K>                                             // compile-time tap count: the index arithmetic is divisions by K * K
+__global__ __launch_bounds__(256) void conv_pack_all_kernel(const float* __restrict__ w, int Cout, int Cin, int C1,
                                                             unsigned short* __restrict__ fwd, unsigned short* __restrict__ tr,
                                                             unsigned short* __restrict__ s3) {
-    __shared__ float tile[32][32 * 9 + 1];
-    const int KK = K * K;
+    constexpr int KK = K * K;
+    __shared__ float tile[32][32 * KK + 1];
     const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
     const int Cin_p = (Cin + 31) / 32 * 32, Cout_p = (Cout + 31) / 32 * 32;
-    const int run = 32 * KK;                                // floats per co row of the tile (contiguous in w when ci0 + 32 <= Cin)
+    constexpr int run = 32 * KK;                            // floats per co row of the tile (contiguous in w when ci0 + 32 <= Cin)
     for (int i = threadIdx.x; i < 32 * run; i += 256) {
         const int cr = i / run, e = i - cr * run;           // e = ci_local * KK + tap
         const int co = co0 + cr, ci = ci0 + e / KK;
@@ -1432,7 +1433,8 @@ __global__ __launch_bounds__(256) void conv_pack_all_kernel(const float* __restr
 hipError_t launch_pack_all(const float* w, int Cout, int Cin, int K, int C1, unsigned short* fwd, unsigned short* tr, unsigned short* s3,
                            hipStream_t st) {
     dim3 grid((unsigned)((Cin + 31) / 32), (unsigned)((Cout + 31) / 32));
-    hipLaunchKernelGGL(conv_pack_all_kernel, grid, dim3(256), 0, st, w, Cout, Cin, K, C1, fwd, tr, s3);
+    if (K == 3) hipLaunchKernelGGL(conv_pack_all_kernel<3>, grid, dim3(256), 0, st, w, Cout, Cin, C1, fwd, tr, s3);
+    else hipLaunchKernelGGL(conv_pack_all_kernel<1>, grid, dim3(256), 0, st, w, Cout, Cin, C1, fwd, tr, s3);
     return hipGetLastError();
 }
 
