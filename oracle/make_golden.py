@@ -355,9 +355,11 @@ PROBE_KEYS = ["segmentation_head.weight", "encoder.conv1.weight", "decoder.block
               "encoder.layer1.0.bn1.weight", "decoder.blocks.2.0.1.bias"]
 
 
-def gen_models(ref):
-    x, gt, scores = model_inputs()
+def gen_models(ref, size=64, suffix="", versions=(1, 2)):
+    x, gt, scores = model_inputs(s=size)
     for version, name, margin, scale in ((1, "vqreptunet1x1", 0.0, 1.0), (2, "vqreptunet1x1v2", 0.5, 30.0)):
+        if version not in versions:
+            continue
         torch.manual_seed(0)
         model = ref.networks.make_model(model_cfg(ref, name, margin=margin, scale=scale))
         shapes = synth.shapes_of(model.state_dict())
@@ -402,14 +404,20 @@ def gen_models(ref):
         for key in ("encoder.bn1.running_mean", "encoder.bn1.running_var", "encoder.layer4.2.bn3.running_var",
                     "decoder.blocks.4.1.1.running_mean", "decoder.blocks.0.0.1.running_var"):
             out["post/" + key] = post[key]
-        meta = dict(version=version, name=name, margin=margin, scale=scale, model_seed=MODEL_SEED,
+        meta = dict(version=version, name=name, margin=margin, scale=scale, model_seed=MODEL_SEED, size=size,
                     n_keys=len(shapes), n_params=int(sum(p.numel() for p in model.parameters())),
                     key_shapes_digest=hash_shapes(shapes), percent=80.0, th=0.7, loss_scale=2.0, proto_scale=5.0,
                     source="models/networks/modified_vqunet/net.py:1141-1222 / :184-260 on a torchvision-like ResNet base")
-        save(f"model_v{version}", meta, **out)
-        if version == 1:
+        save(f"model_v{version}{suffix}", meta, **out)
+        if version == 1 and not suffix:
             with open(os.path.join(OUT, "state_dict_layout_vqreptunet1x1.json"), "w") as f:
                 json.dump({k: list(v) for k, v in shapes.items()}, f)
+
+
+def gen_models128(ref):
+    """The v1 model at 128^2: 32 samples per channel at the deepest level (64^2 has 8), which is what lets the GPU test hold
+    the whole-model gradients to a tighter bar (train-mode BatchNorm over a handful of samples amplifies rounding)."""
+    gen_models(ref, size=128, suffix="_128", versions=(1,))
 
 
 def gen_unet(ref):
@@ -507,9 +515,9 @@ def hash_shapes(shapes):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_harness.ref_modules()
-    which = set(sys.argv[1:]) or {"vq", "kmeans", "decoder", "proto", "losses", "models", "unet", "cps", "curve", "block"}
+    which = set(sys.argv[1:]) or {"vq", "kmeans", "decoder", "proto", "losses", "models", "models128", "unet", "cps", "curve", "block"}
     for tag, fn in (("vq", gen_vq), ("kmeans", gen_kmeans), ("decoder", gen_decoder), ("proto", gen_proto),
-                    ("losses", gen_losses), ("models", gen_models), ("unet", gen_unet), ("cps", gen_cps), ("curve", gen_curve), ("block", gen_decoder_block)):
+                    ("losses", gen_losses), ("models", gen_models), ("models128", gen_models128), ("unet", gen_unet), ("cps", gen_cps), ("curve", gen_curve), ("block", gen_decoder_block)):
         if tag in which:
             print(f"[{tag}]")
             fn(ref)

@@ -41,7 +41,7 @@ def grad_close(a, b, l2tol, maxtol, what=""):
     assert l2 <= l2tol and mx <= maxtol, f"{what}: rel L2 err {l2:.3e} (tol {l2tol:g}), max err {mx:.3e} of scale (tol {maxtol:g})"
 
 
-def build(name, margin, scale, seed):
+def build(name, margin, scale, seed, size=64):
     from vq_seg_amd.models.networks import make_model
     cfg = {"name": name, "params": {"encoder_name": "resnet50", "num_classes": 3, "depth": 5,
                                     "vq_cfg": {"num_embeddings": [0, 0, 512, 512, 512], "distance": "euclidean",
@@ -52,18 +52,27 @@ def build(name, margin, scale, seed):
     model.load_state_dict(sd)
     model.prototype_loss.initted = True
     model = model.to(dev())
-    x, gt, _ = cases.model_inputs()
+    x, gt, _ = cases.model_inputs(s=size)
     version = 1 if name == "vqreptunet1x1" else 2
     cases.prepare_module_model(model, x.to(dev()), gt.to(dev()), version,
                                to_input=lambda t: t.contiguous(memory_format=torch.channels_last))
     return model
 
 
-@pytest.mark.parametrize("version", [1, 2])
-def test_whole_model_matches_reference_golden(version):
-    fx = golden_io.load(f"model_v{version}")
-    model = build(fx.meta["name"], fx.meta["margin"], fx.meta["scale"], fx.meta["model_seed"])
-    x, gt, scores = cases.model_inputs()
+# Gradient bars (relative L2, max of scale) per fixture.  Measured on MI355X: 64^2 1.7e-2 / 6.6e-2, 128^2 2.1e-2 / 3.7e-2.  The
+# 128^2 fixture (32 samples per channel at the deepest level instead of 8) was added to test whether the small BatchNorm sample
+# count explains the 64^2 error: it does not -- the CPU oracle ITSELF moves these gradients by 3e-3..4.5e-3 of scale under a
+# 1e-6 input perturbation at BOTH sizes (tests/diagnostics/conditioning.py 64|128 1e-6: ReLU masks flipping through 53 convolutions),
+# i.e. an amplification of ~3000x, and the fp32-precise kernels differ from ATen's CPU fp32 by ~5e-6 per layer.
+GRAD_TOL = {"model_v1": (3e-2, 0.10), "model_v2": (3e-2, 0.10), "model_v1_128": (3e-2, 0.06)}
+
+
+@pytest.mark.parametrize("fixture", ["model_v1", "model_v2", "model_v1_128"])
+def test_whole_model_matches_reference_golden(fixture):
+    fx = golden_io.load(fixture)
+    version, size = fx.meta["version"], fx.meta.get("size", 64)
+    model = build(fx.meta["name"], fx.meta["margin"], fx.meta["scale"], fx.meta["model_seed"], size)
+    x, gt, scores = cases.model_inputs(s=size)
     x, gt, scores = x.to(dev()), gt.to(dev()), scores.to(dev())
     model.eval()
     with torch.no_grad():
@@ -90,12 +99,17 @@ def test_whole_model_matches_reference_golden(version):
     total.backward()
     named = dict(model.named_parameters())
     # Tolerance: a 1e-6 perturbation of the INPUT moves these gradients by up to 5e-3 of their scale on the CPU
-    # oracle itself (53 convs + train-mode BN over as few as 8 samples at the 2x2 levels; tests/diagnostics/conditioning.py), and
-    # a change of the last float bit of the BatchNorm statistics (a different but equally exact merge order) moves
-    # them by 1e-2.  Cross-device agreement is therefore asserted at 5e-2 (L2) here; the per-operator gradient
-    # checks in test_nn_gpu.py carry the tight bar (2e-4 of scale in fp32).
+    # oracle itself (tests/diagnostics/conditioning.py), and a change of the last float bit of the BatchNorm statistics
+    # (a different but equally exact merge order) moves them by 1e-2.  Cross-device agreement is therefore asserted at
+    # GRAD_TOL here; the per-operator gradient checks in test_nn_gpu.py carry the tight bar (2e-4 of scale in fp32).
+    worst = [0.0, 0.0]
     for key in [k[5:] for k in fx if k.startswith("grad/")]:
-        grad_close(golden_io.probe(named[key].grad), fx["grad/" + key], 5e-2, 0.15, "grad " + key)
+        a, b = golden_io.probe(named[key].grad).double().cpu(), torch.as_tensor(fx["grad/" + key]).double()
+        worst[0] = max(worst[0], ((a - b).norm() / (b.norm() + 1e-30)).item())
+        worst[1] = max(worst[1], ((a - b).abs().max() / (b.abs().max() + 1e-30)).item())
+    print(f"{fixture}: worst gradient error rel-L2 {worst[0]:.3e}, max-of-scale {worst[1]:.3e}")
+    for key in [k[5:] for k in fx if k.startswith("grad/")]:
+        grad_close(golden_io.probe(named[key].grad), fx["grad/" + key], *GRAD_TOL[fixture], "grad " + key)
     for i in (2, 3, 4):
         assert named[f"codebook.{i}.codebook.embedding.weight"].grad is None
     post = model.state_dict()
