@@ -756,6 +756,9 @@ static void launch_glds_t(const ConvArgs& a, hipStream_t st) {
 //   of the current chunk) + a ring of NBW weight stages; counted vmcnt, one raw barrier per tap.
 // Rows are unpadded 128 B with the 16-byte chunks XOR-swizzled through the DMA source address.
 // =====================================================================================================
+#ifndef PATCH_ABL
+#define PATCH_ABL 0               // debug builds only (results wrong): 1 no weight DMA after the prologue, 2 no patch DMA after chunk 0,
+#endif                            // 4 no per-tap barrier, 8 no per-tap vmcnt wait  (tools/ab_conv.py with VQSEG_LIB: DESIGN 4.2, "what bounds it")
 #ifndef CONV_SETPRIO
 #define CONV_SETPRIO 0            // 1: s_setprio pair around every MFMA cluster of the patch kernel (measured: see DESIGN 4.2)
 #endif
@@ -972,17 +975,17 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
                     if (tt < PI && tc + 1 < n_chunks) young += 1;
                 }
             }
-            switch (young) {
+            if (!(PATCH_ABL & 9)) switch (young) {
 #define VM_CASE(N_) case N_: __builtin_amdgcn_s_waitcnt(((N_) & 0xF) | 0x0F70); break;
                 VM_CASE(1) VM_CASE(2) VM_CASE(3) VM_CASE(4) VM_CASE(5) VM_CASE(6) VM_CASE(7) VM_CASE(8) VM_CASE(9) VM_CASE(10)
 #undef VM_CASE
                 default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
             }
-            __builtin_amdgcn_s_barrier();
+            if (!(PATCH_ABL & 4)) __builtin_amdgcn_s_barrier();
             auto issue_next = [&]() {
-                if (tap < PI && more) issue_patch(chunk + 1, tap);
+                if (tap < PI && more && !(PATCH_ABL & 2)) issue_patch(chunk + 1, tap);
                 const int s2 = s + NBW - 1;
-                if (s2 < n_stage) {
+                if (s2 < n_stage && !(PATCH_ABL & 1)) {
                     const int c2 = tap + NBW - 1 >= 9 ? chunk + 1 : chunk, t2 = tap + NBW - 1 >= 9 ? tap + NBW - 1 - 9 : tap + NBW - 1;
                     int ws2 = wslot + NBW - 1;
                     if (ws2 >= NBW) ws2 -= NBW;
