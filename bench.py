@@ -137,7 +137,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # VQSEG_DIST_SINGLE=1 (with the rendezvous variables set, e.g. under torch.distributed.run --nproc-per-node 1): a ONE-rank RCCL
+    # process group and the whole N > 1 code path on top of it (vq_seg_amd.dist.collectives_on) -- what a one-GPU box can
+    # exercise of the RCCL path: communicator initialisation, ReduceOp.AVG, async handles, stream ordering.
+    multi = world > 1 or os.environ.get("VQSEG_DIST_SINGLE") == "1"      # a process group exists: barriers / reductions run
+    if multi:
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -167,7 +171,7 @@ def main():
         one(i)
         torch.cuda.synchronize()
         note(f"warm-up step {i + 1}/{args.warmup} done")
-    if world > 1:
+    if multi:
         dist.barrier()
     if rank == 0:
         _hip.profile_begin(64 * args.steps)
@@ -176,11 +180,11 @@ def main():
     for i in range(args.steps):
         out = one(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     loss = float(out["loss"])
@@ -211,16 +215,16 @@ def main():
     if not args.no_extras:
         trainer.supervised_step(l_in, l_tg)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         ts = time.perf_counter()
         for _ in range(3):
             trainer.supervised_step(l_in, l_tg)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         tsup = torch.tensor([(time.perf_counter() - ts) / 3], device=device, dtype=torch.float64)
-        if world > 1:
+        if multi:
             dist.all_reduce(tsup, op=dist.ReduceOp.MAX)
         sup_s = float(tsup.item())
 
@@ -231,16 +235,16 @@ def main():
         trainer.cfg.eval_amp = True
         one(0)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         ta = time.perf_counter()
         for i in range(args.steps):
             one(i)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         tt = torch.tensor([time.perf_counter() - ta], device=device, dtype=torch.float64)
-        if world > 1:
+        if multi:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         all_bf16_s = float(tt.item())
         trainer.cfg.eval_amp = False
@@ -260,7 +264,7 @@ def main():
         torch.cuda.synchronize()
         conv_recs = _hip.conv_profile_collect(4096)
         trainer._two_streams = was_two
-    if world > 1:
+    if multi:
         dist.barrier()
 
     if rank == 0:
@@ -295,6 +299,8 @@ def main():
                                    "v1 recipe: 6 forwards + 4 backwards + 2 Adam steps) on 512x512x3 images",
                        "images_per_step_per_gpu": 2 * args.batch, "labelled_per_gpu": args.batch,
                        "unlabelled_per_gpu": args.batch, "parallelism": f"dp{world}",
+                       "collectives": ("none (one process)" if not multi else "gloo rehearsal, every rank on cuda:0 (timings meaningless)" if rehearsal
+                                       else "RCCL" + (" (one-rank drive of the N > 1 code path, VQSEG_DIST_SINGLE)" if world == 1 else "")),
                        "vq_dtype": "f32 (exact fp32 MFMA, bit-exact argmin)", "conv_dtype": args.dtype,
                        "precision_per_forward": {
                            "4 training forwards + 4 backwards": args.dtype + (" (under autocast, like the reference's AMP region; its fp16 -> bf16)" if args.dtype == "bf16" else ""),
@@ -348,7 +354,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -39,6 +39,7 @@ class GradBuckets:
     def __init__(self, params: List[nn.Parameter], bucket_mb: float = 64.0):
         self.params = [p for p in params if p.requires_grad]
         self.world = vdist.world_size()
+        self.on = vdist.collectives_on()                   # world > 1, or the single-rank RCCL drive (VQSEG_DIST_SINGLE)
         cap = int(bucket_mb * (1 << 20) / 4)
         self.buckets: List[torch.Tensor] = []
         self.owner: Dict[int, int] = {}
@@ -71,13 +72,13 @@ class GradBuckets:
         self._names = {}
         self.launched_in_backward = []                     # per step: which buckets were reduced from inside backward (tests)
         # RCCL has an averaging reduction; gloo (CPU tests, rehearsal) does not: sum, then scale
-        self._avg = dist.ReduceOp.AVG if (self.world > 1 and dist.get_backend() == "nccl") else None
+        self._avg = dist.ReduceOp.AVG if (self.on and dist.get_backend() == "nccl") else None
         self.producer_streams = []          # set by CPSTrainer: the side stream(s) the gradient kernels of these params run on
         for p in self.params:
             # the HIP weight-gradient kernels add straight into the bucket views (nnf grad sinks) and report here;
             # parameters whose gradient still comes from autograd (VQ-free torch ops) report through the hook
-            p._vq_grad_sink = self._on_grad if self.world > 1 else None
-            if self.world > 1:
+            p._vq_grad_sink = self._on_grad if self.on else None
+            if self.on:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
     def zero(self):
@@ -125,7 +126,7 @@ class GradBuckets:
     def finish(self):
         """Call after backward: reduce what is left (parameters without a gradient this step keep
         their bucket from completing), wait, average."""
-        if self.world == 1:
+        if not self.on:
             return
         self.launched_in_backward = list(self._launched)
         if self._silent is None:
@@ -239,7 +240,7 @@ class CPSTrainer:
             for m in self.models:
                 init_weight([m.decoder, m.segmentation_head], nn.init.kaiming_normal_, nn.BatchNorm2d, cfg.bn_eps,
                             cfg.bn_momentum, mode="fan_in", nonlinearity="relu")
-        if vdist.world_size() > 1:
+        if vdist.collectives_on():
             for m in self.models:
                 for t in list(m.parameters()) + list(m.buffers()):
                     dist.broadcast(t.data, src=0)
@@ -419,7 +420,7 @@ class CPSTrainer:
         """Data parallel: BatchNorm running statistics are per-rank (each rank normalises with its own batch statistics -- the
         reference's single-device semantics per rank; parameters and codebooks ARE identical on all ranks).  This broadcasts
         rank 0's buffers so that every rank holds the state a checkpoint written by rank 0 contains."""
-        if vdist.world_size() > 1:
+        if vdist.collectives_on():
             for m in self.models:
                 for b in m.buffers():
                     dist.broadcast(b.data, src=0)

@@ -20,7 +20,7 @@ from torch import nn
 
 from .. import _hip
 from .._wcache import cache_of as _cache_of, invalidate as _invalidate
-from ..dist import world_size as _world_size, broadcast0 as _broadcast0, all_reduce_sum as _all_reduce_sum
+from ..dist import collectives_on as _collectives_on, broadcast0 as _broadcast0, all_reduce_sum as _all_reduce_sum
 
 
 class _VQFunction(torch.autograd.Function):
@@ -155,7 +155,7 @@ def kmeans(rows: torch.Tensor, num_clusters: int, num_iters: int, init_means: to
     than one rank, every rank ends with the same means: rank 0's initial draw is broadcast
     and the per-iteration cluster sums / counts are all-reduced over RCCL."""
     means = (kmeans_init_means(rows, num_clusters) if init_means is None else init_means.clone()).contiguous()
-    if _world_size() == 1:
+    if not _collectives_on():
         return _hip.kmeans(rows, means, num_iters)
     _broadcast0(means)
     counts = torch.zeros(num_clusters, dtype=torch.int64, device=rows.device)
@@ -212,7 +212,7 @@ class EuclideanCodebook(nn.Module):
     def ema_step(self, rows: torch.Tensor, idx: torch.Tensor):
         """Extension: one EMA update from the rows (N, C) of this forward and their code indices."""
         sums, counts = _hip.vq_code_sums(rows, idx.reshape(-1), self.num_embeddings)
-        if _world_size() > 1:                                # every rank applies the same update to the same state
+        if _collectives_on():                                # every rank applies the same update to the same state
             _all_reduce_sum(sums)
             _all_reduce_sum(counts)
         _hip.vq_ema_update(self.cluster_size, self.embed_avg, self.embedding.weight.detach(), sums, counts, self.decay, self.eps)
