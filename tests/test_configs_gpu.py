@@ -138,3 +138,42 @@ def test_decoder_block_at_bench_scale_matches_reference(mode):
     post = blk.state_dict()
     for name, key in (("run_mean0", "0.1.running_mean"), ("run_var0", "0.1.running_var"), ("run_var1", "1.1.running_var")):
         assert torch.allclose(post[key].cpu(), fx[name], rtol=2e-2 if amp else 1e-4, atol=1e-3 if amp else 1e-6), name
+
+
+def test_shipped_config_size_448_matches_oracle_and_trains():
+    """The reference's SHIPPED configs resize to 448 x 448 at batch 4 (config/vqreptunet1x1.json:10,34; 512 / 64 are BASELINE's
+    choices): feature maps of 224 / 112 / 56 / 28 / 14 pixels, so the deep levels are NOT multiples of the 3x3 kernels' 16- and
+    32-pixel tiles and take the generic implicit-GEMM kernels.  (1) eval forward in fp32 against the CPU oracle on the same state
+    (logits 1e-3 of scale -- north_star --, code indices of the three levels equal, dead-code percentages equal);
+    (2) two bf16 CPSTrainer steps at the shipped batch size, every term finite."""
+    from oracle import torch_ref as R
+    from tests.test_model_gpu import build, rel_close
+    from vq_seg_amd.trainer import CPSConfig, CPSTrainer, SyntheticCropWeed
+    size = 448
+    model = build("vqreptunet1x1", 0.0, 1.0, 77, size=size)           # synthetic state + the calibration recipe of the fixtures
+    x, _gt, _ = cases.model_inputs(s=size)
+    model.eval()
+    with torch.no_grad():
+        logits, closs, usage, proto = model(x.to(dev()))
+        feats = model.encoder(x.to(dev()).contiguous(memory_format=torch.channels_last))[1:]
+        idx = [model.codebook[lvl](feats[lvl])[1].cpu() for lvl in (2, 3, 4)]
+    assert [tuple(f.shape[-2:]) for f in feats] == [(224, 224), (112, 112), (56, 56), (28, 28), (14, 14)]
+    sd = {k: v.detach().float().cpu() if v.is_floating_point() else v.cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref_logits, _closs, ref_usage, _proto, aux = R.vq_unet_forward(sd, x, False, (0, 0, 512, 512, 512), version=1)
+    rel_close(logits, ref_logits, 1e-3, "eval logits at 448^2")
+    for got, want, lvl in zip(idx, aux["indices"], (2, 3, 4)):
+        assert torch.equal(got, want), f"level {lvl}: code indices differ from the oracle's"
+    assert torch.allclose(usage.double(), torch.stack([u.double() for u in ref_usage]).cpu(), rtol=1e-6)
+
+    cfg = {"name": "vqreptunet1x1", "params": {"encoder_name": "resnet50", "num_classes": 3, "depth": 5,
+                                               "vq_cfg": {"num_embeddings": [0, 0, 512, 512, 512], "distance": "euclidean", "kmeans_init": True},
+                                               "margin": 0.0, "scale": 1.0, "use_feature": False, "encoder_weights": None}}
+    torch.manual_seed(0)
+    tr = CPSTrainer(CPSConfig(model=cfg, recipe="v1", total_iters=10, amp_dtype=torch.bfloat16), dev())
+    data = SyntheticCropWeed(size, 4, dev(), seed=11)
+    (l_in, l_tg), ul_in = data.labelled(), data.unlabelled()
+    for _ in range(2):
+        out = tr.step(l_in, l_tg, ul_in)
+        for key, v in out.items():
+            assert torch.isfinite(torch.as_tensor(v)).all(), key
