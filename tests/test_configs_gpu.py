@@ -177,3 +177,35 @@ def test_shipped_config_size_448_matches_oracle_and_trains():
         out = tr.step(l_in, l_tg, ul_in)
         for key, v in out.items():
             assert torch.isfinite(torch.as_tensor(v)).all(), key
+
+
+@pytest.mark.parametrize("h,w", [(200, 328), (96, 160)])
+def test_ragged_non_square_sizes_match_oracle(h, w):
+    """Sizes the tile geometry of no kernel divides (feature maps 100x164 / 50x82 / 25x41 / 13x21 / 7x11 for 200 x 328: odd extents
+    from the stem's and the stride-2 bottlenecks' rounding, non-square, the decoder's bilinear resize to a skip of a different aspect):
+    eval AND train-mode forward against the CPU oracle on the same state -- logits 1e-3 of scale, commitment loss, code indices."""
+    from oracle import torch_ref as R
+    from tests.test_model_gpu import build, close, rel_close
+    x = synth.uniform(7100 + h, (2, 3, h, w))
+    gt = synth.blob_labels(7101 + h, 2, max(h, w), cell=8)[:, :h, :w].contiguous()
+    model = build("vqreptunet1x1", 0.0, 1.0, 77, inputs=(x, gt))
+    sd = {k: v.detach().float().cpu() if v.is_floating_point() else v.cpu() for k, v in model.state_dict().items()}
+    ks = (0, 0, 512, 512, 512)
+    model.eval()
+    with torch.no_grad():
+        logits = model(x.to(dev()))[0]
+        feats = model.encoder(x.to(dev()).contiguous(memory_format=torch.channels_last))[1:]
+        idx = [model.codebook[lvl](feats[lvl])[1].cpu() for lvl in (2, 3, 4)]
+        ref_logits, _c, _u, _p, aux = R.vq_unet_forward(sd, x, False, ks, version=1)
+    assert logits.shape == (2, 3, h, w)
+    rel_close(logits, ref_logits, 1e-3, f"eval logits at {h}x{w}")
+    for got, want, lvl in zip(idx, aux["indices"], (2, 3, 4)):
+        assert torch.equal(got, want), f"level {lvl}: code indices differ from the oracle's"
+    model.train()
+    with torch.no_grad():
+        logits, closs, usage, proto = model(x.to(dev()), gt.to(dev()), percent=80.0)
+        p = {k: v.clone() for k, v in sd.items()}
+        ref = R.vq_unet_forward(p, x, True, ks, gt=gt, version=1, percent=80.0)
+    rel_close(logits, ref[0], 1e-3, f"train logits at {h}x{w}")
+    close(closs, ref[1], rtol=1e-4, what="commitment")
+    close(proto, ref[3], rtol=1e-4, what="prototype loss")

@@ -41,7 +41,7 @@ def grad_close(a, b, l2tol, maxtol, what=""):
     assert l2 <= l2tol and mx <= maxtol, f"{what}: rel L2 err {l2:.3e} (tol {l2tol:g}), max err {mx:.3e} of scale (tol {maxtol:g})"
 
 
-def build(name, margin, scale, seed, size=64):
+def build(name, margin, scale, seed, size=64, inputs=None):
     from vq_seg_amd.models.networks import make_model
     cfg = {"name": name, "params": {"encoder_name": "resnet50", "num_classes": 3, "depth": 5,
                                     "vq_cfg": {"num_embeddings": [0, 0, 512, 512, 512], "distance": "euclidean",
@@ -52,7 +52,7 @@ def build(name, margin, scale, seed, size=64):
     model.load_state_dict(sd)
     model.prototype_loss.initted = True
     model = model.to(dev())
-    x, gt, _ = cases.model_inputs(s=size)
+    x, gt = inputs if inputs is not None else cases.model_inputs(s=size)[:2]
     version = 1 if name == "vqreptunet1x1" else 2
     cases.prepare_module_model(model, x.to(dev()), gt.to(dev()), version,
                                to_input=lambda t: t.contiguous(memory_format=torch.channels_last))
