@@ -341,11 +341,14 @@ def main():
                 "frac": round(k3["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                 "traffic_source": "profiles/r01_conv_patch_pmc.md (PMC passes of the patch kernel)",
                 "by_kind": {"3x3 bf16": k3, "1x1 bf16": rate(lambda kd: kd == 100), "3x3 split-3 (fp32-precision eval)": rate(lambda kd: kd == 302),
-                            "1x1 split-3": rate(lambda kd: kd == 102), "precise (fp32 activations)": rate(lambda kd: kd % 100 == 1)},
-                "whole_step_delivered_tflops": round(sum(f for f, _k, _m in conv_recs) / 2 / (elapsed / args.steps) / 1e12, 1),
+                            "1x1 split-3": rate(lambda kd: kd == 102), "precise (fp32 activations)": rate(lambda kd: kd % 100 == 1),
+                            "3x3 weight gradient bf16": rate(lambda kd: kd == 350), "1x1 weight gradient bf16": rate(lambda kd: kd == 150),
+                            "7x7 stem weight gradient": rate(lambda kd: kd // 100 == 7 and kd % 100 >= 50)},
+                "whole_step_delivered_tflops": round(sum(f for f, kd, _m in conv_recs if kd % 100 < 50) / 2 / (elapsed / args.steps) / 1e12, 1),
                 "note": "algorithmic flops 2*KH*KW*Cin*Cout*pixels per launch / in-stream HIP-event time, two extra steps after the timed "
                         "region with both networks on ONE stream (kernels alone on the chip); split-3 launches are counted at the LOGICAL "
-                        "convolution's flops (they execute 3x that on the MFMA pipes); weight-gradient kernels are not in this object; "
+                        "convolution's flops (they execute 3x that on the MFMA pipes); weight-gradient kernels are listed by_kind (kernel only, the slab "
+                        "sums that follow are separate launches) and not part of achieved / whole_step_delivered; "
                         "whole_step_delivered = all convolution forward/data-gradient flops of a step / the headline's step time"}
         if all_bf16_s is not None:
             line["all_bf16_step"] = {"images_per_sec": round(images / all_bf16_s, 3), "ms_per_step": round(all_bf16_s / args.steps * 1e3, 3),

@@ -25,4 +25,4 @@ for fl, kd, ms, sh in recs:
 tot = sum(v[2] for v in agg.values())
 print(f"{len(recs)} launches, {tot:.1f} ms")
 for (kd, sh), (n, fl, ms) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
-    print(f"k{kd // 100} {'bf16 prec s3 '.split()[kd % 100]:4s} px {sh[0]:5d}k cin {sh[1]:5d} cout {sh[2]:5d} s{sh[3] // 10} up{sh[3] % 10}  x{n:3d}  {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TF/s")
+    print(f"k{kd // 100} { {0: 'bf16', 1: 'prec', 2: 's3', 50: 'wgrad', 51: 'wgrad-prec'}[kd % 100]:5s} px {sh[0]:5d}k cin {sh[1]:5d} cout {sh[2]:5d} s{sh[3] // 10} up{sh[3] % 10}  x{n:3d}  {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TF/s")

@@ -2295,7 +2295,30 @@ int wgrad_slabs_max(const WgradArgs& a) {
     return m;
 }
 
+static hipError_t launch_wgrad_impl(const WgradArgs& a, int precise, int slabs, int* final_layout, hipStream_t st);
+
+// the convolution profile files weight-gradient launches under kind KH * 100 + 50 + precise (the slab sums that follow are separate,
+// unrecorded launches); flops = 2 * taps * Cin * Cout * output pixels, the same count as the forward layer
 hipError_t launch_wgrad(const WgradArgs& a, int precise, int slabs, int* final_layout, hipStream_t st) {
+    const bool rec = g_cprof.enabled && g_cprof.count < g_cprof.capacity;
+    const int slot = g_cprof.count;
+    if (rec) {
+        const double px = (double)a.N * a.Ho * a.Wo;
+        g_cprof.flops[slot] = 2.0 * a.KH * a.KW * (double)a.Cin * a.Cout * px;
+        g_cprof.kind[slot] = a.KH * 100 + 50 + (precise ? 1 : 0);
+        g_cprof.shape[4 * slot + 0] = (int)(((long)a.N * a.Ho * a.Wo) >> 10);
+        g_cprof.shape[4 * slot + 1] = a.Cin;
+        g_cprof.shape[4 * slot + 2] = a.Cout;
+        g_cprof.shape[4 * slot + 3] = a.stride * 10 + 1;
+        ++g_cprof.count;
+        (void)hipEventRecord(g_cprof.ev[2 * slot], st);
+    }
+    const hipError_t e = launch_wgrad_impl(a, precise, slabs, final_layout, st);
+    if (rec) (void)hipEventRecord(g_cprof.ev[2 * slot + 1], st);
+    return e;
+}
+
+static hipError_t launch_wgrad_impl(const WgradArgs& a, int precise, int slabs, int* final_layout, hipStream_t st) {
     const Wg3Plan pl = wgrad3x3_plan(a, precise, false);
     *final_layout = pl.cot ? 1 : 0;                          // 1: slabs already are [Cout][Cin][KH][KW]
     if (pl.cot) {
