@@ -67,7 +67,8 @@ int vqseg_profile_collect(int max_records, int64_t* n_rows_host, int* channels_h
 
 /* The same for the convolution kernels (forward, data gradient, fused-epilogue and split-3 launches of vqseg_conv2d_*): per launch
  * the ALGORITHMIC flops 2 * KH * KW * Cin * Cout * output pixels (logical channels for split-3; forward-layer pixels for the
- * data gradient of a strided layer), kind = KH * 100 + {0 bf16, 1 precise, 2 split-3}, the in-stream milliseconds and the shape. */
+ * data gradient of a strided layer), kind = KH * 100 + {0 bf16, 1 precise, 2 split-3; 50 / 51: the weight-gradient kernel of
+ * vqseg_conv2d_wgrad_f in bf16 / precise mode, without its slab sum}, the in-stream milliseconds and the shape. */
 int vqseg_conv_profile_begin(int capacity);
 int vqseg_conv_profile_collect(int max_records, double* flops_host, int* kind_host, float* ms_host,
                                int* shape_host /* optional [4] per record: output pixels / 1024, Cin, Cout, stride * 10 + up */);
