@@ -253,16 +253,20 @@ def main():
     # stream (with two streams a launch's in-stream time would include the other network's kernels sharing the chip).  Outside
     # the timed region: ~700 event pairs per step would perturb the headline.
     conv_recs = []
-    if rank == 0 and not args.no_extras:
+    if not args.no_extras:
+        # EVERY rank runs these steps (they hold the gradient all-reduces: a rank that skipped them would leave the others
+        # waiting in a collective); rank 0 alone brackets its launches with events
         was_two = trainer._two_streams
         trainer._two_streams = False
         one(0)
         torch.cuda.synchronize()
-        _hip.conv_profile_begin(4096)
+        if rank == 0:
+            _hip.conv_profile_begin(4096)
         for i in range(2):
             one(i)
         torch.cuda.synchronize()
-        conv_recs = _hip.conv_profile_collect(4096)
+        if rank == 0:
+            conv_recs = _hip.conv_profile_collect(4096)
         trainer._two_streams = was_two
     if multi:
         dist.barrier()

@@ -68,3 +68,21 @@ def test_cps_trainer_on_a_one_rank_rccl_group_equals_the_plain_run():
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run([sys.executable, "-c", JOB], env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "RCCL_SINGLE_OK" in res.stdout, res.stdout[-2000:] + "\n" + res.stderr[-4000:]
+
+
+def test_bench_two_rank_rehearsal_with_extras_completes():
+    """`bench.py` exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), here as the gloo rehearsal
+    with both ranks on cuda:0: the timed region AND the extra legs after it (supervised step, all-bf16 step, the event-bracketed
+    roofline_conv steps) hold gradient all-reduces, so every rank has to run every one of them -- a leg run by rank 0 alone leaves the
+    job hanging in a collective (it did, before round 2).  The rehearsal also asserts bit-identical parameters on both ranks."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VQSEG_DIST_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "1"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-4000:]
+    import json
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and "rehearsal" in line["config"]["collectives"]
+    assert line["roofline_conv"]["by_kind"]["3x3 bf16"]["launches_per_step"] > 0 and line["all_bf16_step"]["images_per_sec"] > 0
+    assert "identical on all 2 ranks" in res.stderr
