@@ -1,6 +1,6 @@
 """Child process of tests/test_compat_gpu.py: the reference trainer's situation on the GPU box.
 
-    python tests/compat_driver.py <repo>/compat <out.npz> iter_v1|iter_v2|curve
+    python tests/compat_driver.py <repo>/compat <out.npz> iter_v1|iter_v2|curve|curve_bf16|train_main
 
 sys.path gets `<repo>/compat` (the maintainer's one line) and -- for the restated loop body only, which lives under tests/ --
 the repository root.  Models, losses, metrics and the schedule are reached through the reference's TOP-LEVEL names
@@ -50,6 +50,8 @@ if what in ("iter_v1", "iter_v2"):
                 arrays[f"it{i}/{k}"] = v.numpy()
 elif what == "curve":
     arrays = cps_loop.run_curve(ns, dev, to_cfg=EasyDict, prepare=prepare)
+elif what == "curve_bf16":                            # the benchmarked precision: training forwards / backwards under bf16 autocast
+    arrays = cps_loop.run_curve(ns, dev, to_cfg=EasyDict, prepare=prepare, half=True, amp_dtype=torch.bfloat16)
 elif what == "train_main":
     # train() of train_vqreptunet1x1v2.py:48-218 as far as the hot path goes: datasets + loaders (:86-93), models + init_weight
     # (:70-80, random init, k-means codebook / prototype init in the first training forward), optimisers + schedule + AMP region

@@ -118,6 +118,18 @@ def test_miou_parity_run(tmp_path):
     assert np.allclose(got["sup_loss_1"][:3], fx["sup_loss_1"].numpy()[:3], rtol=1e-3)
 
 
+def test_miou_parity_run_bf16_autocast(tmp_path):
+    """The same run at the BENCHMARKED precision (training forwards / backwards under bf16 autocast, pseudo-label forwards fp32 --
+    the reference's AMP layout with its fp16 replaced by bf16) against the reference's fp32 CPU curve: the end point has to land
+    within the north_star's 0.2 mIoU points as well; on the way bf16 rounding may move a step's mIoU more than fp32 does."""
+    got, fx = drive(tmp_path, "curve_bf16"), golden_io.load("cps_curve_v1")
+    a, b = got["test_miou"], fx["test_miou"].numpy()
+    print("test mIoU  GPU bf16:", np.round(a, 5), " reference CPU fp32:", np.round(b, 5))
+    assert abs(a[0] - b[0]) <= 1e-4                                  # the first evaluation precedes any training (fp32 eval)
+    assert abs(a[-1] - b[-1]) <= 0.002, (a, b)
+    assert np.abs(a - b).max() <= 0.05, (a, b)
+
+
 def test_trainer_main_flow_on_a_synthetic_folder(tmp_path):
     """train() of train_vqreptunet1x1v2.py as far as the hot path goes -- BaseDataset folders and loaders, make_model + init_weight
     from random init (k-means codebook / prototype initialisation in the first training forward), Adam + cosine schedule, the bf16
