@@ -343,7 +343,7 @@ def main():
                 "kernel": "conv3x3_patch_kernel / conv_igemm_glds_kernel (every 3x3 bf16 launch: forward + data gradient)",
                 "bound": "mfma", "achieved": k3["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(k3["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "traffic_source": "profiles/r01_conv_patch_pmc.md (PMC passes of the patch kernel)",
+                "traffic_source": "profiles/r02_conv_patch_pmc.md (per-layer PMC passes of the patch kernel: HBM-side bytes 1.2-4.0x algorithmic, Infinity-Cache hits included; no single per-launch figure exists for an aggregate over 260 launches of 40 shapes)",
                 "by_kind": {"3x3 bf16": k3, "1x1 bf16": rate(lambda kd: kd == 100), "3x3 split-3 (fp32-precision eval)": rate(lambda kd: kd == 302),
                             "1x1 split-3": rate(lambda kd: kd == 102), "precise (fp32 activations)": rate(lambda kd: kd % 100 == 1),
                             "3x3 weight gradient bf16": rate(lambda kd: kd == 350), "1x1 weight gradient bf16": rate(lambda kd: kd == 150),
