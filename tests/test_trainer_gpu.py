@@ -103,3 +103,51 @@ def test_shared_stem_patches_change_nothing():
         finally:
             _hip.PY_OPTS.pop("py_stem_share", None)
     assert torch.equal(res[0], res[1])
+
+
+def test_checkpoint_resume_is_bit_exact(tmp_path):
+    """Checkpoint / resume: two steps, save_checkpoint (the reference's dictionary layout + `initted` flags +
+    the schedule's iteration counter), load into a DIFFERENTLY initialised trainer, two more steps == four uninterrupted steps,
+    bit for bit: parameters, BatchNorm buffers, codebooks, Adam moments; and k-means does not re-run on the loaded codebooks."""
+    from vq_seg_amd.trainer import CPSConfig, CPSTrainer, SyntheticCropWeed
+    from vq_seg_amd.utils.ckpoints import load_ckpoints
+    dev = torch.device("cuda:0")
+    model = {"name": "vqreptunet1x1", "params": {"encoder_name": "resnet50", "num_classes": 3, "depth": 5,
+                                                 "vq_cfg": {"num_embeddings": [0, 0, 32, 32, 32], "distance": "euclidean", "kmeans_init": True},
+                                                 "margin": 0.0, "scale": 1.0, "use_feature": False, "encoder_weights": None}}
+
+    def trainer(seed):
+        return CPSTrainer(CPSConfig(model=model, recipe="v1", total_iters=8, amp_dtype=torch.bfloat16, seed=seed), dev)
+    data = SyntheticCropWeed(64, 2, dev, seed=21)
+    batches = [(data.labelled(), data.unlabelled()) for _ in range(4)]
+
+    def run(tr, sel):
+        for (l_in, l_tg), ul_in in sel:
+            tr.step(l_in, l_tg, ul_in)
+
+    def state(tr):
+        torch.cuda.synchronize()
+        out = [t.detach().clone() for m in tr.models for t in m.state_dict().values()]
+        for o in tr.opts:
+            for st in o.state_dict()["state"].values():
+                out += [v.detach().clone() for v in st.values() if torch.is_tensor(v)]
+        return out
+
+    a = trainer(42)
+    run(a, batches)
+    b = trainer(42)
+    run(b, batches[:2])
+    path = str(tmp_path / "ck.pth")
+    b.save_checkpoint(path, epoch=3, batch_idx=7)
+    c = trainer(7)                                                   # other initial weights: everything must come from the file
+    assert c.load_checkpoint(path) == (3, 7) and c.iter == 2
+    assert all(m.codebook[i].codebook.initted for m in c.models for i in (2, 3, 4)) and all(m.prototype_loss.initted for m in c.models)
+    codebooks = [m.codebook[2].codebook.embedding.weight.detach().clone() for m in c.models]
+    run(c, batches[2:])
+    for m, w in zip(c.models, codebooks):
+        assert torch.equal(m.codebook[2].codebook.embedding.weight, w), "k-means re-ran over the loaded codebook"
+    sa, sc = state(a), state(c)
+    assert len(sa) == len(sc) and all(torch.equal(x, y) for x, y in zip(sa, sc)), "resumed run differs from the uninterrupted one"
+    # the file is the reference's layout: its loader returns model_2 (training) / model_1 (testing), utils/ckpoints.py:15-21
+    m2, epoch, batch_idx, o1, o2 = load_ckpoints(path, True, map_location="cpu")
+    assert (epoch, batch_idx) == (3, 7) and set(m2) == set(b.models[1].state_dict()) and "state" in o1 and "param_groups" in o2

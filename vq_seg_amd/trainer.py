@@ -25,6 +25,7 @@ from .measurement import confusion_matrix_device, miou_device
 from . import nnf
 from .models import init_weight
 from .models.networks import make_model
+from .utils.ckpoints import load_training_state, restore_initted, save_ckpoints
 from .utils.lr_schedulers import CosineAnnealingLR
 
 
@@ -431,6 +432,28 @@ class CPSTrainer:
         if sync:
             self.sync_buffers()
         return (self.models[0].state_dict(), self.models[1].state_dict(), self.opts[0].state_dict(), self.opts[1].state_dict())
+
+    def save_checkpoint(self, filepath, epoch: int = 0, batch_idx: int = 0):
+        """The reference's checkpoint dictionary (utils/ckpoints.py:7-13: model_1, model_2, epoch, batch_idx, optimizer_1,
+        optimizer_2) plus what a bit-exact resume needs and the reference does not store: the `initted` flags and
+        the iteration counter that positions the cosine schedule.  Every rank calls it (the buffer sync is a collective);
+        rank 0 writes."""
+        m1, m2, o1, o2 = self.state_dicts()
+        if vdist.rank() == 0:
+            save_ckpoints(m1, m2, epoch, batch_idx, o1, o2, filepath, models=self.models, extra={"iter": self.iter})
+
+    def load_checkpoint(self, filepath):
+        """Resume from save_checkpoint's file (or a reference-written one: then the flags and the counter stay as they are).
+        Returns (epoch, batch_idx)."""
+        state = load_training_state(filepath, map_location=self.device)
+        for m, o, i in zip(self.models, self.opts, (1, 2)):
+            m.load_state_dict(state[f"model_{i}"])
+            o.load_state_dict(state[f"optimizer_{i}"])
+            nnf.invalidate_weight_caches(m)
+        for m, flags in zip(self.models, state.get("initted") or (None, None)):
+            restore_initted(m, flags)
+        self.iter = int(state.get("iter", self.iter))
+        return state.get("epoch", 0), state.get("batch_idx", 0)
 
     def _ce_dice(self, pred, target):
         """0.5 * CE(ignore 255) + criterion (train_vqreptunet1x1v2.py:165-187); with the Dice criterion both terms come from

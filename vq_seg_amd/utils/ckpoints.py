@@ -22,13 +22,18 @@ def _initted_flags(model):
     return {name: bool(m.initted) for name, m in model.named_modules() if hasattr(m, "initted")}
 
 
-def save_ckpoints(model_1, model_2, epoch, batch_idx, optimizer_1, optimizer_2, filepath, models=None):
+def save_ckpoints(model_1, model_2, epoch, batch_idx, optimizer_1, optimizer_2, filepath, models=None, extra=None):
     """model_k / optimizer_k are state_dicts (train_vqreptunet1x1v2.py:245-259).  `models` (optional, the two nn.Modules)
-    adds their `initted` flags."""
+    adds their `initted` flags; `extra` (optional dict of plain values, e.g. the iteration counter of the LR schedule) is stored
+    beside the reference's keys."""
     blob = {"model_1": model_1, "model_2": model_2, "epoch": epoch, "batch_idx": batch_idx,
             "optimizer_1": optimizer_1, "optimizer_2": optimizer_2}
     if models is not None:
         blob["initted"] = [_initted_flags(m) for m in models]
+    for k, v in (extra or {}).items():
+        if k in blob:
+            raise KeyError(f"extra key {k!r} collides with the checkpoint layout")
+        blob[k] = v
     torch.save(blob, filepath)
 
 
