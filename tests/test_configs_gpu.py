@@ -210,3 +210,49 @@ def test_ragged_non_square_sizes_match_oracle(h, w):
     rel_close(logits, ref[0], 1e-3, f"train logits at {h}x{w}")
     close(closs, ref[1], rtol=1e-4, what="commitment")
     close(proto, ref[3], rtol=1e-4, what="prototype loss")
+
+
+def test_bf16_argmin_mismatch_rate_is_reported():
+    """SURVEY 5 (mixed precision): bf16 is a build-side speed mode whose argmin mismatch rate has to be REPORTED, not assumed zero.
+    The benchmark's network shape (K = 512, 512^2) on the calibrated synthetic state of the fixtures, codebooks = the package's own
+    10-iteration k-means on the network's fp32 eval features (every code alive: real near-tie structure).  Code indices of an eval
+    forward under bf16 autocast against the same forward in fp32 (the parity mode), per level, and the logits' distance.  The
+    mismatches are rows whose two best codes are closer than the bf16 rounding of the features moves them -- nothing the VQ kernel
+    does (its arithmetic is exact fp32 on whatever rows it is given: tests/test_vq_gpu.py)."""
+    from tests.test_model_gpu import build
+    from vq_seg_amd.vector_quantizer.vq_img import kmeans
+    size = 512
+    m = build("vqreptunet1x1", 0.0, 1.0, 77, size=size)
+    x = cases.model_inputs(s=size)[0].to(dev()).contiguous(memory_format=torch.channels_last)
+    m.eval()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        feats = m.encoder(x)[1:]
+        for lvl in (2, 3, 4):
+            f = feats[lvl].float()
+            rows = f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]).contiguous()
+            means, bins = kmeans(rows, 512, 10)
+            cb = m.codebook[lvl].codebook
+            cb.embedding.weight.data.copy_(means)
+            cb.initted = True
+        from vq_seg_amd import nnf
+        nnf.invalidate_weight_caches(m)                               # `.data` writes: drop the prepared codebooks (_wcache)
+
+    def indices_and_logits(autocast):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            feats = m.encoder(x)[1:]
+            out = [m.codebook[lvl](feats[lvl]) for lvl in (2, 3, 4)]
+            logits = m(x)[0].float()
+        return [o[1] for o in out], [float(o[3]) for o in out], logits
+    idx32, dead32, log32 = indices_and_logits(False)
+    idx16, dead16, log16 = indices_and_logits(True)
+    lines = []
+    for lvl, a, b, d in zip((2, 3, 4), idx32, idx16, dead32):
+        rate = (a != b).float().mean().item()
+        lines.append(f"level {lvl}: {a.numel()} rows, {d:.1f} % dead codes, bf16 index != fp32 index in {100 * rate:.2f} % of the rows")
+        assert rate < 0.5
+    rel = ((log16 - log32).abs().max() / log32.abs().max()).item()
+    agree = (log16.argmax(1) == log32.argmax(1)).float().mean().item()
+    lines.append(f"logits: max |bf16 - fp32| = {rel:.2e} of scale; arg-max class agrees on {100 * agree:.2f} % of the pixels")
+    print("\n".join(lines))
+    assert rel < 0.2 and agree > 0.9
