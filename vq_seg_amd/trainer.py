@@ -309,11 +309,15 @@ class CPSTrainer:
         s2.wait_stream(main)
         f1 = on(s1, m1.encode, a1[0])
         f2 = on(s2, m2.encode, a2[0])
-        s1.wait_event(s2.record_event())                                # model 2's encoder done before model 1 quantises
+        alone = nnf.py_opt("py_vq_alone", 1)                            # 0 (A/B runs): the VQ phases share the chip like everything else
+        if alone:
+            s1.wait_event(s2.record_event())                            # model 2's encoder done before model 1 quantises
         q1 = on(s1, m1.quantize, f1)
-        s2.wait_event(s1.record_event())
+        if alone:
+            s2.wait_event(s1.record_event())
         q2 = on(s2, m2.quantize, f2)
-        s1.wait_event(s2.record_event())                                # ... and model 1 stays idle meanwhile
+        if alone:
+            s1.wait_event(s2.record_event())                            # ... and model 1 stays idle meanwhile
         o1 = on(s1, m1.finish, *q1, *a1[1:], **kw)
         o2 = on(s2, m2.finish, *q2, *a2[1:], **kw)
         for t in tuple(o1) + tuple(o2):
