@@ -91,6 +91,60 @@ def cpu_baseline():
                       f"labelled + {NB} unlabelled images = 2*eval + 4*train = {dt:.1f}s per {2 * NB} images"}
 
 
+def bn_roofline(device):
+    """HBM-bound side of the step: the BatchNorm passes (apply; backward = reduce + apply) of three of the step's layer shapes, bf16,
+    operands rotated through buffer sets larger than the Infinity Cache, in-stream events -- algorithmic bytes / time against the
+    HBM peak.  Outside the timed region."""
+    from vq_seg_amd import _hip
+    L = _hip.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    tot_bytes = tot_us = 0.0
+    per = {}
+    for M, C, res in ((32 * 256 * 256, 64, 0), (32 * 128 * 128, 256, 1), (32 * 32 * 32, 1024, 1)):
+        sets = max(2, min(8, int(1.2e9 / (M * C * 2 * 3))))
+        sc, sh = torch.rand(C, device=device) + 0.5, torch.randn(C, device=device) * 0.1
+        ys = [torch.randn(M, C, device=device).bfloat16() for _ in range(sets)]
+        gs = [torch.randn(M, C, device=device).bfloat16() for _ in range(sets)]
+        rs = [torch.randn(M, C, device=device).bfloat16() for _ in range(sets)] if res else None
+        outs = [torch.empty_like(t) for t in ys]
+        mean, inv, gamma = torch.zeros(C, device=device), torch.ones(C, device=device), torch.ones(C, device=device)
+        ws = torch.empty(L.vqseg_bn_backward_workspace_floats(M, C), device=device)
+        dg, gy = torch.empty(2, C, device=device), torch.empty_like(ys[0])
+        gres = torch.empty_like(ys[0]) if res else None
+
+        def apply(i):
+            k = i % sets
+            rc = L.vqseg_bn_apply_f(1, ys[k].data_ptr(), rs[k].data_ptr() if res else None, sc.data_ptr(), sh.data_ptr(), M, C, 1, outs[k].data_ptr(), st)
+            assert rc == 0, L.vqseg_last_error()
+
+        def bwd(i):
+            k = i % sets
+            rc = L.vqseg_bn_backward_f(1, gs[k].data_ptr(), outs[k].data_ptr() if res else None, ys[k].data_ptr(), mean.data_ptr(), inv.data_ptr(),
+                                       gamma.data_ptr(), sc.data_ptr(), sh.data_ptr(), M, C, 1, 1, 0, ws.data_ptr(), dg[0].data_ptr(), dg[1].data_ptr(),
+                                       gy.data_ptr(), gres.data_ptr() if res else None, st)
+            assert rc == 0, L.vqseg_last_error()
+        for name, fn, nbytes in (("apply", apply, M * C * 2 * (3 if res else 2)), ("backward", bwd, M * C * 2 * (8 if res else 5))):
+            fn(0)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(8):
+                fn(i + 1)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 8 * 1e3
+            tot_bytes += nbytes
+            tot_us += us
+            per[f"{name} M{M}xC{C}{'+res' if res else ''}"] = {"us": round(us, 1), "GBps": round(nbytes / us / 1e3, 1)}
+        del ys, gs, rs, outs, gy, gres
+    achieved = tot_bytes / tot_us / 1e3
+    return {"kernel": "bn_apply_kernel / bn_bwd_reduce_kernel + bn_bwd_apply_kernel (bf16)", "bound": "hbm", "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "per_shape": per,
+            "note": "algorithmic bytes (apply: y in [+ residual] + out; backward: (g, y) read by the reduce, (g, y) read + g_y [+ g_res] written "
+                    "by the apply) / in-stream event time, kernels alone on the chip, HBM-cold operands; the guide's achievable streaming rate is "
+                    "~6.3 TB/s of the 8 TB/s peak"}
+
+
 def pmc_traffic(shapes):
     """HBM bytes per launch of the distance+argmin kernel from the committed rocprofv3 --pmc summary of this same command
     (profiles/*_vq_assign_pmc.json: FETCH_SIZE x 2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), looked up by the
@@ -354,6 +408,8 @@ def main():
                         "convolution's flops (they execute 3x that on the MFMA pipes); weight-gradient kernels are listed by_kind (kernel only, the slab "
                         "sums that follow are separate launches) and not part of achieved / whole_step_delivered; "
                         "whole_step_delivered = all convolution forward/data-gradient flops of a step / the headline's step time"}
+        if not args.no_extras:
+            line["roofline_bn"] = bn_roofline(device)
         if all_bf16_s is not None:
             line["all_bf16_step"] = {"images_per_sec": round(images / all_bf16_s, 3), "ms_per_step": round(all_bf16_s / args.steps * 1e3, 3),
                                      "what": "the same step with the two pseudo-label forwards under bf16 autocast too (CPSConfig.eval_amp=True); "
