@@ -49,6 +49,11 @@ const char* vqseg_kernel_name(const char* entry_point);
  *                                   M tile run on the same XCD and share the input rows through its L2 (default 4; 0: off)
  *   "conv3x3_patch_chunk_stage"     1 (default): 3x3 layers with 32-channel K chunks and <= 64 outputs (or 32 inputs) load all nine
  *                                   taps' weights with the patch -- one wait and barrier per chunk instead of per tap; 0: tap ring
+ *   "conv3x3_patch_tile512"         512-pixel tiles of the patch kernel (32-channel chunks) for 32 / 64 output channels: 2 (default) on, 0
+ *                                   off (192 -> 32 at 256^2 is 28 % faster with them; for 128 outputs they measured 10-17 % slower);
+ *                                   "conv3x3_patch_tile512_min_workgroups" their minimum grid (default 512);
+ *                                   "conv3x3_patch_tile512_launches" returns the number of launches that took such a tile so far and
+ *                                   sets the counter to the value passed (tests)
  *   "conv3x3_patch_xcd_pair"        1: the Cout chunks of a pixel tile are dispatched onto the same XCD (default 0:
  *                                   measured equal; the kernel does not wait on HBM for its patches)
  *   "conv_short_k_small_tile", "conv_short_k_single_buffer"   K loops of up to that many 64-channel stages take the

@@ -17,7 +17,8 @@ HOT = {
     "vq_kernels.hip": ["vq_assign_f32_kernelILi8E", "vq_assign_f32_kernelILi4E", "vq_assign_f32_kernelILi2E", "vq_gather_kernel"],
     "conv_kernels.hip": ["conv3x3_patch_kernelILi128ELi3ELb1ELi64E", "conv3x3_patch_kernelILi64ELi3ELb1ELi64E",
                          "conv3x3_patch_kernelILi32ELi3ELb1ELi64E", "conv3x3_patch_kernelILi128ELi3ELb1ELi32E",
-                         "conv3x3_patch_kernelILi32ELi0ELb1ELi32E", "conv_igemm_glds_kernelILi256ELi128ELi8ELi3ELi1E",
+                         "conv3x3_patch_kernelILi32ELi0ELb1ELi32E", "conv3x3_patch_kernelILi64ELi0ELb1ELi32ELb0ELi512E",
+                         "conv3x3_patch_kernelILi32ELi0ELb1ELi32ELb1ELi512E", "conv_igemm_glds_kernelILi256ELi128ELi8ELi3ELi1E",
                          "conv_igemm_glds_kernelILi128ELi128ELi4ELi2ELi1E", "conv_wgrad3x3_kernelILi4ELi2E",
                          "conv_wgrad1x1_kernelILi8ELi4E"],
 }

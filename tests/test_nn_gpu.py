@@ -195,8 +195,35 @@ PATCH_CASES = [
 ]
 
 
+TALL_CASES = [
+    # 512-pixel tiles (16 x 32 or 32 x 16 pixels; 32- / 64-channel outputs, 32-channel chunks): n, c1, c2, cout, h, w, reflect
+    (1, 128, 64, 32, 16, 32, False), (2, 128, 0, 64, 32, 32, False), (2, 32, 0, 32, 16, 32, False), (2, 32, 64, 32, 16, 32, True),
+    (1, 64, 0, 64, 32, 16, True), (2, 192, 0, 32, 32, 64, False), (1, 64, 64, 64, 16, 64, True), (3, 96, 0, 32, 32, 48, True),
+]
+
+
+@pytest.mark.parametrize("case", TALL_CASES)
+def test_conv3x3_patch_kernel_512_pixel_tiles(case, force_patch_kernel):
+    """The same check on the 512-pixel-tile instantiations (default for 32 / 64 output channels once the grid is large enough; here
+    the grid bar is lowered), with the dispatch confirmed by the library's launch counter; BatchNorm partials keep their slot size
+    (64 rows from 64 channels on, else 32)."""
+    from vq_seg_amd import _hip
+    L = _hip.lib()
+    prev = L.vqseg_set_option(b"conv3x3_patch_tile512_min_workgroups", 1)
+    L.vqseg_set_option(b"conv3x3_patch_tile512_launches", 0)
+    try:
+        _patch_case(case)
+    finally:
+        L.vqseg_set_option(b"conv3x3_patch_tile512_min_workgroups", prev)
+    assert L.vqseg_set_option(b"conv3x3_patch_tile512_launches", 0) >= 2, "the 512-pixel tile was not dispatched"
+
+
 @pytest.mark.parametrize("case", PATCH_CASES)
 def test_conv3x3_patch_kernel(case, force_patch_kernel):
+    _patch_case(case)
+
+
+def _patch_case(case):
     """The patch-reuse bf16 3x3 kernel through the C ABI (forward form and, with tap-flipped transposed weights, the
     data-gradient form) against an fp64 convolution of the SAME bf16 values: products are exact in fp32, only the
     accumulation order differs, so the bf16-rounded outputs agree to one bf16 ulp (2^-8 relative)."""

@@ -58,13 +58,19 @@ def test_conv_bn_act_split3_matches_cpu_fp32(cin, c2, cout, k, stride, reflect, 
         want = F.relu(want + r) if res else F.relu(want)
     conv, bn = conv.to(dev()), bn.to(dev())
     cl = lambda t: t.to(dev()).contiguous(memory_format=torch.channels_last)
-    _hip.lib().vqseg_set_option(b"conv3x3_patch_min_workgroups", 1)                      # small test shapes reach the patch kernels too
+    L = _hip.lib()
+    L.vqseg_set_option(b"conv3x3_patch_min_workgroups", 1)                                # small test shapes reach the patch kernels too,
+    L.vqseg_set_option(b"conv3x3_patch_tile512_min_workgroups", 1)                        # ... and their 512-pixel tiles (32 / 64 outputs)
+    L.vqseg_set_option(b"conv3x3_patch_tile512_launches", 0)
     try:
         with torch.no_grad():
             got = nnf.conv_bn_act(nnf.to_s3(cl(x)), conv, bn, relu=True, x2=nnf.to_s3(cl(x2)) if c2 else None,
                                   residual=nnf.to_s3(cl(r)) if res else None)
     finally:
-        _hip.lib().vqseg_set_option(b"conv3x3_patch_min_workgroups", 256)
+        L.vqseg_set_option(b"conv3x3_patch_min_workgroups", 256)
+        L.vqseg_set_option(b"conv3x3_patch_tile512_min_workgroups", 512)
+    tall = L.vqseg_set_option(b"conv3x3_patch_tile512_launches", 0)
+    assert (tall >= 1) == (k == 3 and stride == 1 and cout == 32 and hw % 32 == 0), "512-pixel split-3 tile dispatch"
     assert isinstance(got, nnf.S3) and got.shape == want.shape
     assert rel(got.float(), want) < 2e-5
 

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vq_seg_amd import _hip
 L = _hip.lib()
 dev = torch.device("cuda:0")
-DEFAULTS = {"conv3x3_patch_min_workgroups": 256, "conv3x3_patch_wide_tile": 0, "conv3x3_patch_unroll": 1, "conv3x3_patch_xcd_pair": 0}
+DEFAULTS = {"conv3x3_patch_tile512": 2, "conv3x3_patch_tile512_min_workgroups": 512, "conv3x3_patch_min_workgroups": 256, "conv3x3_patch_wide_tile": 0, "conv3x3_patch_unroll": 1, "conv3x3_patch_xcd_pair": 0}
 variants = [dict(DEFAULTS, **dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in v.split(",") if kv)) for v in (sys.argv[1:] or [""])]
 LAYERS = [("dec0.0", 2048, 0, 1024, 16), ("dec0.1", 1024, 0, 1024, 16), ("dec1.0", 1024, 1024, 512, 32), ("dec1.1", 512, 0, 512, 32),
           ("dec2.0", 512, 512, 256, 64), ("dec2.1", 256, 0, 256, 64), ("dec3.0", 256, 256, 128, 128), ("dec3.1", 128, 0, 128, 128),

@@ -167,7 +167,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
     }
     if (p.stat_partial && !(GLDS_ABL & 4)) {
         // one (mean, M2) partial per SLOT of RPS consecutive rows: 64 rows (two 32-row tiles) or 32 when the wave has one
-        constexpr int TPS = MT >= 2 ? 2 : 1, RPS = TPS * 32;
+        constexpr int TPS = (MT >= 2 && BN >= 64) ? 2 : 1, RPS = TPS * 32;   // vqseg_conv_stat_slots: 64 rows per slot from 64 output channels on, else 32
 #pragma unroll
         for (int b = 0; b < NTT; ++b) {
             const int co = co0 + (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
@@ -792,16 +792,20 @@ struct TileRows {                                           // tile row -> outpu
 
 // CK: input channels per chunk (64, or 32 for layers whose channel count is not a multiple of 64: rows of 64 bytes,
 // four 16-byte chunks swizzled by (row >> 2) & 3, two K steps per tap)
-template <int BN, int NBW, bool UNROLL_TAPS, int CK = 64, bool S3 = false>
+// TBM: output pixels per workgroup (256, or 512 with 32-channel chunks: twice the pixels per staged weight tile -- half the weight
+// DMA per MFMA -- and wave tiles twice as tall: a quarter fewer fragment reads per MFMA (a third for the 32-channel-wide tiles))
+template <int BN, int NBW, bool UNROLL_TAPS, int CK = 64, bool S3 = false, int TBM = 256>
 __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
-    constexpr int TBM = 256, NW = 8;
+    constexpr int NW = 8;
+    static_assert(TBM == 256 || (TBM == 512 && CK == 32), "512-pixel tiles stage 32-channel chunks (two patch buffers must fit the LDS)");
+    constexpr int PATCH_PX = TBM == 256 ? 344 : 616;       // haloed patch pixels, rounded up: 10 x 34 (18 x 18) / 18 x 34 (34 x 18)
     constexpr int NT = BN >= 128 ? 2 : 1;                  // 32-channel tiles per wave
     constexpr int WN = BN / (32 * NT), WM = NW / WN;       // wave grid; wave tile (MT*32) px x (NT*32) co
     constexpr int MT = TBM / (WM * 32);                    // BN 256/128/64/32 -> MT 4/2/2/1 (64/32-row BN stat slots)
     constexpr int ROWB = CK * 2;                           // bytes per LDS row (one pixel / one output channel)
     constexpr int RPI = 1024 / ROWB;                       // rows per 1 KB DMA instruction
     constexpr int KS = CK / 16;                            // MFMA K steps per tap
-    constexpr int PI = (344 + RPI * NW - 1) / (RPI * NW);  // patch DMA instructions per wave and chunk (6 or 3)
+    constexpr int PI = (PATCH_PX + RPI * NW - 1) / (RPI * NW);   // patch DMA instructions per wave and chunk (6 or 3; 5 for 512 pixels)
     constexpr int PATCH_BYTES = PI * NW * 1024;
     constexpr int W_ROWS = (BN * ROWB >= NW * 1024) ? BN : NW * 1024 / ROWB;   // weight rows staged per tap (rows >= Cout: zero page)
     constexpr int W_BYTES = W_ROWS * ROWB;
@@ -1035,6 +1039,9 @@ static int g_patch_wide = 0;                                // 1: take the 256-c
 #endif
 static int g_short_k_small = 1;                             // K loops of up to this many stages take the 128x128 tile at 4 waves/SIMD
 static int g_short_k_single = 8;                            // K loops of up to this many stages: single-buffered 128x128 tile, 4 workgroups/CU
+static int g_patch_tile512 = 2;                             // 512-pixel tiles for 32 / 64 output channels: 0 off, 2 on
+static int g_patch_tile512_min_wgs = 512;
+static int g_patch_tile512_launches = 0;                    // launches that took a 512-pixel tile (tests read it to see the dispatch)
 static int g_patch_unroll = 1;                              // 128-channel tile: tap loop unrolled
 
 int conv_set_option(const char* key, int value) {
@@ -1073,6 +1080,21 @@ int conv_set_option(const char* key, int value) {
         g_patch_chunk_stage = value ? 1 : 0;
         return prev;
     }
+    if (key && !strcmp(key, "conv3x3_patch_tile512")) {
+        const int prev = g_patch_tile512;
+        g_patch_tile512 = value;
+        return prev;
+    }
+    if (key && !strcmp(key, "conv3x3_patch_tile512_launches")) {   // returns the counter, then sets it to `value`
+        const int prev = g_patch_tile512_launches;
+        g_patch_tile512_launches = value;
+        return prev;
+    }
+    if (key && !strcmp(key, "conv3x3_patch_tile512_min_workgroups")) {
+        const int prev = g_patch_tile512_min_wgs;
+        g_patch_tile512_min_wgs = value;
+        return prev;
+    }
     if (key && !strcmp(key, "conv3x3_patch_wide_tile")) {
         const int prev = g_patch_wide;
         g_patch_wide = value ? 1 : 0;
@@ -1092,18 +1114,18 @@ static bool conv3x3_patch_ok(const ConvArgs& a) {
     return (long)a.N * (a.H / th) * (a.W / tw) * (a.Cout / bn) >= g_patch_min_wgs;   // at least one workgroup per CU
 }
 
-template <int BN, int NBW, bool UNROLL_TAPS, int CK = 64>
+template <int BN, int NBW, bool UNROLL_TAPS, int CK = 64, int TBM = 256>
 static void launch_patch_t(const ConvArgs& a, hipStream_t st) {
-    constexpr int ROWB = CK * 2, RPI = 1024 / ROWB, PI = (344 + RPI * 8 - 1) / (RPI * 8);
+    constexpr int ROWB = CK * 2, RPI = 1024 / ROWB, PI = ((TBM == 256 ? 344 : 616) + RPI * 8 - 1) / (RPI * 8);
     constexpr int W_ROWS = (BN * ROWB >= 8 * 1024) ? BN : 8 * 1024 / ROWB;
     size_t lds = 2 * (size_t)PI * 8 * 1024 + (size_t)NBW * W_ROWS * ROWB;
     if (NBW == 0) {                                          // chunk stages: one or two (patch + nine taps of weights) buffers
         const int nb = a.Cin / CK > 1 ? 2 : 1;
         lds = (size_t)nb * ((size_t)PI * 8 * 1024 + 9 * (size_t)BN * ROWB);
     }
-    const size_t out_tile = (size_t)256 * (BN + 8) * 2 * (a.out_s3 ? 2 : 1);
+    const size_t out_tile = (size_t)TBM * (BN + 8) * 2 * (a.out_s3 ? 2 : 1);
     if (out_tile > lds) lds = out_tile;
-    const int tw = (a.W % 32 == 0) ? 32 : 16, th = 256 / tw;
+    const int tw = (a.W % 32 == 0) ? 32 : 16, th = TBM / tw;
     const long tiles = (long)a.N * (a.H / th) * (a.W / tw);
     const int chunks = a.Cout / BN;
     if (g_patch_pair && chunks > 1) {
@@ -1111,13 +1133,22 @@ static void launch_patch_t(const ConvArgs& a, hipStream_t st) {
         b.pair_chunks = chunks;
         b.pair_tiles = (int)tiles;
         const dim3 grid1((unsigned)((tiles + 7) / 8 * 8 * chunks));
-        if (a.out_s3) hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK, true>), grid1, dim3(512), lds, st, b);
-        else hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK>), grid1, dim3(512), lds, st, b);
+        if (a.out_s3) hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK, true, TBM>), grid1, dim3(512), lds, st, b);
+        else hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK, false, TBM>), grid1, dim3(512), lds, st, b);
         return;
     }
     dim3 grid((unsigned)tiles, (unsigned)chunks);
-    if (a.out_s3) hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK, true>), grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK>), grid, dim3(512), lds, st, a);
+    if (a.out_s3) hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK, true, TBM>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<BN, NBW, UNROLL_TAPS, CK, false, TBM>), grid, dim3(512), lds, st, a);
+}
+
+// 512-pixel tiles: geometry (16 x 32 or 32 x 16 pixel tiles must divide the image), LDS of the split-3 output tile, enough workgroups
+static bool conv3x3_tile512_ok(const ConvArgs& a, int bn) {
+    if (a.Cin % 32 || (a.C1 != a.Cin && a.C1 % 32)) return false;
+    const int tw = (a.W % 32 == 0) ? 32 : 16, th = 512 / tw;
+    if (a.W % tw || a.H % th) return false;
+    if (a.out_s3 && (size_t)512 * (bn + 8) * 2 * 2 > 160 * 1024) return false;
+    return (long)a.N * (a.H / th) * (a.W / tw) * (a.Cout / bn) >= g_patch_tile512_min_wgs;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1340,6 +1371,15 @@ static hipError_t launch_conv_impl(const ConvArgs& a, int precise, hipStream_t s
         if (bn == 128) launch_t<128, true, 32>(a, st);
         else if (bn == 64) launch_t<64, true, 32>(a, st);
         else launch_t<32, true, 32>(a, st);
+    } else if ((g_patch_tile512 & 2) && conv3x3_patch_ok(a) && (a.Cout == 32 || (a.Cout == 64 && a.Cin >= 64)) && conv3x3_tile512_ok(a, a.Cout)) {
+        // 32 / 64 output channels: the 256-pixel tile gives every wave ONE 32-pixel row block (two LDS fragment reads per MFMA: the
+        // LDS port is the limit); 512 pixels make it two (1.5 reads per MFMA) and halve the weight DMA per MFMA.  Measured (B = 32):
+        // 192 -> 32 at 256^2 469 -> 337 us, 64 -> 64 at 128^2 83 -> 75 us, 32 -> 32 at 256^2 97 -> 91 us; single-chunk 32 -> 64 is
+        // 14 % slower and stays on the 256-pixel tile; the 128-channel tile was 10-17 % slower at 512 pixels (and spilled in its epilogue):
+        // not instantiated
+        ++g_patch_tile512_launches;
+        if (a.Cout == 64) launch_patch_t<64, 0, true, 32, 512>(a, st);
+        else launch_patch_t<32, 0, true, 32, 512>(a, st);
     } else if (!k64 && conv3x3_patch_ok(a)) {                // 32-channel chunks (the last decoder level and its gradients)
         // taps of one or two K steps: all nine taps' weights ride with the patch (chunk stages) where that fits LDS
         if (g_patch_chunk_stage && a.Cout == 64) launch_patch_t<64, 0, true, 32>(a, st);
