@@ -121,7 +121,7 @@ def test_dice_and_ce_dice_match_oracle(layout):
     xx = xg.clone().requires_grad_(True)
     got = dice_loss(xx, t.to(dev()), 3, ignore_index=255)
     (got * 2.5).backward()
-    assert abs(float(got) - float(want)) < 2e-6 and rel(xx.grad, xc.grad) < 2e-4
+    assert abs(float(got.detach()) - float(want.detach())) < 2e-6 and rel(xx.grad, xc.grad) < 2e-4
     xc = x.clone().requires_grad_(True)
     want = 0.5 * F.cross_entropy(xc, t, ignore_index=255) + R.dice_loss(xc, t)
     want.backward()
