@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Launch contract: one process per GPU.  Under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment) this process IS one rank.  A plain `python bench.py --gpus N` with N > 1 and no WORLD_SIZE is the launcher: before any
+HIP call it starts N fresh rank processes of itself with those variables set (127.0.0.1 rendezvous), relays rank 0's JSON line and
+exits with the worst child's return code -- it never touches the GPU and never re-execs.
+
 A step = ONE cross-pseudo-supervision training iteration of the two VQ-UNets on B labelled +
 B unlabelled synthetic 512x512 images per GPU (6 forwards, 4 backwards, 2 Adam steps):
 "images" = the 2*B input images a step consumes per GPU.  Inputs are resident in HBM before the
@@ -12,8 +17,9 @@ timed region.  Rank 0 prints ONE JSON line.  Extra objects:
   roofline     -- the hand-written distance+argmin kernel (vq_assign_f32_kernel): algorithmic flops
                   2*N*K*C of every launch inside the timed region / its HIP-event time, vs the fp32
                   MFMA peak (157.3 TF/s, MI355X_MICROARCH.md)
-  cpu_baseline -- the CPU oracle's restatement of the same iteration (oracle/cps_ref.py) timed on this
-                  host's cores on a bounded sample (B=1+1); a reported baseline, not the target.
+  cpu_baseline -- the CPU oracle's restatement of the same iteration (the building blocks of
+                  oracle/cps_ref.py) timed on this host's cores on a bounded sample (4 full 512x512 images, composed as
+                  2 eval forwards + 4 training forward/backwards); a reported baseline, not the target.
 """
 from __future__ import annotations
 
@@ -165,6 +171,46 @@ def pmc_traffic(shapes):
     return None, None
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: become the launcher.  Starts N fresh children of this same
+    script, one per GPU, with the rendezvous variables torch.distributed.run would set; rank 0's stdout (the one JSON line) is this
+    process's stdout, every rank's stderr is passed through.  The launcher has not initialised HIP (importing torch does not) and does
+    not exec: children are ordinary subprocesses.  Return code = the worst child's; when one rank dies the others are terminated (by
+    PID) instead of being left waiting in a collective."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("VQSEG_DIST_REHEARSAL") == "1"
+    if not rehearsal:
+        have = torch.cuda.device_count()                       # device_count() does not create a HIP context
+        if have < n:
+            print(f"bench.py: --gpus {n} but this node shows {have} GPU(s); set VQSEG_DIST_REHEARSAL=1 for the one-GPU gloo rehearsal "
+                  f"of the N > 1 path", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                print(f"bench.py launcher: rank {r} exited with {rc}", file=sys.stderr)
+                worst = worst or rc
+                for o in live:                                   # exact PIDs of our own children
+                    procs[o].terminate()
+        time.sleep(0.2)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,7 +226,10 @@ def main():
                          "precision: its trainers run them in fp32, outside autocast)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # VQSEG_DIST_REHEARSAL=1: every rank on cuda:0 with gloo -- a functional rehearsal of the N > 1 code path on a
@@ -200,7 +249,6 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)      # "nccl" IS RCCL on ROCm
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from vq_seg_amd import _hip
     from vq_seg_amd.trainer import CPSConfig, CPSTrainer, SyntheticCropWeed

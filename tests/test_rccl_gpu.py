@@ -86,3 +86,21 @@ def test_bench_two_rank_rehearsal_with_extras_completes():
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and "rehearsal" in line["config"]["collectives"]
     assert line["roofline_conv"]["by_kind"]["3x3 bf16"]["launches_per_step"] > 0 and line["all_bf16_step"]["images_per_sec"] > 0
     assert "identical on all 2 ranks" in res.stderr
+
+
+def test_plain_bench_gpus_2_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2` in exactly the plain form (no torch.distributed.run, no WORLD_SIZE): the launcher starts two fresh
+    rank processes before any HIP call, relays rank 0's one JSON line and returns the worst child's code.  On a
+    one-GPU box the ranks share cuda:0 over gloo (VQSEG_DIST_REHEARSAL=1)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VQSEG_DIST_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "1", "--no-extras"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["value"] > 0
+    assert "identical on all 2 ranks" in res.stderr
