@@ -94,6 +94,66 @@ def gen_vq(ref):
              w_grad_is_none=np.array(vq.codebook.embedding.weight.grad is None))
 
 
+# ---------------------------------------------------------------- argmin at BASELINE row counts, live codebooks
+def gen_vq_big(ref):
+    """the reference's EuclideanCodebook.forward (vector_quantizer/vq_img.py:160-177) at the row counts of the
+    BASELINE configurations, on codebooks where every code is alive.  Per case (tests/cases.py::VQ_BIG_CASES): structured post-ReLU rows;
+    the reference's own `kmeans` (10 iterations, initial means patched to fixed sample rows); labels = the fp64 assignment to those
+    means; codebook = one more Lloyd update from the labels in float64 with a fixed summation order (cases.codebook_from_labels --
+    the test re-derives the SAME bits from the stored labels); then the reference VectorQuantizer in eval mode on (a) the fp32 rows and
+    (b) the same rows rounded to bfloat16.  Stored: labels (int16), the indices as sparse differences against the labels, and the
+    fp64 top-2 relative-gap histogram of both row sets."""
+    from tests import cases
+    import time
+    arrays, metas = {}, []
+    for case in cases.VQ_BIG_CASES:
+        t0 = time.time()
+        n, c, k = case["n"], case["c"], case["k"]
+        rows = cases.vq_big_rows(case)
+        means0 = cases.vq_big_means0(rows, case)
+        orig = ref.vq_img.batched_sample_vectors
+        ref.vq_img.batched_sample_vectors = lambda s_, num, _m=means0: _m[None].clone()
+        try:
+            means, bins = ref.vq_img.kmeans(rows[None], k, 10)
+        finally:
+            ref.vq_img.batched_sample_vectors = orig
+        assert int((bins[0] == 0).sum()) == 0, "k-means left an empty cluster: pick other initial means"
+
+        def d2_fp64(r, W):
+            r64, W64 = r.double(), W.double()
+            return (r64.pow(2).sum(1, keepdim=True) + W64.pow(2).sum(1)[None] - 2.0 * r64 @ W64.t()).clamp_min(0)
+        labels = d2_fp64(rows, means[0]).argmin(1)
+        W = cases.codebook_from_labels(rows, labels.numpy(), k)
+        out = {}
+        for tag, r in (("f32", rows), ("bf16", cases.bf16_exact(rows))):
+            vq = ref.vq_img.VectorQuantizer(dim=c, num_embeddings=k, commitment_weight=1)
+            with torch.no_grad():
+                vq.codebook.embedding.weight.copy_(W)
+            vq.eval()
+            x = r.reshape(1, n, 1, c).permute(0, 3, 1, 2)                     # (B=1, C, H=n, W=1): rows in order
+            with torch.no_grad():
+                q, idx, loss, usage = vq(x)
+            idx = idx.reshape(-1)
+            assert torch.equal(q.permute(0, 2, 3, 1).reshape(n, c), W[idx])
+            d2 = d2_fp64(r, W)
+            top2 = torch.topk(d2, 2, dim=1, largest=False)
+            gap = (top2.values[:, 1] - top2.values[:, 0]) / top2.values[:, 1].clamp_min(1e-30)
+            hist = torch.histc(gap.clamp(1e-12, 1.0).log10(), bins=24, min=-12.0, max=0.0)
+            wrong64 = int((top2.indices[:, 0] != idx).sum())
+            diff = (idx != labels).nonzero()[:, 0]
+            out[tag] = dict(usage=float(usage), min_gap=float(gap.min()), n_gap_lt_1e6=int((gap < 1e-6).sum()), n_gap_lt_1e5=int((gap < 1e-5).sum()),
+                            n_differs_from_fp64_argmin=wrong64, n_differs_from_labels=int(diff.numel()))
+            arrays[f"{case['name']}/{tag}/diff_pos"] = diff.to(torch.int32)
+            arrays[f"{case['name']}/{tag}/diff_idx"] = idx[diff].to(torch.int16)
+            arrays[f"{case['name']}/{tag}/gap_hist_log10"] = hist.to(torch.int32)
+            arrays[f"{case['name']}/{tag}/idx_sum"] = idx.double().sum()
+        arrays[f"{case['name']}/labels"] = labels.to(torch.int16)
+        metas.append(dict(case, rows_sum=synth.checksum(rows), w_sum=synth.checksum(W), **{f"{t}_{k_}": v for t, d in out.items() for k_, v in d.items()}))
+        print(f"  {case['name']}: {time.time() - t0:.0f}s  {out}")
+    save("vq_big", dict(cases=metas, source="vector_quantizer/vq_img.py:29-63 kmeans (patched initial means) -> :193-244 VectorQuantizer eval; "
+                                            "codebook = tests/cases.py::codebook_from_labels(labels)"), **arrays)
+
+
 # ---------------------------------------------------------------- k-means
 KMEANS_CASES = [
     dict(name="kmeans_small", n=512, c=32, k=16, iters=10, empty=False),
@@ -517,7 +577,7 @@ def main():
     ref = ref_harness.ref_modules()
     which = set(sys.argv[1:]) or {"vq", "kmeans", "decoder", "proto", "losses", "models", "models128", "unet", "cps", "curve", "block"}
     for tag, fn in (("vq", gen_vq), ("kmeans", gen_kmeans), ("decoder", gen_decoder), ("proto", gen_proto),
-                    ("losses", gen_losses), ("models", gen_models), ("models128", gen_models128), ("unet", gen_unet), ("cps", gen_cps), ("curve", gen_curve), ("block", gen_decoder_block)):
+                    ("losses", gen_losses), ("models", gen_models), ("models128", gen_models128), ("unet", gen_unet), ("cps", gen_cps), ("curve", gen_curve), ("block", gen_decoder_block), ("vqbig", gen_vq_big)):
         if tag in which:
             print(f"[{tag}]")
             fn(ref)

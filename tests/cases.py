@@ -147,3 +147,79 @@ def block_inputs(meta):
     sd = synth.synth_state_dict(shapes, 3501)
     g = synth.uniform(3502, (b, cout, s, s), -1.0, 1.0)
     return x, sd, g
+
+
+# ---------------------------------------------------------------- argmin at BASELINE row counts on LIVE codebooks (vq_big.npz)
+VQ_BIG_CASES = [
+    # B = 8 images of 512x512: the three levels of one forward (also run as ONE grouped launch), then K = 256 / K = 1024
+    dict(name="l2_k512", n=32768, c=512, k=512), dict(name="l3_k512", n=8192, c=1024, k=512), dict(name="l4_k512", n=2048, c=2048, k=512),
+    dict(name="l2_k256", n=8192, c=512, k=256), dict(name="l2_k1024", n=16384, c=512, k=1024),
+]
+
+
+def vq_big_rows(case) -> torch.Tensor:
+    """Post-ReLU pixel rows with cluster structure: iid post-ReLU noise on top of k sparse post-ReLU centres at a quarter of its
+    scale (row i sits near centre i mod k: overlapping clusters, so that second-best codes come close).  Only IEEE-exact fp32
+    operations -> identical on every machine."""
+    n, c, k = case["n"], case["c"], case["k"]
+    seed = 7000 + sum(map(ord, case["name"]))
+    base = synth.relu_features(seed, (n, c))
+    cent = synth.relu_features(seed + 3, (k, c), sparsity=0.5, scale=1.0)
+    rows = base + cent[torch.arange(n) % k] * case.get("centre_scale", 0.25)
+    # values on a 2^-12 grid (exact fp32 operations): every cluster sum is then EXACT in float64 whatever the summation order, so
+    # codebook_from_labels() returns the same bits on every machine / numpy build
+    return (torch.round(rows * 4096.0) / 4096.0).contiguous()
+
+
+def vq_big_means0(rows: torch.Tensor, case) -> torch.Tensor:
+    """Initial means for the reference's k-means: the first row of every centre (no cluster can start empty)."""
+    return rows[: case["k"]].clone()
+
+
+def codebook_from_labels(rows: torch.Tensor, labels, k: int) -> torch.Tensor:
+    """One Lloyd update in float64, rounded to fp32: the codebook both the fixture generator (reference side) and the GPU test derive
+    from the stored cluster labels.  The rows sit on a 2^-12 grid (vq_big_rows), so the float64 sums are exact and the result is
+    bit-identical on every machine -- the reference's indices for it can be compared exactly.  Every cluster must be non-empty."""
+    import numpy as np
+    lab = np.asarray(labels).astype(np.int64)
+    sums = np.zeros((k, rows.shape[1]), dtype=np.float64)
+    np.add.at(sums, lab, rows.numpy().astype(np.float64))
+    cnt = np.bincount(lab, minlength=k)
+    assert (cnt > 0).all(), "dead cluster in a live-codebook fixture"
+    return torch.from_numpy((sums / cnt[:, None]).astype(np.float32))
+
+
+def bf16_exact(rows: torch.Tensor) -> torch.Tensor:
+    """fp32 rows whose every value is a bfloat16 (round-to-nearest-even): what the bf16 training path hands to the VQ layer."""
+    return rows.bfloat16().float()
+
+
+def vq_big_expected(fx, case, tag: str):
+    """(rows fp32, codebook, expected reference indices int64) of one vq_big case; tag "f32" | "bf16" (rows rounded to bfloat16)."""
+    name = case["name"]
+    rows = vq_big_rows(case)
+    assert synth.checksum(rows) == case["rows_sum"], "synthetic rows drifted"
+    labels = fx[f"{name}/labels"].long()
+    W = codebook_from_labels(rows, labels.numpy(), case["k"])
+    assert synth.checksum(W) == case["w_sum"], "codebook_from_labels is not bit-reproducible on this machine"
+    idx = labels.clone()
+    idx[fx[f"{name}/{tag}/diff_pos"].long()] = fx[f"{name}/{tag}/diff_idx"].long()
+    assert float(idx.double().sum()) == float(fx[f"{name}/{tag}/idx_sum"])
+    return (bf16_exact(rows) if tag == "bf16" else rows), W, idx
+
+
+def near_tie_audit(rows: torch.Tensor, W: torch.Tensor, got: torch.Tensor, want: torch.Tensor):
+    """Rows whose index differs from the expected one, audited in float64: (count, largest relative squared-distance gap between the
+    two candidate codes over those rows, largest excess of either candidate over the true fp64 minimum).  SURVEY 7: an fp32 distance
+    carries ~1e-6 of rounding whose sign depends on the accumulation order (ATen's blocked sgemm on the CPU, a k-ordered fmaf chain
+    on the MFMA path), so two correct fp32 implementations may order a pair of codes closer than that differently -- those rows, and
+    only those, may differ."""
+    bad = (got != want).nonzero()[:, 0]
+    if bad.numel() == 0:
+        return 0, 0.0, 0.0
+    d2 = (rows[bad].double()[:, None, :] - W.double()[None]).pow(2).sum(-1)
+    dg, dw = d2.gather(1, got[bad, None])[:, 0], d2.gather(1, want[bad, None])[:, 0]
+    best = d2.min(1).values
+    gap = (dg - dw).abs() / torch.maximum(dg, dw).clamp_min(1e-30)
+    excess = (torch.maximum(dg, dw) - best) / best.clamp_min(1e-30)
+    return int(bad.numel()), float(gap.max()), float(excess.max())

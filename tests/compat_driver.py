@@ -1,6 +1,6 @@
 """Child process of tests/test_compat_gpu.py: the reference trainer's situation on the GPU box.
 
-    python tests/compat_driver.py <repo>/compat <out.npz> iter_v1|iter_v2|curve|curve_bf16|train_main
+    python tests/compat_driver.py <repo>/compat <out.npz> iter_v1|iter_v2|iter_v1_amp|iter_v2_amp|curve|curve_bf16|curve_amp|train_main
 
 sys.path gets `<repo>/compat` (the maintainer's one line) and -- for the restated loop body only, which lives under tests/ --
 the repository root.  Models, losses, metrics and the schedule are reached through the reference's TOP-LEVEL names
@@ -35,23 +35,34 @@ def prepare(model, x, gt, version):
 
 
 arrays = {}
-if what in ("iter_v1", "iter_v2"):
-    version = int(what[-1])
-    outs = cps_loop.run_iterations(ns, version, dev, n_iters=2, backward=True, to_cfg=EasyDict, prepare=prepare)
+def _flatten(outs, prefix=""):
     for i, o in enumerate(outs):
         for k, v in o.items():
             if k.startswith("grad_none"):
-                arrays[f"it{i}/{k}"] = np.array(v)
+                arrays[f"{prefix}it{i}/{k}"] = np.array(v)
             elif k.startswith("param/"):
-                arrays[k] = v.numpy()
+                arrays[prefix + k] = v.numpy()
             elif isinstance(v, float):
-                arrays[f"it{i}/{k}"] = np.array(v, dtype=np.float64)
+                arrays[f"{prefix}it{i}/{k}"] = np.array(v, dtype=np.float64)
             else:
-                arrays[f"it{i}/{k}"] = v.numpy()
+                arrays[f"{prefix}it{i}/{k}"] = v.numpy()
+
+
+if what in ("iter_v1", "iter_v2"):
+    _flatten(cps_loop.run_iterations(ns, int(what[6]), dev, n_iters=2, backward=True, to_cfg=EasyDict, prepare=prepare))
+elif what in ("iter_v1_amp", "iter_v2_amp"):
+    # the trainer's LITERAL mixed-precision region: torch.cuda.amp.autocast(enabled=True) (no dtype: float16) + GradScaler -- and,
+    # beside it, the same iterations under an explicit bfloat16 autocast without a scaler (what this repository's modules compute in
+    # ANY enabled autocast region): the two must agree
+    _flatten(cps_loop.run_iterations(ns, int(what[6]), dev, n_iters=2, backward=True, to_cfg=EasyDict, prepare=prepare, half=True, scaler=True), "amp/")
+    _flatten(cps_loop.run_iterations(ns, int(what[6]), dev, n_iters=2, backward=True, to_cfg=EasyDict, prepare=prepare, half=True,
+                                     amp_dtype=torch.bfloat16), "bf16/")
 elif what == "curve":
     arrays = cps_loop.run_curve(ns, dev, to_cfg=EasyDict, prepare=prepare)
 elif what == "curve_bf16":                            # the benchmarked precision: training forwards / backwards under bf16 autocast
     arrays = cps_loop.run_curve(ns, dev, to_cfg=EasyDict, prepare=prepare, half=True, amp_dtype=torch.bfloat16)
+elif what == "curve_amp":                             # `half: true` as shipped: fp16-default autocast + GradScaler, literally
+    arrays = cps_loop.run_curve(ns, dev, to_cfg=EasyDict, prepare=prepare, half=True, scaler=True)
 elif what == "train_main":
     # train() of train_vqreptunet1x1v2.py:48-218 as far as the hot path goes: datasets + loaders (:86-93), models + init_weight
     # (:70-80, random init, k-means codebook / prototype init in the first training forward), optimisers + schedule + AMP region

@@ -96,8 +96,13 @@ class Loop:
     """State of a training run: two models, two Adam optimisers, schedule, criteria (train_vqreptunet1x1v2.py:70-114)."""
 
     def __init__(self, ns, version: int, model_1, model_2, total_iters: int, half: bool = False, train: Dict = None,
-                 amp_dtype=torch.float16, with_optim: bool = True):
+                 amp_dtype=torch.float16, with_optim: bool = True, scaler: bool = False):
+        """`scaler=True`: the trainer's LITERAL mixed-precision region (train_vqreptunet1x1v2.py:114,151,172,199-202):
+        `torch.cuda.amp.autocast(enabled=half)` WITHOUT a dtype argument (CUDA/HIP default: float16) and
+        `torch.cuda.amp.GradScaler(enabled=half)` with scale(loss).backward() / step(opt1) / step(opt2) / update()."""
         self.ns, self.version = ns, version
+        self.literal_amp = bool(scaler)
+        self.scaler = torch.cuda.amp.GradScaler(enabled=half) if scaler else None                       # :114
         self.m1, self.m2 = model_1, model_2
         self.t = SimpleNamespace(**dict(TRAIN, **(train or {})))
         self.half, self.amp_dtype = half, amp_dtype
@@ -110,6 +115,8 @@ class Loop:
         self.it = 0
 
     def _autocast(self):
+        if self.literal_amp:
+            return torch.cuda.amp.autocast(enabled=self.half)                                             # :151, :172
         if not self.half:
             return contextlib.nullcontext()
         dev = next(self.m1.parameters()).device.type
@@ -160,18 +167,33 @@ class Loop:
         usage = (u_l1 + u_l2 + u_u1 + u_u2) / 4
         grads = {}
         if backward:
-            loss.backward()                                             # GradScaler(enabled=False) is the identity
+            inv = 1.0
+            if self.scaler is not None:
+                grads["scale_before"] = float(self.scaler.get_scale())
+                inv = 1.0 / grads["scale_before"]
+                self.scaler.scale(loss).backward()                      # :199
+            else:
+                loss.backward()                                         # GradScaler(enabled=False) is the identity
             for tag, m in (("m1", m1), ("m2", m2)):
                 named = dict(m.named_parameters())
                 for key in PROBES:
-                    grads[f"grad/{tag}/{key}"] = golden_io.probe(named[key].grad).detach().float().cpu().clone()
+                    grads[f"grad/{tag}/{key}"] = (golden_io.probe(named[key].grad).detach().float() * inv).cpu().clone()
             grads["grad_none/m1"] = sorted(k for k, p in m1.named_parameters() if p.grad is None)
-            self.opt1.step(), self.opt2.step()
+            if self.scaler is not None:
+                self.scaler.step(self.opt1)                             # :200-202
+                self.scaler.step(self.opt2)
+                self.scaler.update()
+                grads["scale_after"] = float(self.scaler.get_scale())
+            else:
+                self.opt1.step(), self.opt2.step()
         conf = self.measurement._make_confusion_matrix(ps1.detach().float().cpu().numpy(), l_target.detach().cpu().numpy())
         miou, ious = self.measurement.miou(conf)
         self.it += 1
         out = dict(loss=loss, sup_loss_1=sup_1, sup_loss_2=sup_2, cps_loss=cps, commitment_loss=commitment, prototype_loss=prototype)
         out = {k: float(torch.as_tensor(v).detach().double().sum().cpu()) for k, v in out.items()}
+        for k in ("scale_before", "scale_after"):
+            if k in grads:
+                out[k] = grads.pop(k)
         out.update(lr=float(lr), step_miou=float(miou), mask_1=mask_1.detach().cpu().to(torch.uint8), mask_2=mask_2.detach().cpu().to(torch.uint8),
                    score_1=score_1.detach().float().cpu(), pred_sup_1=ps1.detach().float().cpu(), pred_ul_2=pu2.detach().float().cpu(),
                    code_usage=torch.as_tensor(usage).detach().float().cpu(), **grads)
@@ -200,11 +222,11 @@ class Loop:
 
 
 def run_iterations(ns, version: int, device, n_iters: int = 2, backward: bool = True, to_cfg=lambda d: d, prepare=None,
-                   half: bool = False, amp_dtype=torch.float16) -> List[Dict[str, object]]:
+                   half: bool = False, amp_dtype=torch.float16, scaler: bool = False) -> List[Dict[str, object]]:
     """fixture (9) of SURVEY 8c: `n_iters` CPS iterations from the prepared pair; per-iteration dictionaries, the last one
     also carries the parameter probes after the final optimiser step."""
     m1, m2 = build_pair(ns, version, device, to_cfg, prepare)
-    loop = Loop(ns, version, m1, m2, total_iters=1000, half=half, amp_dtype=amp_dtype, with_optim=backward)
+    loop = Loop(ns, version, m1, m2, total_iters=1000, half=half, amp_dtype=amp_dtype, with_optim=backward, scaler=scaler)
     outs = []
     for l_in, l_tg, ul_in in batches(n_iters):
         outs.append(loop.iteration(l_in.to(device), l_tg.to(device), ul_in.to(device), backward=backward))
@@ -216,20 +238,21 @@ CURVE = dict(size=64, batch=4, steps=40, eval_every=10, eval_images=16, learning
 
 
 def run_curve(ns, device, to_cfg=lambda d: d, prepare=None, half: bool = False, amp_dtype=torch.float16, k=(0, 0, 64, 64, 64),
-              spec: Dict = None) -> Dict[str, object]:
+              spec: Dict = None, scaler: bool = False) -> Dict[str, object]:
     """The mIoU-parity run (north_star: "mIoU within +-0.2"): `steps` v1 iterations on the synthetic crop/weed blobs, test-set
     mIoU of model_1 (the trainers' test()) every `eval_every` steps."""
     s = SimpleNamespace(**dict(CURVE, **(spec or {})))
     m1, m2 = build_pair(ns, 1, device, to_cfg, prepare, k=k, size=s.size, batch=s.batch)
-    loop = Loop(ns, 1, m1, m2, total_iters=s.steps, half=half, amp_dtype=amp_dtype, train=dict(learning_rate=s.learning_rate))
+    loop = Loop(ns, 1, m1, m2, total_iters=s.steps, half=half, amp_dtype=amp_dtype, train=dict(learning_rate=s.learning_rate), scaler=scaler)
     test_img, test_lab = synth.blob_images(9900, s.eval_images, s.size, cell=8)
     test_img, test_lab = test_img.to(device), test_lab.to(device)
-    mious, losses, step_mious = [loop.evaluate(test_img, test_lab)], [], []
+    mious, losses, step_mious, scales = [loop.evaluate(test_img, test_lab)], [], [], []
     data = batches(s.steps, s.size, s.batch, seed=8500)
     for i, (l_in, l_tg, ul_in) in enumerate(data):
         out = loop.iteration(l_in.to(device), l_tg.to(device), ul_in.to(device), epoch_frac=0.0)
         losses.append(out["sup_loss_1"])
         step_mious.append(out["step_miou"])
+        scales.append(out.get("scale_after", 1.0))
         if (i + 1) % s.eval_every == 0:
             mious.append(loop.evaluate(test_img, test_lab))
-    return dict(test_miou=np.array(mious), sup_loss_1=np.array(losses), step_miou=np.array(step_mious))
+    return dict(test_miou=np.array(mious), sup_loss_1=np.array(losses), step_miou=np.array(step_mious), scale=np.array(scales))

@@ -137,3 +137,70 @@ def test_trainer_main_flow_on_a_synthetic_folder(tmp_path):
     got = drive(tmp_path, "train_main")
     assert int(got["iters"]) == 6 and np.isfinite(got["losses"]).all() and got["initted"].all()
     assert ((got["mious"] >= 0) & (got["mious"] <= 1)).all()
+
+
+def _check_amp_iterations(got, fx, version):
+    """The reference trainer's LITERAL mixed-precision region (`half: true` in every shipped config): `torch.cuda.amp.autocast(
+    enabled=True)` with no dtype (float16 by default) + `GradScaler` (train_vqreptunet1x1v2.py:114,151,172,199-202).  This repository's
+    modules compute in bfloat16 inside ANY enabled autocast region (nnf.act_dtype), so the yardstick is the SAME two
+    iterations under an explicit `torch.autocast(dtype=torch.bfloat16)` without a scaler (`bf16/...`, produced by the same child
+    process): every forward term and logit of the literal region (`amp/...`) must equal it (the loss scale 65536 is a power of two:
+    it moves exponents only, and bf16 has fp32's exponent range), un-scaled gradients and post-step parameters within 1e-5 of scale.
+    The scaler must never see an inf (scale stays 65536: no skipped optimiser step).  Against the reference's fp32 CPU fixture only
+    the loose bf16 bars apply at this size (BatchNorm over 8 samples at the deepest level amplifies bf16 rounding): iteration-0 losses
+    within 5e-2 relative; the fp32 pseudo-label forward (outside autocast) keeps the 1e-3 bar."""
+    rep = []
+    for i in range(2):
+        assert float(got[f"amp/it{i}/scale_before"]) == 65536.0 and float(got[f"amp/it{i}/scale_after"]) == 65536.0, "GradScaler skipped a step"
+        for key in ("loss", "sup_loss_1", "sup_loss_2", "cps_loss", "commitment_loss", "prototype_loss"):
+            a, b = float(got[f"amp/it{i}/{key}"]), float(got[f"bf16/it{i}/{key}"])
+            assert np.isfinite(a) and abs(a - b) <= (1e-6, 1e-3)[i] * abs(b) + 1e-9, (i, key, a, b)
+            rep.append(f"it{i} {key}: literal AMP {a:.7f}  bf16 autocast {b:.7f}")
+        for key in ("mask_1", "mask_2"):
+            diff = int((got[f"amp/it{i}/{key}"] != got[f"bf16/it{i}/{key}"]).sum())
+            assert diff <= (0, 40)[i], (i, key, diff)
+        for key in ("score_1", "pred_sup_1", "pred_ul_2"):
+            a, b = got[f"amp/it{i}/{key}"].astype(np.float64), got[f"bf16/it{i}/{key}"].astype(np.float64)
+            err = np.abs(a - b).max() / np.abs(b).max()
+            assert err <= (0.0, 2e-2)[i], (i, key, err)
+            rep.append(f"it{i} {key}: literal AMP vs bf16 autocast {err:.2e} of scale")
+        for tag in ("m1", "m2"):
+            for key in cps_loop.PROBES:
+                a, b = got[f"amp/it{i}/grad/{tag}/{key}"].astype(np.float64), got[f"bf16/it{i}/grad/{tag}/{key}"].astype(np.float64)
+                assert np.isfinite(a).all(), (i, tag, key)
+                if i == 0:
+                    l2 = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+                    assert l2 <= 1e-5, (tag, key, l2)
+                    rep.append(f"it0 grad {tag} {key}: rel L2 {l2:.2e}")
+    assert set(got["amp/it0/grad_none/m1"].tolist()) == set(got["bf16/it0/grad_none/m1"].tolist())
+    for key in ("loss", "sup_loss_1", "sup_loss_2", "cps_loss", "commitment_loss", "prototype_loss"):
+        a, b = float(got[f"amp/it0/{key}"]), float(fx[f"it0/{key}"])
+        assert abs(a - b) <= 5e-2 * abs(b) + 1e-6, (key, a, b)
+        rep.append(f"it0 {key}: {a:.6f} vs reference fp32 {b:.6f}")
+    a, b = torch.from_numpy(got["amp/it0/score_1"]).double(), fx["it0/score_1"].double()
+    assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item()          # the pseudo-label forward is OUTSIDE autocast: fp32 bar
+    for key in ("pred_sup_1", "pred_ul_2"):
+        a, b = torch.from_numpy(got[f"amp/it0/{key}"]).double(), fx[f"it0/{key}"].double()
+        rep.append(f"it0 {key}: {(a - b).abs().max().item() / b.abs().max().item():.2e} of scale from the reference's fp32 logits (bf16 region)")
+    print("\n".join(rep))
+
+
+def test_v2_literal_amp_region_with_gradscaler(tmp_path):
+    """v2 loop body, fp16-default autocast + GradScaler, two iterations, against cps_iter_v2.npz."""
+    _check_amp_iterations(drive(tmp_path, "iter_v2_amp"), golden_io.load("cps_iter_v2"), 2)
+
+
+def test_v1_literal_amp_region_with_gradscaler(tmp_path):
+    _check_amp_iterations(drive(tmp_path, "iter_v1_amp"), golden_io.load("cps_iter_v1"), 1)
+
+
+def test_miou_parity_run_literal_amp(tmp_path):
+    """The 40-step mIoU run under the trainer's literal AMP region (fp16-default autocast + GradScaler): no skipped step, end point
+    within the north_star's 0.2 mIoU points of the reference's fp32 CPU curve."""
+    got, fx = drive(tmp_path, "curve_amp"), golden_io.load("cps_curve_v1")
+    a, b = got["test_miou"], fx["test_miou"].numpy()
+    print("test mIoU  GPU literal AMP:", np.round(a, 5), " reference CPU fp32:", np.round(b, 5))
+    assert (got["scale"] == 65536.0).all(), got["scale"]
+    assert abs(a[0] - b[0]) <= 1e-4
+    assert abs(a[-1] - b[-1]) <= 0.002, (a, b)
+    assert np.abs(a - b).max() <= 0.05, (a, b)

@@ -327,3 +327,23 @@ def test_decoder_block_at_bench_scale():
     close(golden_io.probe(p["blk.0.0.weight"].grad), fx["grad_w0"], rtol=1e-3, atol=1e-5 * float(fx["grad_w0_stats"][2]))
     close(p["blk.1.1.weight"].grad, fx["grad_bn_w1"], rtol=1e-3, atol=1e-4 * float(fx["grad_bn_w1"].abs().max()))
     close(p["blk.0.1.running_var"], fx["run_var0"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["f32", "bf16"])
+def test_oracle_argmin_at_baseline_row_counts_on_live_codebooks(tag):
+    """vq_big.npz (oracle/make_golden.py::gen_vq_big): the reference's eval-mode VectorQuantizer at N = 32768 / 8192 / 2048 / 8192 /
+    16384 rows on codebooks with no dead code.  The torch restatement must return the reference's indices exactly on every case;
+    the C chain oracle (the arithmetic the GPU kernel reproduces bit for bit) is checked on the cases it finishes in seconds."""
+    from oracle import vq_chain
+    fx = golden_io.load("vq_big")
+    for case in fx.meta["cases"]:
+        rows, W, idx = cases.vq_big_expected(fx, case, tag)
+        n, c = rows.shape
+        x = rows.reshape(1, n, 1, c).permute(0, 3, 1, 2)
+        with torch.no_grad():
+            q, got, loss, usage = R.vq_forward(x, W, training=False)
+        assert torch.equal(got.reshape(-1), idx), case["name"]
+        assert float(usage) == 0.0 == case[f"{tag}_usage"]                      # every code alive
+        if n * c * case["k"] <= 2 ** 31:
+            cidx, _ = vq_chain.assign(rows.numpy(), W.numpy(), vq_chain.ORDER_MFMA8)
+            assert np.array_equal(cidx, idx.numpy()), case["name"]

@@ -353,3 +353,43 @@ def test_model_quantize_uses_the_grouped_launch_and_matches_per_level_calls():
     mods[2].codebook.kmeans_init, mods[2].codebook.initted = True, False           # k-means pending -> not groupable
     mods.train(True)
     assert quantize_group(list(mods[2:]), feats[2:]) is None
+
+
+@pytest.mark.parametrize("tag", ["f32", "bf16"])
+def test_argmin_at_baseline_row_counts_matches_the_reference_on_live_codebooks(tag):
+    """VERDICT r2 item 3.  vq_big.npz holds what the REFERENCE's EuclideanCodebook.forward (vector_quantizer/vq_img.py:160-177)
+    returned at BASELINE row counts -- (N, C, K) = (32768, 512, 512), (8192, 1024, 512), (2048, 2048, 512), (8192, 512, 256),
+    (16384, 512, 1024) -- on codebooks from its own k-means (no dead code; smallest fp64 top-2 gap 5e-6 relative).  Indices must
+    equal the reference's: fp32 rows through the f32 entry point, bf16-exact rows through BOTH the f32 entry point and the bf16 one
+    (the rows the training path hands over), and the three levels of a forward through the grouped launch.  The only rows that may
+    differ are near-ties below fp32 resolution (cases.near_tie_audit: both candidates within 1e-5 relative in float64, never more
+    rows than the fixture's own census of such gaps); they are counted and printed -- 0 on the MI355X runs so far."""
+    from vq_seg_amd import _hip
+    fx = golden_io.load("vq_big")
+    level, report = {}, []
+
+    def same(got, idx, rows, W, case, what):
+        n_bad, gap, excess = cases.near_tie_audit(rows, W, got, idx.to(got.device))
+        report.append(f"{case['name']} {tag} {what}: {n_bad} of {idx.numel()} indices differ from the reference "
+                      f"(fixture: {case[tag + '_n_gap_lt_1e5']} rows with a top-2 gap < 1e-5, min gap {case[tag + '_min_gap']:.1e})")
+        assert n_bad <= case[tag + "_n_gap_lt_1e5"] and gap < 1e-5 and excess < 1e-5, report[-1] + f"; gap {gap:.1e}, excess {excess:.1e}"
+
+    for case in fx.meta["cases"]:
+        rows, W, idx = cases.vq_big_expected(fx, case, tag)
+        rd, Wd = rows.to(dev()), W.to(dev())
+        same(_hip.vq_assign(rd, Wd), idx, rd, Wd, case, "f32 entry point")
+        if tag == "bf16":
+            same(_hip.vq_assign(rd.bfloat16(), Wd), idx, rd, Wd, case, "bf16 entry point")
+        quant, idx_f, _loss, dead = _hip.vq_forward(rd if tag == "f32" else rd.bfloat16(), Wd, False, 1.0)[:4]
+        same(idx_f, idx, rd, Wd, case, "forward")
+        assert float(dead) == 0.0
+        assert torch.equal(quant.float(), Wd[idx_f] if tag == "f32" else Wd[idx_f].bfloat16().float())
+        if case["k"] == 512:
+            level[case["name"]] = (rd if tag == "f32" else rd.bfloat16(), Wd, idx_f)
+    rows_l, books, want = zip(*(level[n] for n in ("l2_k512", "l3_k512", "l4_k512")))
+    preps = [_hip.vq_prepare(w) for w in books]
+    for training in (False, True):
+        group = _hip.vq_forward_group(list(rows_l), list(books), preps, training, [1.0, 1.0, 1.0])
+        for g, w in zip(group, want):
+            assert torch.equal(g[1], w)                                        # grouped launch == single launches, bit for bit
+    print("\n".join(report))
