@@ -148,7 +148,7 @@ def gen_vq_big(ref):
             arrays[f"{case['name']}/{tag}/gap_hist_log10"] = hist.to(torch.int32)
             arrays[f"{case['name']}/{tag}/idx_sum"] = idx.double().sum()
         arrays[f"{case['name']}/labels"] = labels.to(torch.int16)
-        metas.append(dict(case, rows_sum=synth.checksum(rows), w_sum=synth.checksum(W), **{f"{t}_{k_}": v for t, d in out.items() for k_, v in d.items()}))
+        metas.append(dict(case, rows_bits=synth.bits_checksum(rows), w_bits=synth.bits_checksum(W), **{f"{t}_{k_}": v for t, d in out.items() for k_, v in d.items()}))
         print(f"  {case['name']}: {time.time() - t0:.0f}s  {out}")
     save("vq_big", dict(cases=metas, source="vector_quantizer/vq_img.py:29-63 kmeans (patched initial means) -> :193-244 VectorQuantizer eval; "
                                             "codebook = tests/cases.py::codebook_from_labels(labels)"), **arrays)

@@ -198,10 +198,10 @@ def vq_big_expected(fx, case, tag: str):
     """(rows fp32, codebook, expected reference indices int64) of one vq_big case; tag "f32" | "bf16" (rows rounded to bfloat16)."""
     name = case["name"]
     rows = vq_big_rows(case)
-    assert synth.checksum(rows) == case["rows_sum"], "synthetic rows drifted"
+    assert synth.bits_checksum(rows) == case["rows_bits"], "synthetic rows drifted"
     labels = fx[f"{name}/labels"].long()
     W = codebook_from_labels(rows, labels.numpy(), case["k"])
-    assert synth.checksum(W) == case["w_sum"], "codebook_from_labels is not bit-reproducible on this machine"
+    assert synth.bits_checksum(W) == case["w_bits"], "codebook_from_labels is not bit-reproducible on this machine"
     idx = labels.clone()
     idx[fx[f"{name}/{tag}/diff_pos"].long()] = fx[f"{name}/{tag}/diff_idx"].long()
     assert float(idx.double().sum()) == float(fx[f"{name}/{tag}/idx_sum"])

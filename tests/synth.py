@@ -40,6 +40,12 @@ def checksum(t: torch.Tensor) -> float:
     return float(t.detach().double().sum().item())
 
 
+def bits_checksum(t: torch.Tensor) -> int:
+    """Order-independent, exact checksum of an fp32 tensor: the int64 sum of its bit patterns (a float64 sum of arbitrary floats
+    depends on the summation order, i.e. on torch's thread count)."""
+    return int(t.detach().contiguous().view(torch.int32).to(torch.int64).sum().item())
+
+
 def synth_state_dict(shapes: Mapping[str, Tuple[int, ...]], seed: int) -> "OrderedDict[str, torch.Tensor]":
     """Fill a state_dict layout (name -> shape) with deterministic, sanely scaled values.
 
