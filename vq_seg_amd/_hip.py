@@ -137,23 +137,72 @@ PY_OPTS: dict = {}
 
 
 def _check(rc: int, what: str) -> None:
+    _raise_if_not_on_gpu()
     if rc != 0:
         msg = lib().vqseg_last_error().decode(errors="replace")
         raise HipLibraryError(f"{what} failed (code {rc}): {msg}")
 
 
-def _dev(t: torch.Tensor, dtype: torch.dtype, name: str) -> int:
-    if not isinstance(t, torch.Tensor) or not t.is_cuda:
-        raise HipLibraryError(f"{name}: the HIP path needs a tensor on a 'cuda' (ROCm) device; got "
-                              f"{getattr(t, 'device', type(t))}. There is no CPU fallback.")
-    if t.dtype != dtype:
-        raise HipLibraryError(f"{name}: expected {dtype}, got {t.dtype}")
-    if not t.is_contiguous():
-        raise HipLibraryError(f"{name}: expected a contiguous tensor")
+_BF_DTYPE = {0: torch.float32, 1: torch.bfloat16, 2: torch.bfloat16}      # the `bf16` flag of the entry points (2: split-3 [hi | lo] rows)
+
+
+def tptr(t, name: str, dtype=None, numel: Optional[int] = None, bf: Optional[int] = None, at_least: bool = False) -> Optional[int]:
+    """THE way a tensor crosses the C ABI: returns its address after checking what the untyped `void*` on the other side cannot --
+    the element type (`dtype`: one torch dtype or a tuple; or `bf`: the 0 / 1 / 2 activation-type flag that is passed to the SAME
+    entry point, so flag and buffer cannot disagree), dense memory, the element count the sizes passed along imply (`numel`, exact
+    unless `at_least`), and a 'cuda' (ROCm) device.  A bf16 buffer behind an f32 flag is a 2x out-of-bounds read on the GPU (it
+    happened: DESIGN 2, r2); here it is a Python exception.  The dtype / size checks come BEFORE the device check, so the CPU test
+    suite can feed every wrapper the wrong type (tests/test_abi_cpu.py).  None passes through as a null pointer."""
+    if t is None:
+        return None
+
+    def bad(msg):
+        _NOT_ON_GPU.clear()
+        return HipLibraryError(f"{name}: {msg}")
+    if not isinstance(t, torch.Tensor):
+        raise bad(f"expected a tensor, got {type(t).__name__}")
+    if bf is not None:
+        dtype = _BF_DTYPE[int(bf)]
+    if dtype is not None and (t.dtype not in dtype if isinstance(dtype, tuple) else t.dtype != dtype):
+        raise bad(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous() and not (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)):
+        raise bad(f"expected a dense (contiguous) tensor, got strides {tuple(t.stride())} for shape {tuple(t.shape)}")
+    if numel is not None and (t.numel() < numel if at_least else t.numel() != numel):
+        raise bad(f"the sizes passed along need {'at least ' if at_least else ''}{numel} elements, the tensor has {t.numel()} (shape {tuple(t.shape)})")
+    if not t.is_cuda:
+        # remembered, raised by _stream() -- the last argument every launch evaluates -- so that the OTHER tensors of the call still get
+        # their type / size checks first (a box without a GPU can then exercise them: tests/test_abi_cpu.py); nothing is launched
+        _NOT_ON_GPU.append(f"{name}: the HIP path needs a tensor on a 'cuda' (ROCm) device; got {t.device}. There is no CPU fallback.")
+        return 0
     return t.data_ptr()
 
 
+_NOT_ON_GPU: list = []
+
+
+def _raise_if_not_on_gpu() -> None:
+    if _NOT_ON_GPU:
+        msg = _NOT_ON_GPU[0]
+        _NOT_ON_GPU.clear()
+        raise HipLibraryError(msg)
+
+
+def _dev(t: torch.Tensor, dtype: torch.dtype, name: str, numel: Optional[int] = None) -> int:
+    if t is None:
+        raise HipLibraryError(f"{name}: expected a tensor, got None")
+    return tptr(t, name, dtype=dtype, numel=numel)
+
+
+def on_device(dev):
+    """`torch.cuda.device(dev)` for the launch; a no-op for a non-GPU device, so that the argument checks (tptr) are what raises
+    when a CPU tensor reaches a wrapper."""
+    import contextlib
+    dev = torch.device(dev) if not isinstance(dev, torch.device) else dev
+    return torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()
+
+
 def _stream() -> int:
+    _raise_if_not_on_gpu()
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -169,7 +218,7 @@ def vq_prepare(codebook: torch.Tensor) -> torch.Tensor:
     wp = _dev(codebook, torch.float32, "codebook")
     nbytes = L.vqseg_vq_prepared_bytes(c, k)
     blob = _workspace(nbytes, codebook.device)
-    with torch.cuda.device(codebook.device):
+    with on_device(codebook.device):
         rc = L.vqseg_vq_prepare_f32(wp, c, k, blob.data_ptr(), nbytes, _stream())
     _check(rc, "vqseg_vq_prepare_f32")
     return blob
@@ -182,7 +231,7 @@ def vq_forward(rows: torch.Tensor, codebook: torch.Tensor, training: bool, commi
     n, c = rows.shape
     k = codebook.shape[0]
     bf16 = rows.dtype == torch.bfloat16                      # bf16 activations: same fp32 arithmetic, bf16 quant
-    xp, wp = _dev(rows, rows.dtype if bf16 else torch.float32, "rows"), _dev(codebook, torch.float32, "codebook")
+    xp, wp = tptr(rows, "rows", bf=int(bf16), numel=n * c), _dev(codebook, torch.float32, "codebook", k * c)
     dev = rows.device
     quant = torch.empty_like(rows)
     idx = torch.empty(n, dtype=torch.int64, device=dev)
@@ -190,9 +239,9 @@ def vq_forward(rows: torch.Tensor, codebook: torch.Tensor, training: bool, commi
     dmin = torch.empty(n, dtype=torch.float32, device=dev) if want_dmin else None
     nbytes = L.vqseg_vq_workspace_bytes(n, c, k)
     ws = _workspace(nbytes, dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         fwd = L.vqseg_vq_forward_bf16 if bf16 else L.vqseg_vq_forward_f32
-        rc = fwd(xp, wp, prepared.data_ptr() if prepared is not None else None, n, c, k,
+        rc = fwd(xp, wp, tptr(prepared, "prepared codebook", dtype=torch.uint8, numel=L.vqseg_vq_prepared_bytes(c, k)), n, c, k,
                  int(bool(training)), float(commitment_weight), quant.data_ptr(),
                  idx.data_ptr(), scal.data_ptr(), scal.data_ptr() + 4,
                  dmin.data_ptr() if want_dmin else None, ws.data_ptr(), nbytes, _stream())
@@ -219,7 +268,7 @@ def vq_forward_group(rows_list, codebooks, prepared_list, training: bool, commit
     for r, w in zip(rows_list, codebooks):
         if r.dtype != rows_list[0].dtype:
             raise HipLibraryError("vq_forward_group: one row type per call")
-        _dev(r, r.dtype if bf16 else torch.float32, "rows"), _dev(w, torch.float32, "codebook")
+        tptr(r, "rows", bf=int(bf16)), _dev(w, torch.float32, "codebook", w.shape[0] * r.shape[1])
         quants.append(torch.empty_like(r))
         idxs.append(torch.empty(r.shape[0], dtype=torch.int64, device=dev))
         scals.append(torch.empty(2, dtype=torch.float32, device=dev))
@@ -227,7 +276,9 @@ def vq_forward_group(rows_list, codebooks, prepared_list, training: bool, commit
     wsb = (c_size_t * nl)(*[w.numel() for w in wss])
     loss_p = (c_void_p * nl)(*[s.data_ptr() for s in scals])
     dead_p = (c_void_p * nl)(*[s.data_ptr() + 4 for s in scals])
-    with torch.cuda.device(dev):
+    for w, p_ in zip(codebooks, prepared_list):
+        tptr(p_, "prepared codebook", dtype=torch.uint8, numel=L.vqseg_vq_prepared_bytes(w.shape[1], w.shape[0]))
+    with on_device(dev):
         rc = L.vqseg_vq_forward_group(nl, int(bf16), ptr(rows_list), ptr(codebooks), ptr(prepared_list), ns.ctypes.data, cs.ctypes.data,
                                       ks.ctypes.data, int(bool(training)), cw.ctypes.data, ptr(quants), ptr(idxs), loss_p, dead_p,
                                       ptr(wss), ctypes.cast(wsb, c_void_p), _stream())
@@ -241,15 +292,15 @@ def vq_assign(rows: torch.Tensor, codebook: torch.Tensor, want_dmin: bool = Fals
     n, c = rows.shape
     k = codebook.shape[0]
     bf16 = rows.dtype == torch.bfloat16                      # bf16 activations: same fp32 arithmetic, bf16 quant
-    xp, wp = _dev(rows, rows.dtype if bf16 else torch.float32, "rows"), _dev(codebook, torch.float32, "codebook")
+    xp, wp = tptr(rows, "rows", bf=int(bf16), numel=n * c), _dev(codebook, torch.float32, "codebook", k * c)
     dev = rows.device
     idx = torch.empty(n, dtype=torch.int64, device=dev)
     dmin = torch.empty(n, dtype=torch.float32, device=dev) if want_dmin else None
     nbytes = L.vqseg_vq_workspace_bytes(n, c, k)
     ws = _workspace(nbytes, dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         fn = L.vqseg_vq_assign_bf16 if bf16 else L.vqseg_vq_assign_f32        # the entry point must match the row type
-        rc = fn(xp, wp, prepared.data_ptr() if prepared is not None else None, n, c, k,
+        rc = fn(xp, wp, tptr(prepared, "prepared codebook", dtype=torch.uint8, numel=L.vqseg_vq_prepared_bytes(c, k)), n, c, k,
                 idx.data_ptr(), dmin.data_ptr() if want_dmin else None, ws.data_ptr(), nbytes, _stream())
     _check(rc, "vqseg_vq_assign_bf16" if bf16 else "vqseg_vq_assign_f32")
     return (idx, dmin) if want_dmin else idx
@@ -259,11 +310,11 @@ def vq_backward(grad_quant: torch.Tensor, grad_loss: Optional[torch.Tensor], row
                 commitment_weight: float) -> torch.Tensor:
     L = lib()
     n, c = rows.shape
-    gq = _dev(grad_quant, torch.float32, "grad_quant")
-    gl = _dev(grad_loss, torch.float32, "grad_loss") if grad_loss is not None else None
+    gq = _dev(grad_quant, torch.float32, "grad_quant", n * c)
+    gl = _dev(grad_loss, torch.float32, "grad_loss", 1) if grad_loss is not None else None
     gx = torch.empty_like(rows)
-    with torch.cuda.device(rows.device):
-        rc = L.vqseg_vq_backward_f32(gq, gl, _dev(rows, torch.float32, "rows"), _dev(quant, torch.float32, "quant"),
+    with on_device(rows.device):
+        rc = L.vqseg_vq_backward_f32(gq, gl, _dev(rows, torch.float32, "rows", n * c), _dev(quant, torch.float32, "quant", n * c),
                                      n, c, float(commitment_weight), gx.data_ptr(), _stream())
     _check(rc, "vqseg_vq_backward_f32")
     return gx
@@ -274,11 +325,13 @@ def vq_backward_bf16(grad_quant: torch.Tensor, grad_loss: Optional[torch.Tensor]
     """bf16 activations: grad_x = grad_quant + (2 w grad_loss / (N C)) (x - codebook[idx]), e re-read in fp32."""
     L = lib()
     n, c = rows.shape
-    gq = _dev(grad_quant, torch.bfloat16, "grad_quant")
-    gl = _dev(grad_loss, torch.float32, "grad_loss") if grad_loss is not None else None
+    gq = _dev(grad_quant, torch.bfloat16, "grad_quant", n * c)
+    gl = _dev(grad_loss, torch.float32, "grad_loss", 1) if grad_loss is not None else None
     gx = torch.empty_like(rows)
-    with torch.cuda.device(rows.device):
-        rc = L.vqseg_vq_backward_bf16(gq, gl, _dev(rows, torch.bfloat16, "rows"), _dev(idx, torch.int64, "idx"),
+    if codebook.dim() != 2 or codebook.shape[1] != c:
+        raise HipLibraryError(f"codebook: expected (K, {c}), got {tuple(codebook.shape)}")
+    with on_device(rows.device):
+        rc = L.vqseg_vq_backward_bf16(gq, gl, _dev(rows, torch.bfloat16, "rows", n * c), _dev(idx, torch.int64, "idx", n),
                                       _dev(codebook, torch.float32, "codebook"), n, c, float(commitment_weight), gx.data_ptr(),
                                       _stream())
     _check(rc, "vqseg_vq_backward_bf16")
@@ -290,11 +343,11 @@ def kmeans(samples: torch.Tensor, means: torch.Tensor, iters: int) -> Tuple[torc
     L = lib()
     n, c = samples.shape
     k = means.shape[0]
-    sp, mp = _dev(samples, torch.float32, "samples"), _dev(means, torch.float32, "means")
+    sp, mp = _dev(samples, torch.float32, "samples", n * c), _dev(means, torch.float32, "means", k * c)
     bins = torch.zeros(k, dtype=torch.int64, device=samples.device)
     nbytes = L.vqseg_kmeans_workspace_bytes(n, c, k)
     ws = _workspace(nbytes, samples.device)
-    with torch.cuda.device(samples.device):
+    with on_device(samples.device):
         rc = L.vqseg_kmeans_f32(sp, mp, bins.data_ptr(), n, c, k, int(iters), ws.data_ptr(), nbytes, _stream())
     _check(rc, "vqseg_kmeans_f32")
     return means, bins
@@ -305,12 +358,12 @@ def kmeans_accumulate(samples: torch.Tensor, means: torch.Tensor) -> Tuple[torch
     L = lib()
     n, c = samples.shape
     k = means.shape[0]
-    sp, mp = _dev(samples, torch.float32, "samples"), _dev(means, torch.float32, "means")
+    sp, mp = _dev(samples, torch.float32, "samples", n * c), _dev(means, torch.float32, "means", k * c)
     sums = torch.empty(k, c, dtype=torch.float32, device=samples.device)
     counts = torch.empty(k, dtype=torch.int64, device=samples.device)
     nbytes = L.vqseg_kmeans_workspace_bytes(n, c, k)
     ws = _workspace(nbytes, samples.device)
-    with torch.cuda.device(samples.device):
+    with on_device(samples.device):
         rc = L.vqseg_kmeans_accumulate_f32(sp, mp, n, c, k, sums.data_ptr(), counts.data_ptr(), ws.data_ptr(), nbytes,
                                            _stream())
     _check(rc, "vqseg_kmeans_accumulate_f32")
@@ -320,9 +373,9 @@ def kmeans_accumulate(samples: torch.Tensor, means: torch.Tensor) -> Tuple[torch
 def kmeans_finalize(sums: torch.Tensor, counts: torch.Tensor, means: torch.Tensor) -> torch.Tensor:
     L = lib()
     k, c = means.shape
-    with torch.cuda.device(means.device):
-        rc = L.vqseg_kmeans_finalize_f32(_dev(sums, torch.float32, "sums"), _dev(counts, torch.int64, "counts"),
-                                         _dev(means, torch.float32, "means"), c, k, _stream())
+    with on_device(means.device):
+        rc = L.vqseg_kmeans_finalize_f32(_dev(sums, torch.float32, "sums", k * c), _dev(counts, torch.int64, "counts", k),
+                                         _dev(means, torch.float32, "means", k * c), c, k, _stream())
     _check(rc, "vqseg_kmeans_finalize_f32")
     return means
 
@@ -331,17 +384,15 @@ def vq_code_sums(rows: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.T
     """Per-code sums (K, C) f32 and counts (K,) i64 of rows (N, C) f32 / bf16 under the assignment idx (N,) i64."""
     L = lib()
     n, c = rows.shape
-    if rows.dtype not in (torch.float32, torch.bfloat16) or not rows.is_cuda or not rows.is_contiguous():
-        raise ValueError("vq_code_sums: rows must be contiguous f32 / bf16 on the GPU")
-    ip = _dev(idx, torch.int64, "idx")
-    if idx.numel() != n:
-        raise ValueError("vq_code_sums: one index per row")
+    if rows.dtype not in (torch.float32, torch.bfloat16):
+        raise HipLibraryError(f"rows: expected torch.float32 or torch.bfloat16, got {rows.dtype}")
+    ip = _dev(idx, torch.int64, "idx", n)
     sums = torch.empty(k, c, dtype=torch.float32, device=rows.device)
     counts = torch.empty(k, dtype=torch.int64, device=rows.device)
     nbytes = L.vqseg_kmeans_workspace_bytes(n, c, k)
     ws = _workspace(nbytes, rows.device)
-    with torch.cuda.device(rows.device):
-        rc = L.vqseg_vq_code_sums(int(rows.dtype == torch.bfloat16), rows.data_ptr(), ip, n, c, k, sums.data_ptr(), counts.data_ptr(),
+    with on_device(rows.device):
+        rc = L.vqseg_vq_code_sums(int(rows.dtype == torch.bfloat16), tptr(rows, "rows", bf=int(rows.dtype == torch.bfloat16), numel=n * c), ip, n, c, k, sums.data_ptr(), counts.data_ptr(),
                                   ws.data_ptr(), nbytes, _stream())
     _check(rc, "vqseg_vq_code_sums")
     return sums, counts
@@ -355,7 +406,7 @@ def vq_ema_update(cluster_size: torch.Tensor, embed_avg: torch.Tensor, codebook:
     if cluster_size.shape != (k,) or embed_avg.shape != (k, c) or sums.shape != (k, c) or counts.shape != (k,):
         raise ValueError("vq_ema_update: shapes must be (K,), (K, C), (K, C), (K, C), (K,)")
     scratch = torch.empty(1, dtype=torch.float32, device=codebook.device)
-    with torch.cuda.device(codebook.device):
+    with on_device(codebook.device):
         rc = L.vqseg_vq_ema_update_f32(_dev(cluster_size, torch.float32, "cluster_size"), _dev(embed_avg, torch.float32, "embed_avg"),
                                        _dev(codebook, torch.float32, "codebook"), _dev(sums, torch.float32, "sums"),
                                        _dev(counts, torch.int64, "counts"), c, k, float(decay), float(eps), scratch.data_ptr(),

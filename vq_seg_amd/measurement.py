@@ -73,8 +73,11 @@ def confusion_matrix_device(logits: torch.Tensor, target: torch.Tensor, num_clas
         tgt = target.reshape(b, h * w).long().contiguous()
         out = torch.empty((b, c, c), dtype=torch.int64, device=x.device)
         with torch.cuda.device(x.device):
-            _hip._check(_hip.lib().vqseg_confusion_counts_f(x.data_ptr(), sb, sc, sw, tgt.data_ptr(), b, c, h * w, out.data_ptr(),
-                                                            torch.cuda.current_stream().cuda_stream), "vqseg_confusion_counts_f")
+            from .nnf import _strided_f32
+            _hip._check(_hip.lib().vqseg_confusion_counts_f(_strided_f32(x, "logits", b * c * h * w), sb, sc, sw,
+                                                            _hip.tptr(tgt, "targets", dtype=torch.int64, numel=b * h * w), b, c, h * w,
+                                                            _hip.tptr(out, "confusion counts", dtype=torch.int64, numel=b * c * c),
+                                                            _hip._stream()), "vqseg_confusion_counts_f")
         return out
     cats = num_classes * target.reshape(n, -1).long() + logits.argmax(dim=1).reshape(n, -1)
     cats = cats + (num_classes ** 2) * torch.arange(n, device=cats.device)[:, None]

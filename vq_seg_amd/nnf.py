@@ -40,8 +40,31 @@ def _is_bf16(t: torch.Tensor) -> int:
     raise _hip.HipLibraryError(f"activations must be float32 (precise mode) or bfloat16 (fast mode), got {t.dtype}")
 
 
-def _p(t: Optional[torch.Tensor]):
-    return None if t is None else t.data_ptr()
+_T = _hip.tptr                # every tensor handed to the library goes through this (dtype / density / element count / device checks)
+
+
+def _w16(t, name, numel=None, at_least=False):
+    """packed bf16 weight images travel as int16 tensors"""
+    return _T(t, name, dtype=torch.int16, numel=numel, at_least=at_least)
+
+
+def _f32(t, name, numel=None):
+    return _T(t, name, dtype=torch.float32, numel=numel)
+
+
+def _strided_f32(t, name, numel):
+    """(B, C, H, W) fp32 logits addressed through the explicit (batch, class, pixel) strides passed along (NCHW and NHWC storage both
+    qualify): a valid torch view bounds every such address by construction, so only type, element count and device are checked."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or t.dtype != torch.float32:
+        raise _hip.HipLibraryError(f"{name}: expected a float32 tensor, got {getattr(t, 'dtype', type(t).__name__)}")
+    if t.numel() != numel:
+        raise _hip.HipLibraryError(f"{name}: the sizes passed along need {numel} elements, the tensor has {t.numel()}")
+    if not t.is_cuda:                                        # deferred like _hip.tptr's: the call's other tensors are checked first
+        _hip._NOT_ON_GPU.append(f"{name}: the HIP path needs a tensor on a 'cuda' (ROCm) device; got {t.device}. There is no CPU fallback.")
+        return 0
+    return t.data_ptr()
 
 
 def act_dtype() -> torch.dtype:
@@ -83,9 +106,11 @@ def _pack_all(weight: torch.Tensor, kind):
             imgs["tr"] = torch.empty(cin * k * k * cout_p, dtype=torch.int16, device=w.device)
         if s3k is not None:
             imgs[s3k] = torch.empty(cout * k * k * 3 * cin, dtype=torch.int16, device=w.device)
-        with torch.cuda.device(w.device):
-            _check(lib().vqseg_conv_pack_all_f32(_dev(w, torch.float32, "weight"), cout, cin, k, s3k[1] if s3k is not None else cin,
-                                                 _p(imgs.get("fwd")), _p(imgs.get("tr")), _p(imgs.get(s3k)) if s3k is not None else None,
+        with _hip.on_device(w.device):
+            _check(lib().vqseg_conv_pack_all_f32(_f32(w, "weight", cout * cin * k * k), cout, cin, k, s3k[1] if s3k is not None else cin,
+                                                 _w16(imgs.get("fwd"), "fwd image", cout * k * k * cin_p),
+                                                 _w16(imgs.get("tr"), "transposed image", cin * k * k * cout_p),
+                                                 _w16(imgs.get(s3k), "split-3 image", cout * k * k * 3 * cin) if s3k is not None else None,
                                                  _stream()), "vqseg_conv_pack_all_f32")
         cache["all"] = imgs
     return imgs[kind]
@@ -107,9 +132,9 @@ def packed_weights(weight: torch.Tensor, precise: bool, transpose_flip: bool):
         n = lib().vqseg_conv_packed_elems(cout, cin, kh, kw, int(transpose_flip))
         hi = torch.empty(n, dtype=torch.int16, device=w.device)
         lo = torch.empty(n, dtype=torch.int16, device=w.device) if precise else None
-        with torch.cuda.device(w.device):
-            _check(lib().vqseg_conv_pack_weights_f32(_dev(w, torch.float32, "weight"), cout, cin, kh, kw, int(transpose_flip),
-                                                     hi.data_ptr(), _p(lo), _stream()), "vqseg_conv_pack_weights_f32")
+        with _hip.on_device(w.device):
+            _check(lib().vqseg_conv_pack_weights_f32(_f32(w, "weight", cout * cin * kh * kw), cout, cin, kh, kw, int(transpose_flip),
+                                                     _w16(hi, "packed hi", n), _w16(lo, "packed lo", n), _stream()), "vqseg_conv_pack_weights_f32")
         cache[k] = (hi, lo)
     return cache[k]
 
@@ -119,11 +144,15 @@ def _conv_raw(x_rows, x2_rows, c1, w_hi, w_lo, out_shape, stat, n, h, w, cin, co
     precise = x_rows.dtype == torch.float32
     y = torch.empty(out_shape, dtype=x_rows.dtype, device=x_rows.device)
     esz = 2
-    with torch.cuda.device(x_rows.device):
-        rc = lib().vqseg_conv2d_f(x_rows.data_ptr(), _p(x2_rows), c1, w_hi.data_ptr() + w_offset_elems * esz,
-                                  (w_lo.data_ptr() + w_offset_elems * esz) if w_lo is not None else None, y.data_ptr(),
-                                  _p(stat), n, h, w, cin, cout, kh, kw, stride, pad, int(reflect), up, ho, wo, int(precise),
-                                  _stream())
+    bfa = 0 if precise else 1
+    wneed = w_offset_elems + cout * kh * kw * ((cin + 31) // 32 * 32)        # the [Cout][KH][KW][Cin ^ 32] slice the kernel reads
+    with _hip.on_device(x_rows.device):
+        rc = lib().vqseg_conv2d_f(_T(x_rows, "conv input", bf=bfa, numel=n * h * w * c1), _T(x2_rows, "conv input 2", bf=bfa, numel=n * h * w * (cin - c1)),
+                                  c1, _w16(w_hi, "packed weights", wneed, at_least=True) + w_offset_elems * esz,
+                                  (_w16(w_lo, "packed weights (lo)", wneed, at_least=True) + w_offset_elems * esz) if w_lo is not None else None,
+                                  _T(y, "conv output", bf=bfa, numel=n * ho * wo * cout),
+                                  _f32(stat, "BN partials", lib().vqseg_conv_stat_slots(n * ho * wo, cout) * 2 * cout if stat is not None else None),
+                                  n, h, w, cin, cout, kh, kw, stride, pad, int(reflect), up, ho, wo, int(precise), _stream())
     _check(rc, "vqseg_conv2d_f")
     return y
 
@@ -225,8 +254,9 @@ class S3:
         """merge back: logical (N, C, H, W) fp32 tensor (channels_last in memory)"""
         n, h, w, _ = self.rows.shape
         out = torch.empty((n, h, w, self.c), dtype=torch.float32, device=self.rows.device)
-        with torch.cuda.device(out.device):
-            _check(lib().vqseg_s3_merge_f(self.rows.data_ptr(), n * h * w, self.c, out.data_ptr(), _stream()), "vqseg_s3_merge_f")
+        with _hip.on_device(out.device):
+            _check(lib().vqseg_s3_merge_f(_T(self.rows, "split-3 rows", bf=2, numel=n * h * w * 2 * self.c), n * h * w, self.c,
+                                          _f32(out, "merged rows", n * h * w * self.c), _stream()), "vqseg_s3_merge_f")
         return _nchw(out)
 
 
@@ -259,8 +289,9 @@ def to_s3(x) -> "S3":
     xr = _rows(x.float())
     n, h, w, c = xr.shape
     out = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=xr.device)
-    with torch.cuda.device(xr.device):
-        _check(lib().vqseg_s3_split_f(xr.data_ptr(), n * h * w, c, out.data_ptr(), _stream()), "vqseg_s3_split_f")
+    with _hip.on_device(xr.device):
+        _check(lib().vqseg_s3_split_f(_f32(xr, "rows", n * h * w * c), n * h * w, c, _T(out, "split-3 rows", bf=2, numel=n * h * w * 2 * c), _stream()),
+               "vqseg_s3_split_f")
     return S3(out, c)
 
 
@@ -286,8 +317,9 @@ def _s3_weights(weight: torch.Tensor, c1: int, as_1x1_cols: int = 0) -> torch.Te
         w = w if w.is_contiguous() else w.contiguous()
         cout, cin, kh, kw = w.shape
         out = torch.empty(cout * kh * kw * 3 * cin, dtype=torch.int16, device=w.device)
-        with torch.cuda.device(w.device):
-            _check(lib().vqseg_conv_pack_weights_s3_f32(_dev(w, torch.float32, "weight"), cout, cin, c1, kh, kw, out.data_ptr(), _stream()),
+        with _hip.on_device(w.device):
+            _check(lib().vqseg_conv_pack_weights_s3_f32(_f32(w, "weight", cout * cin * kh * kw), cout, cin, c1, kh, kw,
+                                                        _w16(out, "split-3 image", cout * kh * kw * 3 * cin), _stream()),
                    "vqseg_conv_pack_weights_s3_f32")
         cache[k] = out
     return cache[k]
@@ -314,13 +346,19 @@ def _conv_bn_act_s3(x: "S3", x2, residual, conv, bn, relu, kernel_1x1_cols: int 
     res = to_s3(residual) if residual is not None else None
     coef = torch.empty(4, cout, dtype=torch.float32, device=dev)
     out = torch.empty((n, ho, wo, 2 * cout), dtype=torch.bfloat16, device=dev)
-    with torch.cuda.device(dev):
-        _check(L.vqseg_bn_finalize_f(None, n * ho * wo, cout, _dev(bn.weight, torch.float32, "bn.weight"), _dev(bn.bias, torch.float32, "bn.bias"),
-                                     _p(bn.running_mean), _p(bn.running_var), float(bn.momentum), float(bn.eps), 0, coef[0].data_ptr(),
-                                     coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), None, _stream()), "vqseg_bn_finalize_f")
-        _check(L.vqseg_conv2d_affine_f(x.rows.data_ptr(), x2s.rows.data_ptr() if x2s is not None else None, c1, wimg.data_ptr(), None,
-                                       coef[0].data_ptr(), coef[1].data_ptr(), res.rows.data_ptr() if res is not None else None, int(relu),
-                                       out.data_ptr(), n, h, w, cin, cout, kh, kw, stride, pad, int(reflect), ho, wo, 2, _stream()),
+    with _hip.on_device(dev):
+        _check(L.vqseg_bn_finalize_f(None, n * ho * wo, cout, _f32(bn.weight, "bn.weight", cout), _f32(bn.bias, "bn.bias", cout),
+                                     _f32(bn.running_mean, "bn.running_mean", cout), _f32(bn.running_var, "bn.running_var", cout),
+                                     float(bn.momentum), float(bn.eps), 0, _f32(coef[0], "scale", cout),
+                                     _f32(coef[1], "shift", cout), _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout), None, _stream()),
+               "vqseg_bn_finalize_f")
+        _check(L.vqseg_conv2d_affine_f(_T(x.rows, "split-3 input", bf=2, numel=n * h * w * 2 * c1),
+                                       _T(x2s.rows, "split-3 input 2", bf=2, numel=n * h * w * 2 * (cin - c1)) if x2s is not None else None, c1,
+                                       _w16(wimg, "split-3 image", cout * kh * kw * 3 * cin), None,
+                                       _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout),
+                                       _T(res.rows, "split-3 residual", bf=2, numel=n * ho * wo * 2 * cout) if res is not None else None, int(relu),
+                                       _T(out, "split-3 output", bf=2, numel=n * ho * wo * 2 * cout), n, h, w, cin, cout, kh, kw, stride, pad,
+                                       int(reflect), ho, wo, 2, _stream()),
                "vqseg_conv2d_affine_f (split-3)")
     return S3(out, cout)
 
@@ -361,31 +399,37 @@ class _ConvBNAct(torch.autograd.Function):
             if rr is not None and rr.dtype != xr.dtype:
                 raise _hip.HipLibraryError("residual dtype differs from the activation dtype")
             out = torch.empty((n, ho, wo, cout), dtype=xr.dtype, device=dev)
-            with torch.cuda.device(dev):
-                _check(L.vqseg_bn_finalize_f(None, m, cout, _dev(gamma, torch.float32, "bn.weight"),
-                                             _dev(beta, torch.float32, "bn.bias"), _p(bn.running_mean), _p(bn.running_var),
-                                             float(bn.momentum), float(bn.eps), 0, coef[0].data_ptr(), coef[1].data_ptr(),
-                                             coef[2].data_ptr(), coef[3].data_ptr(), None, _stream()), "vqseg_bn_finalize_f")
-                _check(L.vqseg_conv2d_affine_f(xr.data_ptr(), _p(x2r), c1, w_hi.data_ptr(), _p(w_lo), coef[0].data_ptr(),
-                                               coef[1].data_ptr(), _p(rr), int(relu), out.data_ptr(), n, h, w, cin, cout, kh, kw,
-                                               stride, pad, int(reflect), ho, wo, int(precise), _stream()), "vqseg_conv2d_affine_f")
+            wneed = cout * kh * kw * ((cin + 31) // 32 * 32)
+            with _hip.on_device(dev):
+                _check(L.vqseg_bn_finalize_f(None, m, cout, _f32(gamma, "bn.weight", cout), _f32(beta, "bn.bias", cout),
+                                             _f32(bn.running_mean, "bn.running_mean", cout), _f32(bn.running_var, "bn.running_var", cout),
+                                             float(bn.momentum), float(bn.eps), 0, _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout),
+                                             _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout), None, _stream()), "vqseg_bn_finalize_f")
+                _check(L.vqseg_conv2d_affine_f(_T(xr, "conv input", bf=bf, numel=n * h * w * c1), _T(x2r, "conv input 2", bf=bf, numel=n * h * w * (cin - c1)),
+                                               c1, _w16(w_hi, "packed weights", wneed), _w16(w_lo, "packed weights (lo)", wneed),
+                                               _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout),
+                                               _T(rr, "residual", bf=bf, numel=m * cout), int(relu), _T(out, "conv output", bf=bf, numel=m * cout),
+                                               n, h, w, cin, cout, kh, kw, stride, pad, int(reflect), ho, wo, int(precise), _stream()),
+                       "vqseg_conv2d_affine_f")
             return _nchw(out)
         stat = torch.empty(L.vqseg_conv_stat_slots(m, cout) * 2 * cout, dtype=torch.float32, device=dev) if training else None
         y = _conv_raw(xr, x2r, c1, w_hi, w_lo, (n, ho, wo, cout), stat, n, h, w, cin, cout, kh, kw, stride, pad, reflect, 1,
                       ho, wo)
-        with torch.cuda.device(dev):
-            _check(L.vqseg_bn_finalize_f(_p(stat), m, cout, _dev(gamma, torch.float32, "bn.weight"),
-                                         _dev(beta, torch.float32, "bn.bias"), _p(bn.running_mean), _p(bn.running_var),
-                                         float(bn.momentum), float(bn.eps), int(training), coef[0].data_ptr(),
-                                         coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
-                                         _p(bn.num_batches_tracked) if training else None, _stream()),   # += 1 in the kernel
+        with _hip.on_device(dev):
+            _check(L.vqseg_bn_finalize_f(_f32(stat, "BN partials"), m, cout, _f32(gamma, "bn.weight", cout), _f32(beta, "bn.bias", cout),
+                                         _f32(bn.running_mean, "bn.running_mean", cout), _f32(bn.running_var, "bn.running_var", cout),
+                                         float(bn.momentum), float(bn.eps), int(training), _f32(coef[0], "scale", cout),
+                                         _f32(coef[1], "shift", cout), _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout),
+                                         _T(bn.num_batches_tracked, "bn.num_batches_tracked", dtype=torch.int64, numel=1) if training else None,
+                                         _stream()),   # += 1 in the kernel
                    "vqseg_bn_finalize_f")
             rr = _rows(residual) if residual is not None else None
             if rr is not None and rr.dtype != y.dtype:
                 raise _hip.HipLibraryError("residual dtype differs from the activation dtype")
             out = torch.empty_like(y)
-            _check(L.vqseg_bn_apply_f(bf, y.data_ptr(), _p(rr), coef[0].data_ptr(), coef[1].data_ptr(), m, cout, int(relu),
-                                      out.data_ptr(), _stream()), "vqseg_bn_apply_f")
+            _check(L.vqseg_bn_apply_f(bf, _T(y, "conv output", bf=bf, numel=m * cout), _T(rr, "residual", bf=bf, numel=m * cout),
+                                      _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout), m, cout, int(relu),
+                                      _T(out, "BN output", bf=bf, numel=m * cout), _stream()), "vqseg_bn_apply_f")
         ctx.save_for_backward(xr, x2r, y, out, coef, weight, gamma)
         ctx.params = (weight, gamma, beta)                                  # the Parameter objects (see grad sinks)
         ctx.links = (link_in, link_out, link_x)
@@ -413,12 +457,14 @@ class _ConvBNAct(torch.autograd.Function):
         sink_w = _sink_ready(p_w) and ctx.needs_input_grad[3]
         dgb = None if sink_bn else torch.empty(2, cout, dtype=torch.float32, device=dev)
         dgamma, dbeta = (p_g.grad, p_b.grad) if sink_bn else (dgb[0], dgb[1])
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             # without a residual the ReLU mask is recomputed from y with the forward's scale / shift: `out` is not re-read
-            _check(L.vqseg_bn_backward_f(bf, g.data_ptr(), out.data_ptr() if has_res else None, y.data_ptr(), coef[2].data_ptr(),
-                                         coef[3].data_ptr(), _dev(gamma.detach(), torch.float32, "bn.weight"),
-                                         coef[0].data_ptr(), coef[1].data_ptr(), m, cout, int(relu), int(training), int(sink_bn),
-                                         ws.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), g_y.data_ptr(), _p(g_res),
+            _check(L.vqseg_bn_backward_f(bf, _T(g, "output gradient", bf=bf, numel=m * cout),
+                                         _T(out, "BN output", bf=bf, numel=m * cout) if has_res else None, _T(y, "conv output", bf=bf, numel=m * cout),
+                                         _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout), _f32(gamma.detach(), "bn.weight", cout),
+                                         _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout), m, cout, int(relu), int(training), int(sink_bn),
+                                         _f32(ws, "BN backward workspace"), _f32(dgamma, "bn.weight.grad", cout), _f32(dbeta, "bn.bias.grad", cout),
+                                         _T(g_y, "conv output gradient", bf=bf, numel=m * cout), _T(g_res, "residual gradient", bf=bf, numel=m * cout),
                                          _stream()), "vqseg_bn_backward_f")
         if sink_bn:
             _sink_done(p_g), _sink_done(p_b)
@@ -431,17 +477,21 @@ class _ConvBNAct(torch.autograd.Function):
             okh, okw, ocin = patches_of[0], patches_of[1], patches_of[2]
             nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, 1, 1)
             wsw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            with torch.cuda.device(dev):
-                _check(L.vqseg_conv2d_wgrad_f(g_y.data_ptr(), xr.data_ptr(), None, cin, n, h, w, cin, ho, wo, cout, okh, okw, 1, 0,
-                                              0, int(precise), ocin, 1, int(sink_w), wsw.data_ptr(), nbytes, gw.data_ptr(), _stream()),
+            with _hip.on_device(dev):
+                _check(L.vqseg_conv2d_wgrad_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), _T(xr, "stem patches", bf=bf, numel=n * h * w * cin),
+                                              None, cin, n, h, w, cin, ho, wo, cout, okh, okw, 1, 0, 0, int(precise), ocin, 1, int(sink_w),
+                                              _T(wsw, "wgrad workspace", dtype=torch.uint8, numel=nbytes), nbytes,
+                                              _f32(gw, "weight gradient", cout * ocin * okh * okw), _stream()),
                        "vqseg_conv2d_wgrad_f")
         else:
             nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, kh, kw)
             wsw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            with torch.cuda.device(dev):
-                _check(L.vqseg_conv2d_wgrad_f(g_y.data_ptr(), xr.data_ptr(), _p(x2r), c1, n, h, w, cin, ho, wo, cout, kh, kw,
-                                              stride, pad, int(reflect), int(precise), cin, 0, int(sink_w), wsw.data_ptr(), nbytes,
-                                              gw.data_ptr(), _stream()), "vqseg_conv2d_wgrad_f")
+            with _hip.on_device(dev):
+                _check(L.vqseg_conv2d_wgrad_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), _T(xr, "conv input", bf=bf, numel=n * h * w * c1),
+                                              _T(x2r, "conv input 2", bf=bf, numel=n * h * w * (cin - c1)), c1, n, h, w, cin, ho, wo, cout, kh, kw,
+                                              stride, pad, int(reflect), int(precise), cin, 0, int(sink_w),
+                                              _T(wsw, "wgrad workspace", dtype=torch.uint8, numel=nbytes), nbytes,
+                                              _f32(gw, "weight gradient", cout * cin * kh * kw), _stream()), "vqseg_conv2d_wgrad_f")
         if sink_w:
             _sink_done(p_w)
         # ---- data gradient(s): the same implicit-GEMM kernel on g_y with tap-flipped, transposed weights
@@ -464,9 +514,13 @@ class _ConvBNAct(torch.autograd.Function):
                     # the data gradient and the residual-branch gradient meet in the convolution's epilogue (one add pass less)
                     one, zero = _unit_affine(dev, c_cnt)
                     gp = torch.empty((n, hp, wp, c_cnt), dtype=g_y.dtype, device=dev)
-                    with torch.cuda.device(dev):
-                        _check(L.vqseg_conv2d_affine_f(g_y.data_ptr(), None, cout, t_hi.data_ptr(), _p(t_lo), one.data_ptr(),
-                                                       zero.data_ptr(), extra.data_ptr(), 0, gp.data_ptr(), n, ho, wo, cout, c_cnt,
+                    with _hip.on_device(dev):
+                        tneed = c_cnt * kh * kw * ((cout + 31) // 32 * 32)
+                        _check(L.vqseg_conv2d_affine_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), None, cout,
+                                                       _w16(t_hi, "transposed image", tneed), _w16(t_lo, "transposed image (lo)", tneed),
+                                                       _f32(one, "unit scale", c_cnt), _f32(zero, "zero shift", c_cnt),
+                                                       _T(extra, "shortcut gradient", bf=bf, numel=n * hp * wp * c_cnt), 0,
+                                                       _T(gp, "input gradient", bf=bf, numel=n * hp * wp * c_cnt), n, ho, wo, cout, c_cnt,
                                                        kh, kw, 1, dpad, 0, hp, wp, int(precise), _stream()), "vqseg_conv2d_affine_f")
                     extra = None
                     return gp
@@ -475,9 +529,11 @@ class _ConvBNAct(torch.autograd.Function):
                     s_hi, s_lo = _s2_weights(weight, precise)
                     gh, gw_ = (h + 2, w + 2) if kh == 3 else (h, w)          # k = 3: the padded input's grid
                     gp = torch.empty((n, gh, gw_, c_cnt), dtype=g_y.dtype, device=dev)
-                    with torch.cuda.device(dev):
-                        _check(L.vqseg_conv2d_dgrad_s2_f(g_y.data_ptr(), s_hi.data_ptr(), _p(s_lo), gp.data_ptr(), n, ho, wo, cout, c_cnt, kh,
-                                                         gh, gw_, int(precise), _stream()), "vqseg_conv2d_dgrad_s2_f")
+                    with _hip.on_device(dev):
+                        sneed = L.vqseg_conv_packed_s2_elems(cout, c_cnt, kh)
+                        _check(L.vqseg_conv2d_dgrad_s2_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), _w16(s_hi, "parity-class image", sneed),
+                                                         _w16(s_lo, "parity-class image (lo)", sneed), _T(gp, "input gradient", bf=bf, numel=n * gh * gw_ * c_cnt),
+                                                         n, ho, wo, cout, c_cnt, kh, gh, gw_, int(precise), _stream()), "vqseg_conv2d_dgrad_s2_f")
                     if kh == 3 and not reflect:                              # zero padding: the gradient of the padded border is dropped
                         return gp[:, 1:h + 1, 1:w + 1, :].contiguous()
                 else:
@@ -488,9 +544,9 @@ class _ConvBNAct(torch.autograd.Function):
                 if pad != 1:
                     raise NotImplementedError("reflect-padding data gradient is implemented for pad == 1")
                 gxx = torch.empty((n, h, w, c_cnt), dtype=gp.dtype, device=dev)
-                with torch.cuda.device(dev):
-                    _check(L.vqseg_reflect_fold_f(bf, gp.data_ptr(), n, h, w, c_cnt, gxx.data_ptr(), _stream()),
-                           "vqseg_reflect_fold_f")
+                with _hip.on_device(dev):
+                    _check(L.vqseg_reflect_fold_f(bf, _T(gp, "padded input gradient", bf=bf, numel=n * (h + 2) * (w + 2) * c_cnt), n, h, w, c_cnt,
+                                                  _T(gxx, "input gradient", bf=bf, numel=n * h * w * c_cnt), _stream()), "vqseg_reflect_fold_f")
                 return gxx
 
             if need1:
@@ -520,8 +576,9 @@ def _s2_weights(weight, precise):
         nel = lib().vqseg_conv_packed_s2_elems(cout, cin, kh)
         hi = torch.empty(nel, dtype=torch.int16, device=w.device)
         lo = torch.empty(nel, dtype=torch.int16, device=w.device) if precise else None
-        with torch.cuda.device(w.device):
-            _check(lib().vqseg_conv_pack_weights_s2_f32(_dev(w, torch.float32, "weight"), cout, cin, kh, hi.data_ptr(), _p(lo), _stream()),
+        with _hip.on_device(w.device):
+            _check(lib().vqseg_conv_pack_weights_s2_f32(_f32(w, "weight", cout * cin * kh * kh), cout, cin, kh, _w16(hi, "parity-class image", nel),
+                                                        _w16(lo, "parity-class image (lo)", nel), _stream()),
                    "vqseg_conv_pack_weights_s2_f32")
         cache[k] = (hi, lo)
     return cache[k]
@@ -613,9 +670,9 @@ def stem_conv_bn_act(x, conv, bn):
 
         def make3():
             out = torch.empty((n, ho, wo, 2 * kp3), dtype=torch.bfloat16, device=x.device)
-            with torch.cuda.device(x.device):
-                _check(lib().vqseg_im2col_f(2, xr.data_ptr(), n, h, w, cin, kh, kw, s, p, int(reflect), ho, wo, kp3, out.data_ptr(), _stream()),
-                       "vqseg_im2col_f (split-3)")
+            with _hip.on_device(x.device):
+                _check(lib().vqseg_im2col_f(2, _f32(xr, "image", n * h * w * cin), n, h, w, cin, kh, kw, s, p, int(reflect), ho, wo, kp3,
+                                            _T(out, "split-3 patches", bf=2, numel=n * ho * wo * 2 * kp3), _stream()), "vqseg_im2col_f (split-3)")
             return out
 
         patches = _shared_stem_patches(x, ("s3", kh, kw, s, p, reflect), make3)
@@ -623,9 +680,9 @@ def stem_conv_bn_act(x, conv, bn):
 
     def make():
         out = torch.empty((n, ho, wo, kp), dtype=dt, device=x.device)
-        with torch.cuda.device(x.device):
-            _check(lib().vqseg_im2col_f(int(dt == torch.bfloat16), xr.data_ptr(), n, h, w, cin, kh, kw, s, p, int(reflect), ho, wo, kp,
-                                        out.data_ptr(), _stream()), "vqseg_im2col_f")
+        with _hip.on_device(x.device):
+            _check(lib().vqseg_im2col_f(int(dt == torch.bfloat16), _f32(xr, "image", n * h * w * cin), n, h, w, cin, kh, kw, s, p, int(reflect), ho, wo, kp,
+                                        _T(out, "patches", bf=int(dt == torch.bfloat16), numel=n * ho * wo * kp), _stream()), "vqseg_im2col_f")
         return out
 
     patches = _shared_stem_patches(x, (dt, kh, kw, s, p, reflect), make)
@@ -643,9 +700,11 @@ class _MaxPool(torch.autograd.Function):
         ho, wo = _out_size(h, 3, 2, 1), _out_size(w, 3, 2, 1)
         y = torch.empty((n, ho, wo, c), dtype=xr.dtype, device=xr.device)
         idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=xr.device) if ctx.needs_input_grad[0] else None
-        with torch.cuda.device(xr.device):
-            _check(lib().vqseg_maxpool3x3s2_f(_is_bf16(xr), 0, xr.data_ptr(), None, n, h, w, c, y.data_ptr(), _p(idx), _stream()),
-                   "vqseg_maxpool3x3s2_f")
+        with _hip.on_device(xr.device):
+            bf = _is_bf16(xr)
+            _check(lib().vqseg_maxpool3x3s2_f(bf, 0, _T(xr, "pool input", bf=bf, numel=n * h * w * c), None, n, h, w, c,
+                                              _T(y, "pool output", bf=bf, numel=n * ho * wo * c),
+                                              _T(idx, "pool argmax", dtype=torch.uint8, numel=n * ho * wo * c), _stream()), "vqseg_maxpool3x3s2_f")
         ctx.save_for_backward(idx)                          # window position of every maximum: the input is not kept
         ctx.cfg = (n, h, w, c, xr.dtype)
         return _nchw(y)
@@ -656,9 +715,11 @@ class _MaxPool(torch.autograd.Function):
         n, h, w, c, dt = ctx.cfg
         gr = _rows(g).to(dt)
         gx = torch.empty((n, h, w, c), dtype=dt, device=gr.device)
-        with torch.cuda.device(gr.device):
-            _check(lib().vqseg_maxpool3x3s2_f(int(dt == torch.bfloat16), 1, None, gr.data_ptr(), n, h, w, c, gx.data_ptr(),
-                                              idx.data_ptr(), _stream()), "vqseg_maxpool3x3s2_f")
+        bf = int(dt == torch.bfloat16)
+        with _hip.on_device(gr.device):
+            _check(lib().vqseg_maxpool3x3s2_f(bf, 1, None, _T(gr, "pool output gradient", bf=bf, numel=idx.numel()), n, h, w, c,
+                                              _T(gx, "pool input gradient", bf=bf, numel=n * h * w * c),
+                                              _T(idx, "pool argmax", dtype=torch.uint8), _stream()), "vqseg_maxpool3x3s2_f")
         return _nchw(gx)
 
 
@@ -667,8 +728,9 @@ def max_pool_3x3_s2(x):
         n, h, w, _ = x.rows.shape
         ho, wo = _out_size(h, 3, 2, 1), _out_size(w, 3, 2, 1)
         y = torch.empty((n, ho, wo, 2 * x.c), dtype=torch.bfloat16, device=x.rows.device)
-        with torch.cuda.device(y.device):
-            _check(lib().vqseg_s3_maxpool3x3s2_f(x.rows.data_ptr(), n, h, w, x.c, y.data_ptr(), _stream()), "vqseg_s3_maxpool3x3s2_f")
+        with _hip.on_device(y.device):
+            _check(lib().vqseg_s3_maxpool3x3s2_f(_T(x.rows, "split-3 pool input", bf=2, numel=n * h * w * 2 * x.c), n, h, w, x.c,
+                                                 _T(y, "split-3 pool output", bf=2, numel=n * ho * wo * 2 * x.c), _stream()), "vqseg_s3_maxpool3x3s2_f")
         return S3(y, x.c)
     return _MaxPool.apply(x)
 
@@ -679,9 +741,10 @@ class _Bilinear(torch.autograd.Function):
         xr = _rows(x)
         n, h, w, c = xr.shape
         y = torch.empty((n, ho, wo, c), dtype=xr.dtype, device=xr.device)
-        with torch.cuda.device(xr.device):
-            _check(lib().vqseg_bilinear_f(_is_bf16(xr), 0, xr.data_ptr(), n, h, w, c, ho, wo, int(align), y.data_ptr(), _stream()),
-                   "vqseg_bilinear_f")
+        with _hip.on_device(xr.device):
+            bf = _is_bf16(xr)
+            _check(lib().vqseg_bilinear_f(bf, 0, _T(xr, "resize input", bf=bf, numel=n * h * w * c), n, h, w, c, ho, wo, int(align),
+                                          _T(y, "resize output", bf=bf, numel=n * ho * wo * c), _stream()), "vqseg_bilinear_f")
         ctx.cfg = (n, h, w, c, ho, wo, int(align), xr.dtype)
         return _nchw(y)
 
@@ -690,9 +753,10 @@ class _Bilinear(torch.autograd.Function):
         n, h, w, c, ho, wo, align, dt = ctx.cfg
         gr = _rows(g).to(dt)
         gx = torch.empty((n, h, w, c), dtype=dt, device=gr.device)
-        with torch.cuda.device(gr.device):
-            _check(lib().vqseg_bilinear_f(int(dt == torch.bfloat16), 1, gr.data_ptr(), n, h, w, c, ho, wo, align, gx.data_ptr(),
-                                          _stream()), "vqseg_bilinear_f")
+        with _hip.on_device(gr.device):
+            bf = int(dt == torch.bfloat16)
+            _check(lib().vqseg_bilinear_f(bf, 1, _T(gr, "resize output gradient", bf=bf, numel=n * ho * wo * c), n, h, w, c, ho, wo, align,
+                                          _T(gx, "resize input gradient", bf=bf, numel=n * h * w * c), _stream()), "vqseg_bilinear_f")
         return _nchw(gx), None, None, None
 
 
@@ -702,9 +766,9 @@ def upsample_bilinear(x, size=None, scale_factor=None, align_corners=False):
     if isinstance(x, S3):
         n, h, w, _ = x.rows.shape
         y = torch.empty((n, int(size[0]), int(size[1]), 2 * x.c), dtype=torch.bfloat16, device=x.rows.device)
-        with torch.cuda.device(y.device):
-            _check(lib().vqseg_s3_bilinear_f(x.rows.data_ptr(), n, h, w, x.c, int(size[0]), int(size[1]), int(bool(align_corners)),
-                                             y.data_ptr(), _stream()), "vqseg_s3_bilinear_f")
+        with _hip.on_device(y.device):
+            _check(lib().vqseg_s3_bilinear_f(_T(x.rows, "split-3 resize input", bf=2, numel=n * h * w * 2 * x.c), n, h, w, x.c, int(size[0]), int(size[1]),
+                                             int(bool(align_corners)), _T(y, "split-3 resize output", bf=2, numel=y.numel()), _stream()), "vqseg_s3_bilinear_f")
         return S3(y, x.c)
     return _Bilinear.apply(x, int(size[0]), int(size[1]), bool(align_corners))
 
@@ -719,9 +783,10 @@ class _Head1x1(torch.autograd.Function):
         cout = weight.shape[0]
         wt = weight.detach().reshape(cout, cin).contiguous()
         y = torch.empty((n, h, w, cout), dtype=torch.float32, device=xr.device)
-        with torch.cuda.device(xr.device):
-            _check(lib().vqseg_head1x1_forward_f(_is_bf16(xr), xr.data_ptr(), _dev(wt, torch.float32, "head weight"), n * h * w, cin,
-                                                 cout, y.data_ptr(), _stream()), "vqseg_head1x1_forward_f")
+        with _hip.on_device(xr.device):
+            bf = _is_bf16(xr)
+            _check(lib().vqseg_head1x1_forward_f(bf, _T(xr, "head input", bf=bf, numel=n * h * w * cin), _f32(wt, "head weight", cout * cin), n * h * w, cin,
+                                                 cout, _f32(y, "logits", n * h * w * cout), _stream()), "vqseg_head1x1_forward_f")
         ctx.save_for_backward(xr, wt)
         return _nchw(y)
 
@@ -735,9 +800,11 @@ class _Head1x1(torch.autograd.Function):
         gx = torch.empty_like(xr)
         gw = torch.empty((cout, cin), dtype=torch.float32, device=xr.device)
         ws = torch.empty(lib().vqseg_head1x1_backward_workspace_floats(m, cin, cout), dtype=torch.float32, device=xr.device)
-        with torch.cuda.device(xr.device):
-            _check(lib().vqseg_head1x1_backward_f(_is_bf16(xr), xr.data_ptr(), wt.data_ptr(), gr.data_ptr(), m, cin, cout, gx.data_ptr(),
-                                                  gw.data_ptr(), ws.data_ptr(), _stream()), "vqseg_head1x1_backward_f")
+        with _hip.on_device(xr.device):
+            bf = _is_bf16(xr)
+            _check(lib().vqseg_head1x1_backward_f(bf, _T(xr, "head input", bf=bf, numel=m * cin), _f32(wt, "head weight", cout * cin),
+                                                  _f32(gr, "logit gradient", m * cout), m, cin, cout, _T(gx, "head input gradient", bf=bf, numel=m * cin),
+                                                  _f32(gw, "head weight gradient", cout * cin), _f32(ws, "head workspace"), _stream()), "vqseg_head1x1_backward_f")
         return _nchw(gx), gw.reshape(cout, cin, 1, 1)
 
 
@@ -747,9 +814,9 @@ def head_conv1x1(x, weight):
         cout = weight.shape[0]
         wt = weight.detach().reshape(cout, x.c).contiguous()
         y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.rows.device)
-        with torch.cuda.device(y.device):
-            _check(lib().vqseg_head1x1_forward_f(2, x.rows.data_ptr(), _dev(wt, torch.float32, "head weight"), n * h * w, x.c, cout, y.data_ptr(),
-                                                 _stream()), "vqseg_head1x1_forward_f")
+        with _hip.on_device(y.device):
+            _check(lib().vqseg_head1x1_forward_f(2, _T(x.rows, "split-3 head input", bf=2, numel=n * h * w * 2 * x.c), _f32(wt, "head weight", cout * x.c),
+                                                 n * h * w, x.c, cout, _f32(y, "logits", n * h * w * cout), _stream()), "vqseg_head1x1_forward_f")
         return _nchw(y)
     return _Head1x1.apply(from_s3(x), weight)
 
@@ -762,8 +829,10 @@ class _Cast(torch.autograd.Function):
             return x
         xr = _rows(x)
         y = torch.empty(xr.shape, dtype=dtype, device=xr.device)
-        with torch.cuda.device(xr.device):
-            _check(lib().vqseg_cast_f(int(dtype == torch.bfloat16), xr.data_ptr(), xr.numel(), y.data_ptr(), _stream()), "vqseg_cast_f")
+        with _hip.on_device(xr.device):
+            to_bf = int(dtype == torch.bfloat16)
+            _check(lib().vqseg_cast_f(to_bf, _T(xr, "cast input", bf=1 - to_bf), xr.numel(), _T(y, "cast output", bf=to_bf, numel=xr.numel()), _stream()),
+                   "vqseg_cast_f")
         return _nchw(y)
 
     @staticmethod
@@ -799,10 +868,13 @@ class _ProtoLoss(torch.autograd.Function):
         nbytes = L.vqseg_proto_loss_workspace_bytes(m, c, k)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xr.device)
         loss = torch.empty((), dtype=torch.float64, device=xr.device)
-        with torch.cuda.device(xr.device):
-            _check(L.vqseg_proto_loss_forward_f(_is_bf16(xr), xr.data_ptr(), proto.data_ptr(), labels.data_ptr(), _p(keep), _p(conf),
-                                                m, c, k, variant, float(scale), float(margin), int(easy_margin), ws.data_ptr(), nbytes,
-                                                loss.data_ptr(), _stream()), "vqseg_proto_loss_forward_f")
+        with _hip.on_device(xr.device):
+            bf = _is_bf16(xr)
+            _check(L.vqseg_proto_loss_forward_f(bf, _T(xr, "decoder features", bf=bf, numel=m * c), _f32(proto, "prototypes", k * c),
+                                                _T(labels, "labels", dtype=torch.int64, numel=m), _T(keep, "keep mask", dtype=torch.uint8, numel=m),
+                                                _f32(conf, "confidence", m), m, c, k, variant, float(scale), float(margin), int(easy_margin),
+                                                _T(ws, "workspace", dtype=torch.uint8, numel=nbytes), nbytes,
+                                                _T(loss, "loss", dtype=torch.float64, numel=1), _stream()), "vqseg_proto_loss_forward_f")
         ctx.save_for_backward(xr, proto, labels, keep, conf)
         ctx.cfg = (m, c, k, variant, float(scale), float(margin), int(easy_margin))
         return loss
@@ -817,10 +889,13 @@ class _ProtoLoss(torch.autograd.Function):
         gproto = torch.empty_like(proto) if ctx.needs_input_grad[1] else None
         nbytes = L.vqseg_proto_loss_workspace_bytes(m, c, k)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xr.device)
-        with torch.cuda.device(xr.device):
-            _check(L.vqseg_proto_loss_backward_f(_is_bf16(xr), xr.data_ptr(), proto.data_ptr(), labels.data_ptr(), _p(keep), _p(conf),
-                                                 m, c, k, variant, scale, margin, easy, g32.data_ptr(), gx.data_ptr(), _p(gproto),
-                                                 ws.data_ptr(), nbytes, _stream()), "vqseg_proto_loss_backward_f")
+        with _hip.on_device(xr.device):
+            bf = _is_bf16(xr)
+            _check(L.vqseg_proto_loss_backward_f(bf, _T(xr, "decoder features", bf=bf, numel=m * c), _f32(proto, "prototypes", k * c),
+                                                 _T(labels, "labels", dtype=torch.int64, numel=m), _T(keep, "keep mask", dtype=torch.uint8, numel=m),
+                                                 _f32(conf, "confidence", m), m, c, k, variant, scale, margin, easy, _f32(g32, "loss gradient", 1),
+                                                 _T(gx, "feature gradient", bf=bf, numel=m * c), _f32(gproto, "prototype gradient", k * c),
+                                                 _T(ws, "workspace", dtype=torch.uint8, numel=nbytes), nbytes, _stream()), "vqseg_proto_loss_backward_f")
         return _nchw(gx), gproto, None, None, None, None, None, None, None
 
 
@@ -853,9 +928,11 @@ class _DiceSums(torch.autograd.Function):
         out = torch.empty(2, b, c, dtype=torch.float32, device=pred.device)
         ce = torch.empty(b, 2, dtype=torch.float32, device=pred.device) if want_ce else None
         ign = -(1 << 62) if ignore_index is None else int(ignore_index)
-        with torch.cuda.device(pred.device):
-            _check(L.vqseg_dice_ce_sums_forward_f(pred.data_ptr(), sb, sc, sw, tgt.data_ptr(), b, c, h * w, ign, ws.data_ptr(), nbytes,
-                                                  out[0].data_ptr(), out[1].data_ptr(), _p(ce), _stream()), "vqseg_dice_ce_sums_forward_f")
+        with _hip.on_device(pred.device):
+            _check(L.vqseg_dice_ce_sums_forward_f(_strided_f32(pred, "logits", b * c * h * w), sb, sc, sw, _T(tgt, "targets", dtype=torch.int64, numel=b * h * w),
+                                                  b, c, h * w, ign, _T(ws, "workspace", dtype=torch.uint8, numel=nbytes), nbytes,
+                                                  _f32(out[0], "intersections", b * c), _f32(out[1], "set sizes", b * c), _f32(ce, "cross-entropy sums", b * 2),
+                                                  _stream()), "vqseg_dice_ce_sums_forward_f")
         ctx.save_for_backward(pred, tgt)
         ctx.cfg = (b, c, h * w, ign, (sb, sc, sw), want_ce)
         if want_ce:
@@ -869,9 +946,11 @@ class _DiceSums(torch.autograd.Function):
         g = torch.empty_strided(pred.shape, pred.stride(), dtype=torch.float32, device=pred.device)
         gi, gs = g_inter.float().contiguous(), g_sets.float().contiguous()
         gc = g_ce.float().contiguous() if (want_ce and g_ce is not None) else None
-        with torch.cuda.device(pred.device):
-            _check(lib().vqseg_dice_ce_sums_backward_f(pred.data_ptr(), sb, sc, sw, tgt.data_ptr(), b, c, hw, ign, gi.data_ptr(),
-                                                       gs.data_ptr(), _p(gc), g.data_ptr(), _stream()), "vqseg_dice_ce_sums_backward_f")
+        with _hip.on_device(pred.device):
+            _check(lib().vqseg_dice_ce_sums_backward_f(_strided_f32(pred, "logits", b * c * hw), sb, sc, sw, _T(tgt, "targets", dtype=torch.int64, numel=b * hw),
+                                                       b, c, hw, ign, _f32(gi, "d intersections", b * c), _f32(gs, "d set sizes", b * c),
+                                                       _f32(gc, "d cross-entropy sums", b * 2), _strided_f32(g, "logit gradient", b * c * hw), _stream()),
+                   "vqseg_dice_ce_sums_backward_f")
         return g, None, None, None
 
 
@@ -906,9 +985,9 @@ def softmax_stats(logits, want_label=True, want_entropy=True, want_top=False):
     label = torch.empty((b, h, w), dtype=torch.int64, device=dev) if want_label else None
     ent = torch.empty((b, h, w), dtype=torch.float32, device=dev) if want_entropy else None
     top = torch.empty((b, h, w), dtype=torch.float32, device=dev) if want_top else None
-    with torch.cuda.device(dev):
-        _check(lib().vqseg_softmax_stats_f(x.data_ptr(), sb, sc, sw, b, c, h * w, _p(label), _p(ent), _p(top), _stream()),
-               "vqseg_softmax_stats_f")
+    with _hip.on_device(dev):
+        _check(lib().vqseg_softmax_stats_f(_strided_f32(x, "logits", b * c * h * w), sb, sc, sw, b, c, h * w, _T(label, "labels", dtype=torch.int64, numel=b * h * w),
+                                           _f32(ent, "entropy", b * h * w), _f32(top, "top probability", b * h * w), _stream()), "vqseg_softmax_stats_f")
     return label, ent, top
 
 
@@ -924,8 +1003,9 @@ def percentile(values, percent: float):
     k = min(max(int(virtual), 0), n - 1)
     ws = torch.empty(lib().vqseg_order_stats_workspace_bytes(), dtype=torch.uint8, device=x.device)
     out = torch.empty(2, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        _check(lib().vqseg_order_stats_f(x.data_ptr(), n, k, ws.data_ptr(), ws.numel(), out.data_ptr(), _stream()), "vqseg_order_stats_f")
+    with _hip.on_device(x.device):
+        _check(lib().vqseg_order_stats_f(_f32(x, "values", n), n, k, _T(ws, "workspace", dtype=torch.uint8), ws.numel(), _f32(out, "order statistics", 2),
+                                         _stream()), "vqseg_order_stats_f")
     frac = virtual - k
     if frac <= 0.0:
         return out[0]
