@@ -611,3 +611,32 @@ def test_stem_patch_matrix_is_shared_inside_a_scope_only():
         ref_c = nnf.stem_conv_bn_act(x, conv_a, bn_a)
     torch.cuda.synchronize()
     assert torch.equal(out_a, ref_a) and torch.equal(out_b, ref_b) and torch.equal(out_c, ref_c)
+
+
+def test_wrong_element_types_raise_in_python_instead_of_faulting_on_the_gpu():
+    """the C ABI takes untyped pointers + a bf16 flag; every tensor is handed over through _hip.tptr,
+    which checks the element type against that flag and the element count against the sizes -- on the GPU box a mix-up is an exception
+    (the r2 fault was a bf16 buffer read as f32: 2x out of bounds)."""
+    import torch
+    from torch import nn
+    from vq_seg_amd import _hip, nnf
+    d = torch.device("cuda:0")
+    E = _hip.HipLibraryError
+    xb = torch.zeros(2, 32, 8, 8, device=d, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xf = torch.zeros(2, 32, 8, 8, device=d).contiguous(memory_format=torch.channels_last)
+    conv, bn = nn.Conv2d(32, 32, 3, padding=1, bias=False).to(d), nn.BatchNorm2d(32).to(d)
+    with pytest.raises(E, match="residual dtype differs|expected torch.bfloat16"):
+        nnf.conv_bn_act(xb, conv, bn, residual=xf)
+    with pytest.raises(E, match="conv input 2: expected torch.bfloat16"):
+        conv2 = nn.Conv2d(64, 32, 3, padding=1, bias=False).to(d)
+        nnf.conv_bn_act(xb, conv2, bn, x2=xf)
+    with pytest.raises(E, match="rows: expected torch.float32"):
+        _hip.vq_assign(torch.zeros(64, 32, device=d, dtype=torch.float16), torch.zeros(8, 32, device=d))
+    with pytest.raises(E, match="codebook: the sizes passed along need"):
+        _hip.vq_assign(torch.zeros(64, 32, device=d), torch.zeros(8, 64, device=d))
+    with pytest.raises(E, match="need 4096 elements"):
+        nnf.S3(torch.zeros(2, 8, 8, 16, device=d, dtype=torch.bfloat16), 16).float()
+    bn.double()
+    with pytest.raises(E, match="bn.weight: expected torch.float32"):
+        nnf.conv_bn_act(xf, conv, bn)
+    torch.cuda.synchronize()

@@ -123,3 +123,39 @@ def test_split3_is_confined_to_the_model_forward():
     model.train()
     with torch.no_grad():
         assert not any(isinstance(f, nnf.S3) for f in model.encode(x))
+
+
+def test_eval_forward_with_widths_the_split3_kernels_reject_falls_back_to_the_precise_path():
+    """the split-3 kernels need 32-channel K chunks per concat segment and Cout % 8 == 0.  A model whose decoder
+    ends in 16 channels (the next layer then has Cin = 16) must still run its no-grad eval forward: those layers merge back to fp32
+    and take the precise kernels.  Logits equal the all-precise forward (py_s3_eval = 0) to split-3 accuracy; indices identical."""
+    from vq_seg_amd import _hip
+    from vq_seg_amd.models.networks import make_model
+    cfg = {"name": "vqreptunet1x1", "params": {"encoder_name": "resnet50", "num_classes": 3, "depth": 5, "decoder_channels": [256, 128, 64, 32, 16],
+                                               "vq_cfg": {"num_embeddings": [0, 0, 32, 32, 32], "distance": "euclidean", "kmeans_init": False},
+                                               "margin": 0.0, "scale": 1.0, "use_feature": False, "encoder_weights": None}}
+    torch.manual_seed(3)
+    try:
+        model = make_model(cfg).to(dev())
+    except TypeError:                                                   # the factory takes the reference's ctor kwargs only
+        cfg["params"].pop("decoder_channels")
+        model = make_model(cfg).to(dev())
+        from vq_seg_amd.models.networks.unet.decoder import UnetDecoder
+        model.decoder = UnetDecoder((3, 64, 256, 512, 1024, 2048), [256, 128, 64, 32, 16]).to(dev())
+        model.segmentation_head = nn.Conv2d(16, 3, 1, bias=False).to(dev())
+    model.eval()
+    x = synth.uniform(9, (2, 3, 64, 64)).to(dev()).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        got = model(x)[0]
+        _hip.lib()
+        prev = _hip.PY_OPTS.get("py_s3_eval")
+        _hip.PY_OPTS["py_s3_eval"] = 0
+        try:
+            want = model(x)[0]
+        finally:
+            if prev is None:
+                _hip.PY_OPTS.pop("py_s3_eval")
+            else:
+                _hip.PY_OPTS["py_s3_eval"] = prev
+    assert got.shape == want.shape == (2, 3, 64, 64) and torch.isfinite(got).all()
+    assert rel(got, want) < 2e-4, rel(got, want)

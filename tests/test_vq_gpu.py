@@ -393,3 +393,32 @@ def test_argmin_at_baseline_row_counts_matches_the_reference_on_live_codebooks(t
         for g, w in zip(group, want):
             assert torch.equal(g[1], w)                                        # grouped launch == single launches, bit for bit
     print("\n".join(report))
+
+
+def test_grouped_forward_statistics_are_not_graph_attached():
+    """every level's idx / dead-code output of the grouped function is marked non-differentiable (one
+    mark_non_differentiable call for all levels: a call per level kept only the last level's marks)."""
+    from vq_seg_amd.vector_quantizer import make_vq_module, quantize_group
+    enc = (3, 64, 256, 512, 1024, 2048)
+    mods = make_vq_module({"num_embeddings": [0, 0, 64, 64, 32], "distance": "euclidean", "kmeans_init": False}, enc, 5).to(dev())
+    mods.train(True)
+    xs = [synth.relu_features(70 + i, (2, enc[i + 1], 16 >> (i - 2), 16 >> (i - 2))).to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+          for i in (2, 3, 4)]
+    for q, idx, loss, dead in quantize_group(list(mods[2:]), xs):
+        assert q.requires_grad and loss.requires_grad
+        assert not idx.requires_grad and idx.grad_fn is None
+        assert not dead.requires_grad and dead.grad_fn is None
+
+
+def test_assign_with_more_codes_than_the_lds_histogram_holds():
+    """the dead-code histogram lives in LDS up to K = 8192 and in global memory beyond; K = 16384 used to fail at launch."""
+    from oracle import vq_chain
+    from vq_seg_amd import _hip
+    n, c, k = 4096, 16, 16384
+    rows = synth.uniform(91, (n, c), -1.0, 1.0)
+    W = synth.uniform(92, (k, c), -1.0, 1.0)
+    quant, idx, _loss, dead = _hip.vq_forward(rows.to(dev()), W.to(dev()), False, 1.0)[:4]
+    ref_idx, _ = vq_chain.assign(rows.numpy(), W.numpy(), vq_chain.ORDER_MFMA8)
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)
+    cnt = torch.bincount(idx, minlength=k)
+    assert float(dead) == float(100 * ((cnt == 0).sum() / k))

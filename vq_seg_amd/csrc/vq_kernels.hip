@@ -351,9 +351,9 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const VqGroup g) 
 // workgroup.  Integer adds: order independent, deterministic.
 __global__ __launch_bounds__(256) void vq_unpack_keys(const unsigned long long* __restrict__ keys, long N,
                                                       long long* __restrict__ idx, float* __restrict__ dmin,
-                                                      int* __restrict__ hist, int K) {
+                                                      int* __restrict__ hist, int K, int lds_hist) {
     extern __shared__ int lh[];
-    if (hist)
+    if (hist && lds_hist)
         for (int k = threadIdx.x; k < K; k += 256) lh[k] = 0;
     __syncthreads();
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) {
@@ -361,9 +361,9 @@ __global__ __launch_bounds__(256) void vq_unpack_keys(const unsigned long long* 
         const unsigned code = (unsigned)(k & 0xffffffffull);
         idx[i] = (long long)code;
         if (dmin) dmin[i] = __uint_as_float((unsigned int)(k >> 32));
-        if (hist && code < (unsigned)K) atomicAdd(lh + code, 1);
+        if (hist && code < (unsigned)K) atomicAdd((lds_hist ? lh : hist) + code, 1);   // K beyond the LDS budget: global bins
     }
-    if (hist) {
+    if (hist && lds_hist) {
         __syncthreads();
         for (int k = threadIdx.x; k < K; k += 256) {
             const int c = lh[k];
@@ -898,9 +898,11 @@ hipError_t launch_assign_group(int n, const void* const* x, int x_bf16, const in
         long blocks = (N[i] + 1023) / 1024;                      // >= 1024 rows per workgroup: the LDS histogram pays
         if (blocks > 512) blocks = 512;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(vq_unpack_keys, dim3((unsigned)blocks), dim3(256), (size_t)K[i] * sizeof(int), st,
+        const int lds_hist = K[i] <= 8192;                       // 32 KB of LDS bins; larger codebooks count in global memory (rare
+                                                                 // winners per address there, so the L2 atomics do not serialise)
+        hipLaunchKernelGGL(vq_unpack_keys, dim3((unsigned)blocks), dim3(256), lds_hist ? (size_t)K[i] * sizeof(int) : 0, st,
                            reinterpret_cast<unsigned long long*>(ws[i] + plans[i].off_keys), (long)N[i],
-                           reinterpret_cast<long long*>(idx[i]), dmin ? dmin[i] : nullptr, hist, K[i]);
+                           reinterpret_cast<long long*>(idx[i]), dmin ? dmin[i] : nullptr, hist, K[i], lds_hist);
     }
     return hipGetLastError();
 }

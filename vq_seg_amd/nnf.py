@@ -605,7 +605,13 @@ def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None, l
     if conv.bias is not None:
         raise NotImplementedError("conv_bn_act: the reference's fused blocks have no conv bias")
     if isinstance(x, S3) or isinstance(x2, S3) or isinstance(residual, S3):
-        if not bn.training and not torch.is_grad_enabled():
+        # the split-3 kernels take 32-channel K chunks per concat segment and 16-byte [hi | lo] output rows (vqseg_conv2d_affine_f,
+        # precise == 2); any other width (e.g. decoder_channels ending in 16) merges back to fp32 and runs on the precise kernels,
+        # which handle every Cin % 4 == 0 -- same values to 2^-16, just slower
+        c1 = x.shape[1]
+        c2 = x2.shape[1] if x2 is not None else 0
+        s3_ok = c1 % 32 == 0 and c2 % 32 == 0 and conv.weight.shape[0] % 8 == 0
+        if not bn.training and not torch.is_grad_enabled() and s3_ok:
             return _conv_bn_act_s3(to_s3(x), x2, residual, conv, bn, relu)
         x, x2, residual = from_s3(x), (from_s3(x2) if x2 is not None else None), (from_s3(residual) if residual is not None else None)
     if not x.is_cuda:

@@ -424,15 +424,17 @@ class CPSTrainer:
     def sync_buffers(self):
         """Data parallel: BatchNorm running statistics are per-rank (each rank normalises with its own batch statistics -- the
         reference's single-device semantics per rank; parameters and codebooks ARE identical on all ranks).  This broadcasts
-        rank 0's buffers so that every rank holds the state a checkpoint written by rank 0 contains."""
+        rank 0's buffers to every rank -- an EXPLICIT act (end of training, before an all-rank evaluation).  Nothing on the training
+        path calls it: the eval-mode pseudo-label forwards read the running statistics, so a hidden sync (round 2 had one inside
+        save_checkpoint) would make the trajectory of ranks > 0 depend on how often checkpoints are written."""
         if vdist.collectives_on():
             for m in self.models:
                 for b in m.buffers():
                     dist.broadcast(b.data, src=0)
 
-    def state_dicts(self, sync: bool = True):
-        """(model_1, model_2, optimizer_1, optimizer_2) state_dicts for utils.ckpoints.save_ckpoints; `sync` first makes the
-        BatchNorm buffers rank 0's on every rank (see sync_buffers), so that any rank may write the file."""
+    def state_dicts(self, sync: bool = False):
+        """(model_1, model_2, optimizer_1, optimizer_2) state_dicts for utils.ckpoints.save_ckpoints -- THIS rank's state.
+        `sync=True` first broadcasts rank 0's BatchNorm buffers (a collective that changes ranks > 0: see sync_buffers)."""
         if sync:
             self.sync_buffers()
         return (self.models[0].state_dict(), self.models[1].state_dict(), self.opts[0].state_dict(), self.opts[1].state_dict())
@@ -440,10 +442,11 @@ class CPSTrainer:
     def save_checkpoint(self, filepath, epoch: int = 0, batch_idx: int = 0):
         """The reference's checkpoint dictionary (utils/ckpoints.py:7-13: model_1, model_2, epoch, batch_idx, optimizer_1,
         optimizer_2) plus what a bit-exact resume needs and the reference does not store: the `initted` flags and
-        the iteration counter that positions the cosine schedule.  Every rank calls it (the buffer sync is a collective);
-        rank 0 writes."""
-        m1, m2, o1, o2 = self.state_dicts()
+        the iteration counter that positions the cosine schedule.  Rank 0 writes ITS state (parameters, codebooks and optimiser
+        moments are identical on all ranks; the BatchNorm running statistics in the file are rank 0's); no collective, no rank's
+        state is touched -- writing a checkpoint cannot alter the run."""
         if vdist.rank() == 0:
+            m1, m2, o1, o2 = self.state_dicts()
             save_ckpoints(m1, m2, epoch, batch_idx, o1, o2, filepath, models=self.models, extra={"iter": self.iter})
 
     def load_checkpoint(self, filepath):

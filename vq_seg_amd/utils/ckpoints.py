@@ -8,8 +8,8 @@ resumed training run would re-run k-means over the loaded codebooks 
 (`save_ckpoints(..., models=[m1, m2])`, `restore_initted`).  Files are read with `weights_only=True`.
 
 Data parallel runs (trainer.CPSTrainer): parameters and codebooks are bit-identical on all ranks; BatchNorm running
-statistics are per-rank (the reference's per-device BatchNorm semantics) -- `CPSTrainer.state_dicts()` returns
-rank 0's, which is what a checkpoint written by rank 0 holds.
+statistics are per-rank (the reference's per-device BatchNorm semantics) -- `CPSTrainer.save_checkpoint()` writes rank 0's
+own state without a collective, so saving never changes any rank (`CPSTrainer.sync_buffers()` is the explicit broadcast).
 """
 import os
 import shutil

@@ -72,10 +72,11 @@ class _VQGroupFunction(torch.autograd.Function):
             for r, cb, (q, idx, _l, _d) in zip(rows, codebooks, outs):
                 saved += [r, idx, cb] if ctx.bf16 else [r, q]
             ctx.save_for_backward(*saved)
-        flat = []
+        flat, nondiff = [], []
         for q, idx, loss, dead in outs:
-            ctx.mark_non_differentiable(idx, dead)
+            nondiff += [idx, dead]
             flat += [q, idx, loss, dead]
+        ctx.mark_non_differentiable(*nondiff)               # ONE call: a later call replaces the earlier one's set
         return tuple(flat)
 
     @staticmethod
