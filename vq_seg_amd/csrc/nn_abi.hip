@@ -122,6 +122,7 @@ int vqseg_set_option(const char* key, int value) {
     if (!key || value < 0) return bad("set_option: null key or negative value");
     int prev = vqseg::conv_set_option(key, value);
     if (prev < 0) prev = vqseg::vq_set_option(key, value);
+    if (prev < 0) prev = vqseg::nn_set_option(key, value);
     return prev < 0 ? bad("set_option: unknown key") : prev;
 }
 

@@ -6,6 +6,7 @@
 
 namespace vqseg {
 
+int nn_set_option(const char* key, int value);              // previous value, or -1 (unknown key)
 hipError_t launch_bn_finalize(float* partial, long n_slots, int rows_per_slot, long M, int C, const float* gamma,
                               const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
                               float* shift, float* save_mean, float* save_invstd, long long* num_batches_tracked, hipStream_t st);

@@ -10,6 +10,7 @@
 // Reductions are two-level with fixed order (no float atomics): results are run-to-run deterministic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "nn_kernels.h"
 
@@ -1131,10 +1132,23 @@ static inline unsigned grid_for(long work, int per_block = 256, long cap = 8192)
     return (unsigned)b;
 }
 
+// debug only (timing experiments, results garbage): bit 1 skip the forward statistics merge + finalize, 2 the backward finalize,
+// 4 the weight-gradient slab sums -- "what do the ~950 tiny launches of a step cost on the wall clock?" (VQSEG_OPTS=debug_skip_small=7)
+static int g_debug_skip_small = 0;
+int nn_set_option(const char* key, int value) {
+    if (key && !strcmp(key, "debug_skip_small")) {
+        const int prev = g_debug_skip_small;
+        g_debug_skip_small = value;
+        return prev;
+    }
+    return -1;
+}
+
 hipError_t launch_bn_finalize(float* partial, long n_slots, int rows_per_slot, long M, int C, const float* gamma,
                               const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
                               float* shift, float* save_mean, float* save_invstd, long long* num_batches_tracked, hipStream_t st_) {
     long spg = 1;                                           // slots per group of level 1
+    if (g_debug_skip_small & 1) return hipSuccess;
     if (n_slots > 128) {
         spg = (n_slots + 127) / 128;
         if (spg < 16) spg = 16;
@@ -1177,6 +1191,7 @@ static hipError_t bn_bwd_t(const void* g_out, const void* out, const void* y, co
     const long nb = bn_bwd_blocks(M);
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK>), dim3((unsigned)nb, (unsigned)((C + BNB_CG - 1) / BNB_CG)), dim3(256), 0, st_,
                        (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, fsc, fsh, M, C, relu, partial);
+    if (!(g_debug_skip_small & 2))
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st_, partial, nb, M, C, gamma, invstd, training, accumulate, dgamma,
                        dbeta, coef);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK>), dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_,
@@ -1283,6 +1298,7 @@ hipError_t launch_head_bwd(int bf16, const void* x, const float* w, const float*
 }
 
 hipError_t launch_reduce_partials(const float* partial, long n_blocks, long n, float* out, int accumulate, hipStream_t st_) {
+    if (!(g_debug_skip_small & 4))
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st_, partial, n_blocks, n, out, accumulate);
     return hipGetLastError();
 }

@@ -37,9 +37,15 @@ struct VqLevel {
     int C, Kp;
     unsigned wg_end;            // exclusive end of this level's workgroup ids in the launch
 };
+#ifndef VQ_TIMELINE
+#define VQ_TIMELINE 0             // debug build only (`make timeline` -> libvqseg_hip_tl.so; tools/vq_timeline.py): per-workgroup clock stamps
+#endif
 struct VqGroup {
     VqLevel lv[VQ_MAX_LEVELS];
     int n;
+#if VQ_TIMELINE
+    unsigned long long* tl;     // [workgroups][16]: (s_memrealtime, s_memtime) at 6 points of wave 0 + HW_ID + XCC_ID, or null
+#endif
 };
 struct Profile {
     bool enabled = false;

@@ -119,8 +119,23 @@ template <> struct RawFrag<__bf16> { typedef u32x2 type; };
 // One launch serves up to VQ_MAX_LEVELS independent quantisation problems ("levels": the three VQ layers of one forward).
 // Workgroup ids [wg_end of the previous level, wg_end) belong to a level; the host orders the levels longest workgroup
 // first (most channels), so that the short workgroups of the last level fill the tail of the launch.
+#if VQ_TIMELINE
+// per-workgroup timeline (debug build): stamp k of wave 0 = (constant 100 MHz real-time counter, shader cycle counter)
+#define TL_STAMP(k_)                                                          \
+    if (g.tl && threadIdx.x == 0) {                                           \
+        tl_rt[k_] = __builtin_amdgcn_s_memrealtime();                         \
+        tl_ck[k_] = __builtin_amdgcn_s_memtime();                             \
+    }
+#else
+#define TL_STAMP(k_)
+#endif
+
 template <int T, typename TX = float>
 __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const VqGroup g) {
+#if VQ_TIMELINE
+    unsigned long long tl_rt[6] = {0, 0, 0, 0, 0, 0}, tl_ck[6] = {0, 0, 0, 0, 0, 0};
+    TL_STAMP(0)
+#endif
     int lvl = 0;
     while (lvl + 1 < g.n && blockIdx.x >= g.lv[lvl].wg_end) ++lvl;                 // uniform (scalar) search
     const unsigned bid = blockIdx.x - (lvl ? g.lv[lvl - 1].wg_end : 0u);           // level offsets are multiples of 8 (XCD pairing below)
@@ -220,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const VqGroup g) 
 #pragma unroll
     for (int j = 0; j < JB; ++j) a_nxt[j] = RawA{};
     __syncthreads();                                           // drains vmcnt, then barrier
+    TL_STAMP(1)                                                // prologue done: the first MFMA follows
 
     // B fragment of lane (r, h) for block j, tile t: Bs[buf][2j + h][32 t + r][0..3]
     const float* bs_lane = Bs + (h * CODES + r) * 4;
@@ -268,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const VqGroup g) 
         widen_a(a_cur, a_nxt);
     }
 
+    TL_STAMP(2)                                                // main loop issued (the last MFMAs are still draining)
     // ---- epilogue: distances -> (min, code) per row over this workgroup's codes
     {
         const float xn = xn_part + __shfl_xor(xn_part, 32);
@@ -318,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const VqGroup g) 
             bthr[i] = clear ? d2 * 0.99999905f : bthr[i];
         }
     }
+    TL_STAMP(3)                                                // running minima done (waited on every accumulator)
     // ---- merge the 32 code lanes of each half: keys (float_bits(sqrt d2) << 32 | code) through LDS, 2 lanes per row
     // (the B stage buffers are free: after the last stage barrier every fragment lives in registers)
     unsigned long long* ks = reinterpret_cast<unsigned long long*>(Bs) + wave * (32 * 33);
@@ -341,8 +359,24 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const VqGroup g) 
         m = o < m ? o : m;
         const int hh = rw >> 4, ii = rw & 15;
         const long orow = row0 + (ii & 3) + 8 * (ii >> 2) + 4 * hh;
+        TL_STAMP(4)
         if (part == 0 && orow < N) atomicMin(keys + orow, m);
     }
+#if VQ_TIMELINE
+    TL_STAMP(5)
+    if (g.tl && threadIdx.x == 0) {
+        unsigned long long* o = g.tl + (size_t)blockIdx.x * 16;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            o[2 * k] = tl_rt[k];
+            o[2 * k + 1] = tl_ck[k];
+        }
+        o[12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13
+        o[13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+        o[14] = (unsigned long long)lvl;
+        o[15] = (unsigned long long)row_tile;
+    }
+#endif
 }
 
 // keys -> int64 code indices (+ the winning distance), and the code histogram of the dead-code statistic (vq_img.py:173-175):
@@ -820,6 +854,10 @@ int profile_collect(int max_records, int64_t* n, int* c, int* k, float* ms) {
     return out;
 }
 
+#if VQ_TIMELINE
+static unsigned long long* g_timeline = nullptr;
+#endif
+
 template <int T, typename TX>
 static void launch_assign_t(const VqGroup& g, hipStream_t st) {
     constexpr int STAGE_FLOATS = stage_floats(T);
@@ -861,6 +899,9 @@ hipError_t launch_assign_group(int n, const void* const* x, int x_bf16, const in
             if (C[order[j]] > C[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
     VqGroup g;
     g.n = n;
+#if VQ_TIMELINE
+    g.tl = g_timeline;
+#endif
     unsigned end = 0;
     for (int q = 0; q < n; ++q) {
         const int i = order[q];
@@ -1033,3 +1074,11 @@ hipError_t launch_km_finalize(const float* sums, const int64_t* counts64, float*
 }
 
 }  // namespace vqseg
+
+#if VQ_TIMELINE
+// debug build only: device buffer [workgroups][16] u64 the next assign launches write their stamps to (null: off)
+extern "C" int vqseg_debug_timeline(void* buf) {
+    vqseg::g_timeline = static_cast<unsigned long long*>(buf);
+    return 0;
+}
+#endif
