@@ -284,6 +284,11 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const VqGroup g) 
         widen_a(a_cur, a_nxt);
     }
 
+    // |e|^2 of this lane's code in every tile: ONE batch of loads, issued while the last MFMAs drain (the fragment registers of the
+    // main loop are dead now; holding these through the loop spilled 67 registers)
+    float en[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) en[t] = enorm[code0 + t * 32 + r];
     TL_STAMP(2)                                                // main loop issued (the last MFMAs are still draining)
     // ---- epilogue: distances -> (min, code) per row over this workgroup's codes
     {
@@ -299,41 +304,59 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const VqGroup g) 
 #pragma unroll
         for (int e = 0; e < 4; ++e) xnr[4 * g + e] = v[e];
     }
-    // Running per-lane minimum in SQUARED-distance space; the reference argmins over sqrt(d2), whose rounding can
-    // collapse nearly equal d2 into one float (then the LOWER index wins).  A candidate within 2^-20 relative of the
-    // holder therefore takes the exact path (compare correctly-rounded square roots); everything else is decided
-    // on d2 alone.  Codes arrive in increasing index order per lane, so "keep the holder on a tie" is the tie rule.
-    float best2[16], bthr[16];
+    // Running per-lane minimum in SQUARED-distance space.
+    float best2[16];
     int best_i[16];
+    // Row by row (the 16 rows of a lane are independent; within a row the codes arrive in increasing index order).
+    // FAST scan, branch-free: only "clearly better" candidates (below the holder by more than the collapse band 2^-20) move the
+    // holder; a candidate inside the band raises `band`.  Without a band event anywhere in the wave the result IS the exact scan's
+    // (every decision was a clear one).  With one (rare: two codes within 1e-6 relative of a row's running minimum) the wave redoes
+    // that row on the EXACT path: the reference argmins over sqrt(d2), whose rounding can collapse nearly equal d2 into one float --
+    // then the LOWER index wins -- so a candidate inside the band compares correctly-rounded square roots, and "keep the holder on
+    // a tie" is the tie rule.  One wave-uniform branch per row instead of one per (row, tile); the tiles' |e|^2 come from en[] (they
+    // used to be loaded tile by tile behind that branch: eight serialised L2 latencies, 19 us of a 141 us workgroup --
+    // profiles/r03_vq_wg_timeline_before.md).
+    const int code_r = code0 + r;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        best2[i] = __builtin_inff();
-        bthr[i] = __builtin_inff();
-        best_i[i] = 0x7fffffff;
-    }
+        float b2 = __builtin_inff(), thr = __builtin_inff();
+        int bi = 0x7fffffff;
+        bool band = false;
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int code = code0 + t * 32 + r;
-        const float en = enorm[code];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int t = 0; t < T; ++t) {
             float d2 = __builtin_fmaf(-2.0f, acc[t][i], xnr[i]);
-            d2 = d2 + en;
+            d2 = d2 + en[t];
             d2 = __builtin_fmaxf(d2, 0.0f);
-            const bool clear = d2 < bthr[i];                                   // better by more than the collapse band
-            const bool near = !clear && d2 < best2[i];                         // inside the band: rare
-            if (__builtin_expect(__any(near), 0)) {
-                if (near) {
-                    const bool better = __builtin_sqrtf(d2) < __builtin_sqrtf(best2[i]);
-                    best_i[i] = better ? code : best_i[i];
-                    best2[i] = d2;                                             // same sqrt class or better: safe to lower
-                    bthr[i] = d2 * 0.99999905f;
-                }
-            }
-            best_i[i] = clear ? code : best_i[i];
-            best2[i] = clear ? d2 : best2[i];
-            bthr[i] = clear ? d2 * 0.99999905f : bthr[i];
+            const bool clear = d2 < thr;                                       // better by more than the collapse band
+            band = band || (!clear && d2 < b2);                                // inside the band
+            bi = clear ? code_r + 32 * t : bi;
+            b2 = clear ? d2 : b2;
+            thr = clear ? d2 * 0.99999905f : thr;
         }
+        if (__builtin_expect(__any(band), 0)) {
+            b2 = __builtin_inff();
+            thr = __builtin_inff();
+            bi = 0x7fffffff;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                float d2 = __builtin_fmaf(-2.0f, acc[t][i], xnr[i]);
+                d2 = d2 + en[t];
+                d2 = __builtin_fmaxf(d2, 0.0f);
+                const bool clear = d2 < thr;
+                const bool near = !clear && d2 < b2;
+                if (near) {
+                    const bool better = __builtin_sqrtf(d2) < __builtin_sqrtf(b2);
+                    bi = better ? code_r + 32 * t : bi;
+                    b2 = d2;                                                   // same sqrt class or better: safe to lower
+                    thr = d2 * 0.99999905f;
+                }
+                bi = clear ? code_r + 32 * t : bi;
+                b2 = clear ? d2 : b2;
+                thr = clear ? d2 * 0.99999905f : thr;
+            }
+        }
+        best2[i] = b2;
+        best_i[i] = bi;
     }
     TL_STAMP(3)                                                // running minima done (waited on every accumulator)
     // ---- merge the 32 code lanes of each half: keys (float_bits(sqrt d2) << 32 | code) through LDS, 2 lanes per row
