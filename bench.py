@@ -115,6 +115,7 @@ def bn_roofline(device):
         outs = [torch.empty_like(t) for t in ys]
         mean, inv, gamma = torch.zeros(C, device=device), torch.ones(C, device=device), torch.ones(C, device=device)
         ws = torch.empty(L.vqseg_bn_backward_workspace_floats(M, C), device=device)
+        sync = torch.zeros(L.vqseg_bn_sync_ints(C), dtype=torch.int32, device=device)
         dg, gy = torch.empty(2, C, device=device), torch.empty_like(ys[0])
         gres = torch.empty_like(ys[0]) if res else None
 
@@ -127,7 +128,7 @@ def bn_roofline(device):
             k = i % sets
             rc = L.vqseg_bn_backward_f(1, gs[k].data_ptr(), outs[k].data_ptr() if res else None, ys[k].data_ptr(), mean.data_ptr(), inv.data_ptr(),
                                        gamma.data_ptr(), sc.data_ptr(), sh.data_ptr(), M, C, 1, 1, 0, ws.data_ptr(), dg[0].data_ptr(), dg[1].data_ptr(),
-                                       gy.data_ptr(), gres.data_ptr() if res else None, st)
+                                       gy.data_ptr(), gres.data_ptr() if res else None, sync.data_ptr(), st)
             assert rc == 0, L.vqseg_last_error()
         for name, fn, nbytes in (("apply", apply, M * C * 2 * (3 if res else 2)), ("backward", bwd, M * C * 2 * (8 if res else 5))):
             fn(0)

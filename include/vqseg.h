@@ -253,17 +253,23 @@ int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, 
  *   backward -> gz = g_out * (out > 0); dgamma, dbeta; g_y (train: with the batch-statistics terms);
  *               g_res = gz when a residual branch exists.  Without a residual `out` may be NULL: the mask is then
  *               recomputed as fma(y, fwd_scale, fwd_shift) > 0, the forward's own expression (one tensor read less). */
+/* `sync` (nullable; finalize and backward): vqseg_bn_sync_ints(c) ints that hold ZEROS between launches (zero them once; the
+ * library leaves them zero) and that no two concurrent launches share -- e.g. one buffer per BatchNorm module and direction.
+ * With it the statistics merge + finalize (forward) / the reduction + finalize (backward) run as ONE launch each: the last
+ * workgroup of a 64-channel group does the final fold, in a fixed order (deterministic; r3: ~700 launches per training step
+ * less).  NULL: the two-launch form. */
+int vqseg_bn_sync_ints(int c);
 int vqseg_bn_finalize_f(float* partial, int64_t m_rows, int c, const float* gamma, const float* beta,
                         float* run_mean, float* run_var, float momentum, float eps, int training,
                         float* scale, float* shift, float* save_mean, float* save_invstd,
-                        int64_t* num_batches_tracked /* nullable: += 1 in training mode */, void* stream);
+                        int64_t* num_batches_tracked /* nullable: += 1 in training mode */, int* sync, void* stream);
 int vqseg_bn_apply_f(int bf16, const void* y, const void* res, const float* scale, const float* shift,
                      int64_t m_rows, int c, int relu, void* out, void* stream);
 size_t vqseg_bn_backward_workspace_floats(int64_t m_rows, int c);
 int vqseg_bn_backward_f(int bf16, const void* g_out, const void* out, const void* y, const float* mean,
                         const float* invstd, const float* gamma, const float* fwd_scale, const float* fwd_shift,
                         int64_t m_rows, int c, int relu, int training, int accumulate,
-                        float* workspace, float* dgamma, float* dbeta, void* g_y, void* g_res, void* stream);
+                        float* workspace, float* dgamma, float* dbeta, void* g_y, void* g_res, int* sync, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) (resnet.py:167) forward / backward (first maximum in scan order).
  * idx (nullable, uint8 [n, ho, wo, c]): forward writes the window position (kh*3+kw) of each maximum; backward

@@ -33,7 +33,7 @@ for (M, C, cnt, res) in ((32 * 256 * 256, 64, 1, 0), (32 * 128 * 128, 64, 6, 0),
         k = i % SETS
         assert L.vqseg_bn_backward_f(1, gs[k].data_ptr(), outs[k].data_ptr() if res else None, ys[k].data_ptr(), mean.data_ptr(), inv.data_ptr(), gamma.data_ptr(),
                                      sc.data_ptr(), sh.data_ptr(), M, C, 1, 1, 0, ws.data_ptr(), dg[0].data_ptr(), dg[1].data_ptr(), gy.data_ptr(),
-                                     gres.data_ptr() if res else None, st) == 0
+                                     gres.data_ptr() if res else None, None, st) == 0
     ta, tb = timeit(apply), timeit(bwd)
     ba = M * C * 2 * (3 if res else 2); bb = M * C * 2 * ((3 if res else 2) + (5 if res else 3))
     tot_a += ta * cnt; tot_b += tb * cnt

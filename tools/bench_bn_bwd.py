@@ -23,7 +23,7 @@ for (M, C) in ((32 * 128 * 128, 64), (32 * 128 * 128, 256), (32 * 64 * 64, 256),
             y, g, out = ys[it[0] % SETS], gs[it[0] % SETS], outs[it[0] % SETS]
             rc = L.vqseg_bn_backward_f(1, g.data_ptr(), out.data_ptr() if use_out else None, y.data_ptr(), mean.data_ptr(), inv.data_ptr(),
                                        gamma.data_ptr(), sc.data_ptr(), sh.data_ptr(), M, C, 1, 1, 0, ws.data_ptr(), dg[0].data_ptr(),
-                                       dg[1].data_ptr(), gy.data_ptr(), None, st)
+                                       dg[1].data_ptr(), gy.data_ptr(), None, None, st)
             assert rc == 0, L.vqseg_last_error()
         it[0] = -1
         run()

@@ -44,7 +44,7 @@ for (M, C) in ((2048, 64), (2048, 32), (100000, 64), (777, 256), (2 * 1024 * 102
     rm = torch.zeros(C, device=dev); rv = torch.ones(C, device=dev)
     coef = torch.empty(4, C, device=dev)
     assert L.vqseg_bn_finalize_f(pt.data_ptr(), M, C, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, 1,
-                                 coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), None, st()) == 0
+                                 coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), None, None, st()) == 0
     torch.cuda.synchronize()
     em = np.abs(coef[2].cpu().numpy() - mean).max() / np.abs(mean).max()
     ei = np.abs(coef[3].cpu().numpy() - 1 / np.sqrt(var + 1e-5)).max()

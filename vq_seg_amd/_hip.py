@@ -58,11 +58,12 @@ SYMBOLS = {
                               [c_int] * 13 + [c_void_p]),
     "vqseg_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int] * 9),
     "vqseg_conv2d_wgrad_f": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 17 + [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "vqseg_bn_sync_ints": (c_int, [c_int]),
     "vqseg_bn_finalize_f": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
-                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqseg_bn_apply_f": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "vqseg_bn_backward_workspace_floats": (c_size_t, [c_int64, c_int]),
-    "vqseg_bn_backward_f": (c_int, [c_int] + [c_void_p] * 8 + [c_int64, c_int, c_int, c_int, c_int] + [c_void_p] * 6),
+    "vqseg_bn_backward_f": (c_int, [c_int] + [c_void_p] * 8 + [c_int64, c_int, c_int, c_int, c_int] + [c_void_p] * 7),
     "vqseg_maxpool3x3s2_f": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vqseg_bilinear_f": (c_int, [c_int, c_int, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p]),
     "vqseg_head1x1_forward_f": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),

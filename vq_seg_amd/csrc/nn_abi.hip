@@ -158,9 +158,11 @@ int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, 
     return e == hipSuccess ? 0 : hipfail(e, "wgrad_reduce_kernel");
 }
 
+int vqseg_bn_sync_ints(int c) { return c > 0 ? (c + 63) / 64 : 0; }
+
 int vqseg_bn_finalize_f(float* partial, int64_t m_rows, int c, const float* gamma, const float* beta, float* run_mean,
                         float* run_var, float momentum, float eps, int training, float* scale, float* shift, float* save_mean,
-                        float* save_invstd, int64_t* num_batches_tracked, void* stream) {
+                        float* save_invstd, int64_t* num_batches_tracked, int* sync, void* stream) {
     if (!gamma || !beta || !scale || !shift || !save_mean || !save_invstd || c <= 0 || m_rows <= 0) return bad("bn_finalize: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e;
@@ -168,7 +170,7 @@ int vqseg_bn_finalize_f(float* partial, int64_t m_rows, int c, const float* gamm
         if (!partial) return bad("bn_finalize: training mode needs the conv epilogue partials");
         e = vqseg::launch_bn_finalize(partial, (m_rows + conv_rows_per_slot(c) - 1) / conv_rows_per_slot(c), conv_rows_per_slot(c), m_rows, c, gamma, beta,
                                       run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd,
-                                      reinterpret_cast<long long*>(num_batches_tracked), st);
+                                      reinterpret_cast<long long*>(num_batches_tracked), sync, st);
     } else {
         if (!run_mean || !run_var) return bad("bn_finalize: eval mode needs running statistics");
         e = vqseg::launch_bn_eval_coeffs(c, gamma, beta, run_mean, run_var, eps, scale, shift, save_mean, save_invstd, st);
@@ -191,7 +193,7 @@ size_t vqseg_bn_backward_workspace_floats(int64_t m_rows, int c) {
 int vqseg_bn_backward_f(int bf16, const void* g_out, const void* out, const void* y, const float* mean, const float* invstd,
                         const float* gamma, const float* fwd_scale, const float* fwd_shift, int64_t m_rows, int c, int relu,
                         int training, int accumulate, float* workspace, float* dgamma, float* dbeta, void* g_y, void* g_res,
-                        void* stream) {
+                        int* sync, void* stream) {
     if (!g_out || !y || !mean || !invstd || !gamma || !workspace || !dgamma || !dbeta || !g_y) return bad("bn_backward: null pointer");
     if (relu && !out && (!fwd_scale || !fwd_shift)) return bad("bn_backward: with ReLU pass either `out` or the forward scale/shift");
     if (relu && !out && g_res) return bad("bn_backward: a residual branch needs `out` (the mask depends on the residual)");
@@ -199,7 +201,7 @@ int vqseg_bn_backward_f(int bf16, const void* g_out, const void* out, const void
     float* partial = workspace;
     float* coef = workspace + (size_t)vqseg::bn_bwd_blocks(m_rows) * 2 * c;
     hipError_t e = vqseg::launch_bn_backward(bf16, g_out, out, y, mean, invstd, gamma, fwd_scale, fwd_shift, m_rows, c, relu, training, accumulate, partial, coef,
-                                             dgamma, dbeta, g_y, g_res, static_cast<hipStream_t>(stream));
+                                             dgamma, dbeta, g_y, g_res, sync, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hipfail(e, "bn_backward");
 }
 

@@ -70,24 +70,30 @@ __device__ __forceinline__ void stv(T* p, long i, const float (&v)[VecN<T>::N]) 
 // pairs, so the whole merge stays in double.  Level 2 (bn_finalize_kernel) sums the group results and derives
 // scale = gamma * invstd, shift = beta - mean * scale and the running-stat update (nn.BatchNorm2d: biased
 // variance to normalise, unbiased for running_var).
+// device-coherent accesses (sc1: written through / read past this XCD's L2) for results one workgroup hands to another inside a launch
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 struct PowerSums {
     double s1, s2;
 };
 
 // sum slots s0, s0 + step, ... < s1 for 64 channels; `merged`: the slots hold level-1 (hi, lo) results
-__device__ __forceinline__ PowerSums fold_slots(const float* __restrict__ partial, long s0, long s1, long step, bool merged,
+template <bool COHERENT = false>                           // COHERENT: the slots were written by OTHER workgroups of this launch (st_agent)
+__device__ __forceinline__ PowerSums fold_slots(const float* partial, long s0, long s1, long step, bool merged,
                                                 int rows_per_slot, long M, int C, int c, PowerSums* lds) {
     const int ty = threadIdx.x >> 6, cl = threadIdx.x & 63;
     PowerSums a{0.0, 0.0};
+    auto rd = [&](long idx) { return COHERENT ? ld_agent(partial + idx) : partial[idx]; };
     if (c < C)
         for (long i = s0 + ty * step; i < s1; i += 4 * step) {
-            const double u = (double)partial[(i * 2 + 0) * C + c], v = (double)partial[(i * 2 + 1) * C + c];
+            const double u = (double)rd((i * 2 + 0) * C + c), v = (double)rd((i * 2 + 1) * C + c);
             if (merged) {
                 a.s1 += u;
                 a.s2 += v;
                 if (i + 1 < s1) {                           // low parts in the next slot (groups hold >= 2 slots)
-                    a.s1 += (double)partial[(i * 2 + 2) * C + c];
-                    a.s2 += (double)partial[(i * 2 + 3) * C + c];
+                    a.s1 += (double)rd((i * 2 + 2) * C + c);
+                    a.s2 += (double)rd((i * 2 + 3) * C + c);
                 }
             } else {
                 long n = M - i * rows_per_slot;
@@ -126,6 +132,79 @@ __global__ __launch_bounds__(256) void bn_stats_merge_kernel(float* __restrict__
     }
 }
 
+// "Last workgroup done" hand-over (used by the fused merge + finalize kernels below): every workgroup of a channel group publishes
+// its result (device-scope release fence), then takes a ticket from sync[group]; the one that draws the last ticket acquires and
+// runs the group's final step alone, in a fixed order -> deterministic, and one launch instead of two.  sync[] holds zeros between
+// launches (the finishing workgroup resets its counter); the caller owns it and never shares it between concurrent launches.
+// The results handed over travel through st_agent / ld_agent: device-coherent accesses (sc1: written through / read past this XCD's
+// L2).  NOT __threadfence(): on gfx950 an agent-scope release / acquire fence writes back and invalidates the XCD's whole L2
+// (buffer_wbl2 / buffer_inv), per workgroup -- measured: the step 165 -> 225 ms, mostly in the OTHER stream's kernels.
+
+__device__ __forceinline__ bool last_workgroup_of(int* sync, int group, unsigned total) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's coherent stores have been performed
+    __syncthreads();                                        // ... and every wave's of the workgroup
+    if (threadIdx.x == 0) {
+        const unsigned t = (unsigned)__hip_atomic_fetch_add(sync + group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == total - 1);
+        if (s_last) __hip_atomic_store(sync + group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
+__device__ __forceinline__ void bn_finalize_channel(const PowerSums& r, long M, int c, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                    float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    const double mean = r.s1 / (double)M;
+    double m2 = r.s2 - (double)M * mean * mean;
+    if (m2 < 0.0) m2 = 0.0;
+    const double var = m2 / (double)M;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = invstd;
+    if (run_mean) {
+        const double unbiased = M > 1 ? m2 / (double)(M - 1) : var;
+        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
+        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// bn_stats_merge_kernel + bn_finalize_kernel in ONE launch: grid (64-channel groups, slot groups); the last workgroup of a channel
+// group folds the group results (same order, same arithmetic as bn_finalize_kernel: bit-identical statistics).
+__global__ __launch_bounds__(256) void bn_stats_merge_finalize_kernel(float* partial, long n_slots, long slots_per_group, int rows_per_slot,
+                                                                      long M, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                      float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
+                                                                      float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                                      float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                                      long long* __restrict__ num_batches_tracked, int* sync) {
+    __shared__ PowerSums lds[256];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const long s0 = (long)blockIdx.y * slots_per_group;
+    long s1 = s0 + slots_per_group;
+    if (s1 > n_slots) s1 = n_slots;
+    const PowerSums r = fold_slots(partial, s0, s1, 1, false, rows_per_slot, M, C, c, lds);
+    if ((threadIdx.x >> 6) == 0 && c < C) {
+        const float h1 = (float)r.s1, h2 = (float)r.s2;
+        st_agent(partial + (s0 * 2 + 0) * C + c, h1);
+        st_agent(partial + (s0 * 2 + 1) * C + c, h2);
+        if (s0 + 1 < s1) {
+            st_agent(partial + (s0 * 2 + 2) * C + c, (float)(r.s1 - (double)h1));
+            st_agent(partial + (s0 * 2 + 3) * C + c, (float)(r.s2 - (double)h2));
+        }
+    }
+    if (!last_workgroup_of(sync, blockIdx.x, gridDim.y)) return;
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;   // nn.BatchNorm2d bookkeeping
+    __syncthreads();                                        // lds is reused
+    const PowerSums t = fold_slots<true>(partial, 0, n_slots, slots_per_group, true, rows_per_slot, M, C, c, lds);
+    if ((threadIdx.x >> 6) == 0 && c < C)
+        bn_finalize_channel(t, M, c, gamma, beta, run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd);
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, long n_slots, long slots_per_group,
                                                           int rows_per_slot, long M, int C, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ run_mean,
@@ -137,23 +216,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;   // nn.BatchNorm2d bookkeeping
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const PowerSums r = fold_slots(partial, 0, n_slots, slots_per_group, slots_per_group > 1, rows_per_slot, M, C, c, lds);
-    if ((threadIdx.x >> 6) == 0 && c < C) {
-        const double mean = r.s1 / (double)M;
-        double m2 = r.s2 - (double)M * mean * mean;
-        if (m2 < 0.0) m2 = 0.0;
-        const double var = m2 / (double)M;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
-        scale[c] = sc;
-        shift[c] = beta[c] - (float)mean * sc;
-        save_mean[c] = (float)mean;
-        save_invstd[c] = invstd;
-        if (run_mean) {
-            const double unbiased = M > 1 ? m2 / (double)(M - 1) : var;
-            run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
-            run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unbiased;
-        }
-    }
+    if ((threadIdx.x >> 6) == 0 && c < C)
+        bn_finalize_channel(r, M, c, gamma, beta, run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd);
 }
 
 // eval mode: scale/shift from the running statistics
@@ -228,22 +292,33 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 // BatchNorm backward (through the fused ReLU / residual):  gz = g_out * (out > 0)
 //   partial[blk][0][c] = sum gz,   partial[blk][1][c] = sum gz * xhat,   xhat = (y - mean) * invstd
 // ---------------------------------------------------------------------------------------------
-constexpr int BNB_ROWS = 256;      // rows per block of the reduce kernel
+constexpr int BNB_ROWS_MIN = 256;  // rows per block of the reduce kernel (more for tall tensors: at most ~512 row blocks)
 constexpr int BNB_CG = 64;         // channels per block
 
 // grid (row chunks, channel groups).  Each thread owns V consecutive channels (one 16-byte load) of every
 // (256 / threads-per-row)-th row of the chunk; row lanes are folded through LDS in a fixed order.
 // MASK: 0 no ReLU, 1 mask from `out`, 2 mask recomputed as fma(y, fsc, fsh) > 0 (the forward's expression; no residual)
+// Finalize arguments of the fused reduce (sync != null): see bn_bwd_finalize_kernel
+struct BnBwdFin {
+    const float* gamma;
+    int training, accumulate;
+    float* dgamma;
+    float* dbeta;
+    float* coef;
+    int* sync;                                             // [channel groups], zeros between launches; null: separate finalize launch
+};
+
 template <typename T, int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ g_out, const T* __restrict__ out,
                                                             const T* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ fsc,
                                                             const float* __restrict__ fsh, long M, int C, int relu,
-                                                            float* __restrict__ partial) {
+                                                            float* partial, int rows_per_block, const BnBwdFin fin) {
     constexpr int V = VecN<T>::N;
     __shared__ float sh[2][256 * V];                       // [sum kind][row lane][channel in group]
     const int cg = C < BNB_CG ? C : BNB_CG;                // channels handled by this block
     const int c0 = blockIdx.y * BNB_CG;
+    const int BNB_ROWS = rows_per_block;
     const long row0 = (long)blockIdx.x * BNB_ROWS;
     float s0[V], s1[V];
 #pragma unroll
@@ -314,8 +389,53 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             a += sh[0][l * cg + threadIdx.x];
             b += sh[1][l * cg + threadIdx.x];
         }
-        partial[((long)blockIdx.x * 2 + 0) * C + c0 + threadIdx.x] = a;
-        partial[((long)blockIdx.x * 2 + 1) * C + c0 + threadIdx.x] = b;
+        if (fin.sync) {
+            st_agent(partial + ((long)blockIdx.x * 2 + 0) * C + c0 + threadIdx.x, a);
+            st_agent(partial + ((long)blockIdx.x * 2 + 1) * C + c0 + threadIdx.x, b);
+        } else {
+            partial[((long)blockIdx.x * 2 + 0) * C + c0 + threadIdx.x] = a;
+            partial[((long)blockIdx.x * 2 + 1) * C + c0 + threadIdx.x] = b;
+        }
+    }
+    if (!fin.sync) return;
+    // ---- fused finalize (was bn_bwd_finalize_kernel, a second launch): the last workgroup of this channel group sums the row
+    // blocks' partials in block order (4 row lanes x 64 channels, coalesced along the channels, lanes folded in lane order:
+    // fixed order -> deterministic) and writes dgamma / dbeta / the apply pass's coefficients for its channels.
+    if (!last_workgroup_of(fin.sync, blockIdx.y, gridDim.x)) return;
+    __shared__ double fr[2][256];
+    const int cl = threadIdx.x & 63, ty = threadIdx.x >> 6, c = c0 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C && cl < cg) {
+        // eight row blocks' partials in flight at a time (device-coherent loads are not batched by the compiler), added in block order
+        const long nbk = (long)gridDim.x;
+        for (long i0 = ty; i0 < nbk; i0 += 32) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long i = i0 + 4 * u;
+                va[u] = i < nbk ? ld_agent(partial + (i * 2 + 0) * C + c) : 0.0f;
+                vb[u] = i < nbk ? ld_agent(partial + (i * 2 + 1) * C + c) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a += (double)va[u];
+                b += (double)vb[u];
+            }
+        }
+    }
+    fr[0][threadIdx.x] = a;
+    fr[1][threadIdx.x] = b;
+    __syncthreads();
+    if (ty == 0 && c < C && cl < cg) {
+        for (int t = 1; t < 4; ++t) {
+            a += fr[0][t * 64 + cl];
+            b += fr[1][t * 64 + cl];
+        }
+        fin.dbeta[c] = fin.accumulate ? fin.dbeta[c] + (float)a : (float)a;
+        fin.dgamma[c] = fin.accumulate ? fin.dgamma[c] + (float)b : (float)b;
+        fin.coef[0 * C + c] = fin.gamma[c] * invstd[c];
+        fin.coef[1 * C + c] = fin.training ? (float)(a / (double)M) : 0.0f;
+        fin.coef[2 * C + c] = fin.training ? (float)(b / (double)M) : 0.0f;
     }
 }
 
@@ -1146,13 +1266,20 @@ int nn_set_option(const char* key, int value) {
 
 hipError_t launch_bn_finalize(float* partial, long n_slots, int rows_per_slot, long M, int C, const float* gamma,
                               const float* beta, float* run_mean, float* run_var, float momentum, float eps, float* scale,
-                              float* shift, float* save_mean, float* save_invstd, long long* num_batches_tracked, hipStream_t st_) {
+                              float* shift, float* save_mean, float* save_invstd, long long* num_batches_tracked, int* sync,
+                              hipStream_t st_) {
     long spg = 1;                                           // slots per group of level 1
     if (g_debug_skip_small & 1) return hipSuccess;
     if (n_slots > 128) {
         spg = (n_slots + 127) / 128;
         if (spg < 16) spg = 16;
         const long groups = (n_slots + spg - 1) / spg;
+        if (sync && groups > 1) {                           // one launch: the last workgroup of every channel group finalizes
+            hipLaunchKernelGGL(bn_stats_merge_finalize_kernel, dim3((C + 63) / 64, (unsigned)groups), dim3(256), 0, st_, partial, n_slots, spg,
+                               rows_per_slot, M, C, gamma, beta, run_mean, run_var, momentum, eps, scale, shift, save_mean, save_invstd,
+                               num_batches_tracked, sync);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL(bn_stats_merge_kernel, dim3((C + 63) / 64, (unsigned)groups), dim3(256), 0, st_, partial, n_slots, spg,
                            rows_per_slot, M, C);
     }
@@ -1181,17 +1308,26 @@ hipError_t launch_bn_apply(int bf16, const void* y, const void* res, const float
                 : bn_apply_t<float>(y, res, scale, shift, M, C, relu, out, st_);
 }
 
-long bn_bwd_blocks(long M) { return (M + BNB_ROWS - 1) / BNB_ROWS; }
+long bn_bwd_blocks(long M) { return (M + BNB_ROWS_MIN - 1) / BNB_ROWS_MIN; }       // upper bound (workspace sizing)
+// rows per workgroup of the reduce: 256, more for tall tensors so that the final sum over the row blocks (done by ONE workgroup per
+// channel group when the finalize is fused) stays short -- at most 512 row blocks
+static int bn_bwd_rows_per_block(long M) {
+    long r = BNB_ROWS_MIN;
+    while ((M + r - 1) / r > 512) r *= 2;
+    return (int)r;
+}
 
 template <typename T, int MASK>
 static hipError_t bn_bwd_t(const void* g_out, const void* out, const void* y, const float* mean, const float* invstd,
                            const float* gamma, const float* fsc, const float* fsh, long M, int C, int relu, int training,
                            int accumulate, float* partial, float* coef,
-                           float* dgamma, float* dbeta, void* g_y, void* g_res, hipStream_t st_) {
-    const long nb = bn_bwd_blocks(M);
+                           float* dgamma, float* dbeta, void* g_y, void* g_res, int* sync, hipStream_t st_) {
+    const int rpb = sync ? bn_bwd_rows_per_block(M) : BNB_ROWS_MIN;
+    const long nb = (M + rpb - 1) / rpb;
+    const BnBwdFin fin{gamma, training, accumulate, dgamma, dbeta, coef, (g_debug_skip_small & 2) ? nullptr : sync};
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK>), dim3((unsigned)nb, (unsigned)((C + BNB_CG - 1) / BNB_CG)), dim3(256), 0, st_,
-                       (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, fsc, fsh, M, C, relu, partial);
-    if (!(g_debug_skip_small & 2))
+                       (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, fsc, fsh, M, C, relu, partial, rpb, fin);
+    if (!(g_debug_skip_small & 2) && !sync)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st_, partial, nb, M, C, gamma, invstd, training, accumulate, dgamma,
                        dbeta, coef);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK>), dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_,
@@ -1201,12 +1337,12 @@ static hipError_t bn_bwd_t(const void* g_out, const void* out, const void* y, co
 hipError_t launch_bn_backward(int bf16, const void* g_out, const void* out, const void* y, const float* mean,
                               const float* invstd, const float* gamma, const float* fsc, const float* fsh, long M, int C, int relu,
                               int training, int accumulate, float* partial,
-                              float* coef, float* dgamma, float* dbeta, void* g_y, void* g_res, hipStream_t st_) {
+                              float* coef, float* dgamma, float* dbeta, void* g_y, void* g_res, int* sync, hipStream_t st_) {
     const int mask = !relu ? 0 : (out ? 1 : 2);
 #define BN_BWD_CASE(T_, MASK_)                                                                                                   \
     if (mask == MASK_)                                                                                                            \
         return bn_bwd_t<T_, MASK_>(g_out, out, y, mean, invstd, gamma, fsc, fsh, M, C, relu, training, accumulate, partial, coef, dgamma, dbeta, \
-                                   g_y, g_res, st_);
+                                   g_y, g_res, sync, st_);
     if (bf16) {
         BN_BWD_CASE(__bf16, 0) BN_BWD_CASE(__bf16, 1) BN_BWD_CASE(__bf16, 2)
     } else {

@@ -9,6 +9,7 @@ Every function here has exactly one implementation; CPU tensors are refused (no 
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Optional
 import weakref
 
@@ -155,6 +156,36 @@ def _conv_raw(x_rows, x2_rows, c1, w_hi, w_lo, out_shape, stat, n, h, w, cin, co
                                   n, h, w, cin, cout, kh, kw, stride, pad, int(reflect), up, ho, wo, int(precise), _stream())
     _check(rc, "vqseg_conv2d_f")
     return y
+
+
+def _bn_sync(bn, backward: bool):
+    """The BatchNorm module's own hand-over counters for the fused merge + finalize / reduce + finalize launches (include/vqseg.h,
+    `sync`): zeros between launches, never shared by concurrent launches -- one buffer per module, one half per direction (a
+    module's forwards and backwards are ordered on its network's stream).  OFF by default: measured on the bench step (r3, same
+    box, alternating) the one-launch forms are 0.3-2 % SLOWER than the two-launch ones -- the last workgroup's fold is a serial
+    tail read through device-coherent loads, and the launches it saves were not on the critical path (the other network's stream
+    covers them).  VQSEG_OPTS=py_bn_fused=1 switches them on."""
+    if not py_opt("py_bn_fused", 0):
+        return None
+    c = bn.num_features
+    g = lib().vqseg_bn_sync_ints(c)
+    buf = getattr(bn, "_vq_sync", None)
+    dev = bn.weight.device
+    if buf is None or buf.device != dev or buf.numel() != 2 * g:
+        buf = bn._vq_sync = torch.zeros(2 * g, dtype=torch.int32, device=dev)
+    return buf[g:] if backward else buf[:g]
+
+
+# Side streams for the weight-gradient kernels: {cuda_stream handle of a network's stream: torch.cuda.Stream}.  A trainer that owns
+# the parameters' .grad storage registers one per network stream (trainer.CPSTrainer), adds it to the buckets' producer streams
+# and joins it before the optimiser step.  Empty: everything stays on the calling stream.
+WGRAD_SIDE_STREAMS: dict = {}
+
+
+def _wgrad_side_stream(dev):
+    if not WGRAD_SIDE_STREAMS:
+        return None
+    return WGRAD_SIDE_STREAMS.get(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def _out_size(h, k, s, p):
@@ -350,7 +381,7 @@ def _conv_bn_act_s3(x: "S3", x2, residual, conv, bn, relu, kernel_1x1_cols: int 
         _check(L.vqseg_bn_finalize_f(None, n * ho * wo, cout, _f32(bn.weight, "bn.weight", cout), _f32(bn.bias, "bn.bias", cout),
                                      _f32(bn.running_mean, "bn.running_mean", cout), _f32(bn.running_var, "bn.running_var", cout),
                                      float(bn.momentum), float(bn.eps), 0, _f32(coef[0], "scale", cout),
-                                     _f32(coef[1], "shift", cout), _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout), None, _stream()),
+                                     _f32(coef[1], "shift", cout), _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout), None, None, _stream()),
                "vqseg_bn_finalize_f")
         _check(L.vqseg_conv2d_affine_f(_T(x.rows, "split-3 input", bf=2, numel=n * h * w * 2 * c1),
                                        _T(x2s.rows, "split-3 input 2", bf=2, numel=n * h * w * 2 * (cin - c1)) if x2s is not None else None, c1,
@@ -404,7 +435,7 @@ class _ConvBNAct(torch.autograd.Function):
                 _check(L.vqseg_bn_finalize_f(None, m, cout, _f32(gamma, "bn.weight", cout), _f32(beta, "bn.bias", cout),
                                              _f32(bn.running_mean, "bn.running_mean", cout), _f32(bn.running_var, "bn.running_var", cout),
                                              float(bn.momentum), float(bn.eps), 0, _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout),
-                                             _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout), None, _stream()), "vqseg_bn_finalize_f")
+                                             _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout), None, None, _stream()), "vqseg_bn_finalize_f")
                 _check(L.vqseg_conv2d_affine_f(_T(xr, "conv input", bf=bf, numel=n * h * w * c1), _T(x2r, "conv input 2", bf=bf, numel=n * h * w * (cin - c1)),
                                                c1, _w16(w_hi, "packed weights", wneed), _w16(w_lo, "packed weights (lo)", wneed),
                                                _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout),
@@ -421,6 +452,7 @@ class _ConvBNAct(torch.autograd.Function):
                                          float(bn.momentum), float(bn.eps), int(training), _f32(coef[0], "scale", cout),
                                          _f32(coef[1], "shift", cout), _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout),
                                          _T(bn.num_batches_tracked, "bn.num_batches_tracked", dtype=torch.int64, numel=1) if training else None,
+                                         _T(_bn_sync(bn, False), "bn sync", dtype=torch.int32) if training else None,
                                          _stream()),   # += 1 in the kernel
                    "vqseg_bn_finalize_f")
             rr = _rows(residual) if residual is not None else None
@@ -432,6 +464,7 @@ class _ConvBNAct(torch.autograd.Function):
                                       _T(out, "BN output", bf=bf, numel=m * cout), _stream()), "vqseg_bn_apply_f")
         ctx.save_for_backward(xr, x2r, y, out, coef, weight, gamma)
         ctx.params = (weight, gamma, beta)                                  # the Parameter objects (see grad sinks)
+        ctx.bn = bn
         ctx.links = (link_in, link_out, link_x)
         ctx.cfg = (stride, pad, bool(reflect), bool(relu), training, residual is not None, patches_of, (n, h, w, c1, cin, cout,
                                                                                                          kh, kw, ho, wo))
@@ -465,33 +498,44 @@ class _ConvBNAct(torch.autograd.Function):
                                          _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout), m, cout, int(relu), int(training), int(sink_bn),
                                          _f32(ws, "BN backward workspace"), _f32(dgamma, "bn.weight.grad", cout), _f32(dbeta, "bn.bias.grad", cout),
                                          _T(g_y, "conv output gradient", bf=bf, numel=m * cout), _T(g_res, "residual gradient", bf=bf, numel=m * cout),
-                                         _stream()), "vqseg_bn_backward_f")
+                                         _T(_bn_sync(ctx.bn, True), "bn sync", dtype=torch.int32), _stream()), "vqseg_bn_backward_f")
         if sink_bn:
             _sink_done(p_g), _sink_done(p_b)
         link_in, link_out, link_x = ctx.links
         if link_out is not None and has_res:
             link_out.g = g_res                                              # picked up by the block's first conv (GradLink)
-        # ---- weight gradient
+        # ---- weight gradient.  With a grad sink (the result is ADDED into the trainer's bucket, nothing returns to autograd) and a
+        # registered side stream, the weight-gradient kernel and its slab sum leave the network's stream: nothing downstream in
+        # backward depends on them, and as filler work they cover the latency-bound links of the main chain (BatchNorm statistics
+        # folds, finalizes, packs: skipping those ~950 launches -- wrong results, timing only -- was worth 11 ms of a 163 ms step)
         gw = p_w.grad if sink_w else torch.empty(weight.shape, dtype=torch.float32, device=dev)
-        if patches_of:
-            okh, okw, ocin = patches_of[0], patches_of[1], patches_of[2]
-            nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, 1, 1)
-            wsw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            with _hip.on_device(dev):
-                _check(L.vqseg_conv2d_wgrad_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), _T(xr, "stem patches", bf=bf, numel=n * h * w * cin),
-                                              None, cin, n, h, w, cin, ho, wo, cout, okh, okw, 1, 0, 0, int(precise), ocin, 1, int(sink_w),
-                                              _T(wsw, "wgrad workspace", dtype=torch.uint8, numel=nbytes), nbytes,
-                                              _f32(gw, "weight gradient", cout * ocin * okh * okw), _stream()),
-                       "vqseg_conv2d_wgrad_f")
-        else:
-            nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, kh, kw)
-            wsw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            with _hip.on_device(dev):
-                _check(L.vqseg_conv2d_wgrad_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), _T(xr, "conv input", bf=bf, numel=n * h * w * c1),
-                                              _T(x2r, "conv input 2", bf=bf, numel=n * h * w * (cin - c1)), c1, n, h, w, cin, ho, wo, cout, kh, kw,
-                                              stride, pad, int(reflect), int(precise), cin, 0, int(sink_w),
-                                              _T(wsw, "wgrad workspace", dtype=torch.uint8, numel=nbytes), nbytes,
-                                              _f32(gw, "weight gradient", cout * cin * kh * kw), _stream()), "vqseg_conv2d_wgrad_f")
+        wside = _wgrad_side_stream(dev) if sink_w else None
+        if wside is not None:
+            main_s = torch.cuda.current_stream(dev)
+            wside.wait_event(main_s.record_event())                             # g_y (bn_backward above) is complete
+            for t_ in (g_y, xr, x2r):
+                if t_ is not None:
+                    t_.record_stream(wside)                                     # allocator: not reusable before the side stream is done
+        with (torch.cuda.stream(wside) if wside is not None else contextlib.nullcontext()):
+            if patches_of:
+                okh, okw, ocin = patches_of[0], patches_of[1], patches_of[2]
+                nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, 1, 1)
+                wsw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                with _hip.on_device(dev):
+                    _check(L.vqseg_conv2d_wgrad_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), _T(xr, "stem patches", bf=bf, numel=n * h * w * cin),
+                                                  None, cin, n, h, w, cin, ho, wo, cout, okh, okw, 1, 0, 0, int(precise), ocin, 1, int(sink_w),
+                                                  _T(wsw, "wgrad workspace", dtype=torch.uint8, numel=nbytes), nbytes,
+                                                  _f32(gw, "weight gradient", cout * ocin * okh * okw), _stream()),
+                           "vqseg_conv2d_wgrad_f")
+            else:
+                nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, kh, kw)
+                wsw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                with _hip.on_device(dev):
+                    _check(L.vqseg_conv2d_wgrad_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), _T(xr, "conv input", bf=bf, numel=n * h * w * c1),
+                                                  _T(x2r, "conv input 2", bf=bf, numel=n * h * w * (cin - c1)), c1, n, h, w, cin, ho, wo, cout, kh, kw,
+                                                  stride, pad, int(reflect), int(precise), cin, 0, int(sink_w),
+                                                  _T(wsw, "wgrad workspace", dtype=torch.uint8, numel=nbytes), nbytes,
+                                                  _f32(gw, "weight gradient", cout * cin * kh * kw), _stream()), "vqseg_conv2d_wgrad_f")
         if sink_w:
             _sink_done(p_w)
         # ---- data gradient(s): the same implicit-GEMM kernel on g_y with tap-flipped, transposed weights

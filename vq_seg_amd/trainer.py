@@ -200,6 +200,7 @@ class CPSConfig:
     keep_aux: bool = False                    # keep the step's pseudo-label masks / scores in `CPSTrainer.aux` (parity tests)
     bucket_mb: float = 64.0
     two_streams: bool = True                  # each network of the pair on its own HIP stream (see CPSTrainer.__init__)
+    wgrad_side_stream: bool = False           # opt-in: weight-gradient kernels on a side stream per network (nnf.WGRAD_SIDE_STREAMS); measured +-0 (r3)
     seed: int = 42
     extra: dict = field(default_factory=dict)
 
@@ -254,8 +255,16 @@ class CPSTrainer:
         import os as _os
         self._two_streams = device.type == "cuda" and cfg.two_streams and _os.environ.get("VQSEG_TWO_STREAMS", "1") == "1"
         self._streams = [torch.cuda.Stream(device) for _ in self.models] if self._two_streams else []
+        # weight-gradient kernels (+ their slab sums) run on a side stream per network (nnf.WGRAD_SIDE_STREAMS): nothing later in
+        # backward depends on them, so they fill the chip under the latency-bound links of the main chain.  They add into the
+        # buckets, so the side streams are producer streams of the buckets and are joined before the optimiser step.
+        self._wgrad_streams = []
+        if self._two_streams and cfg.wgrad_side_stream and nnf.py_opt("py_wgrad_side", 1):
+            self._wgrad_streams = [torch.cuda.Stream(device) for _ in self.models]
         for b, s_ in zip(self.buckets, self._streams):
             b.producer_streams = [s_]
+        for b, s_, w_ in zip(self.buckets, self._streams, self._wgrad_streams):
+            b.producer_streams.append(w_)
         self._pending_sides = set()
         self.opts = [torch.optim.Adam(m.parameters(), lr=cfg.learning_rate, betas=(0.9, 0.999), fused=self.device.type == "cuda")
                      for m in self.models]
@@ -333,6 +342,14 @@ class CPSTrainer:
             main.wait_stream(s_)
         self._pending_sides.clear()
 
+    def _wgrad_sides(self, on: bool):
+        """register / unregister the weight-gradient side streams with nnf for the duration of a backward pass"""
+        for s_, w_ in zip(self._streams, self._wgrad_streams):
+            if on and self._two_streams:
+                nnf.WGRAD_SIDE_STREAMS[s_.cuda_stream] = w_
+            else:
+                nnf.WGRAD_SIDE_STREAMS.pop(s_.cuda_stream, None)
+
     def _side_stream(self, model):
         if not self._two_streams:
             return None
@@ -406,9 +423,13 @@ class CPSTrainer:
         for o in self.opts:
             o.param_groups[0]["lr"] = lr
         loss = sup_1 + sup_2 + cfg.cps_loss_weight * cps + commitment.sum() + prototype.float()
-        loss.backward()
-        if self._two_streams:                                           # the sinks wrote p.grad on the per-model streams
-            for s_ in self._streams:
+        self._wgrad_sides(True)
+        try:
+            loss.backward()
+        finally:
+            self._wgrad_sides(False)
+        if self._two_streams:                                           # the sinks wrote p.grad on the per-model (and side) streams
+            for s_ in self._streams + self._wgrad_streams:
                 torch.cuda.current_stream().wait_stream(s_)
         for b in self.buckets:
             b.finish()
