@@ -155,21 +155,49 @@ def bn_roofline(device):
 def pmc_traffic(shapes):
     """HBM bytes per launch of the distance+argmin kernel from the committed rocprofv3 --pmc summary of this same command
     (profiles/*_vq_assign_pmc.json: FETCH_SIZE x 2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), looked up by the
-    launch's grid: one launch serves the levels `shapes` = [(N, C, K), ...] of a forward.  PMC passes serialise kernels, so they
-    cannot run inside the timed bench."""
+    launch's grid and row type: one launch serves the levels `shapes` = [(N, C, K), ...] of a forward; -> ({"bf16": bytes, "f32":
+    bytes}, source file).  PMC passes serialise kernels, so they cannot run inside the timed bench."""
     import glob
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_vq_assign_pmc.json")))
     if not files:
-        return None, None
+        return {}, None
     table = json.load(open(files[-1]))["shapes"]
     for t in (8, 4, 2, 1):                                             # vq_group_tiles (csrc/vq_kernels.hip)
         if any(((k + 31) // 32) % t for _n, _c, k in shapes):
             continue
         wgs = sum(((n + 127) // 128 + 7) // 8 * 8 * (((k + 31) // 32) // t) for n, _c, k in shapes)
         if wgs >= 512 or t == 1:
-            e = table.get(f"WG{wgs}_T{t}")
-            return (round(e["hbm_bytes"]) if e else None), os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
-    return None, None
+            out = {}
+            for rows in ("bf16", "f32"):
+                e = table.get(f"WG{wgs}_T{t}_{rows}")
+                if e:
+                    out[rows] = round(e["hbm_bytes"])
+            return out, os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
+    return {}, None
+
+
+def vq_per_level(device, group, bf16_rows=True, reps=10):
+    """Each level of the grouped launch ALONE (its own launch of the same kernel, in-stream events, outside the timed region): the
+    grouped launch's time cannot be split by level, so the per-shape rates are measured, not apportioned."""
+    from vq_seg_amd import _hip
+    out = {}
+    for n, c, k in group:
+        x = torch.relu(torch.randn(n, c, device=device))
+        x = x.to(torch.bfloat16) if bf16_rows else x
+        W = torch.relu(torch.randn(k, c, device=device))
+        prep = _hip.vq_prepare(W)
+        for _ in range(3):
+            _hip.vq_assign(x, W, prepared=prep)
+        torch.cuda.synchronize()
+        _hip.profile_begin(2 * reps)
+        for _ in range(reps):
+            _hip.vq_assign(x, W, prepared=prep)
+        recs = _hip.profile_collect(2 * reps)
+        ms = sorted(r[3] for r in recs)[len(recs) // 2]
+        out[f"N{n}xC{c}xK{k}"] = {"alone_us": round(ms * 1e3, 1), "tflops": round(2.0 * n * c * k / ms / 1e9, 1),
+                                  "frac": round(2.0 * n * c * k / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}
+        del x, W, prep
+    return out
 
 
 def launch_ranks(n: int) -> int:
@@ -377,23 +405,23 @@ def main():
     if rank == 0:
         flops = sum(2.0 * n * c * k for n, c, k, _ in recs)
         ms = sum(r[3] for r in recs)
-        per_shape = {}
-        for n, c, k, m in recs:
-            e = per_shape.setdefault(f"N{n}xC{c}xK{k}", [0, 0.0, 2.0 * n * c * k])
-            e[0] += 1
-            e[1] += m
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # the other roof (quote both): algorithmic bytes per row = C*s_in (rows) + C*s_out (quantised rows) + 8 (index)
-        elem = 2 if args.dtype == "bf16" else 4
-        alg_bytes = sum(n * (2.0 * c * elem + 8) for n, c, k, _ in recs)
-        hbm_gbs = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         group = []                                               # the levels of one (grouped) launch: records until a shape repeats
         for n, c, k, _ in recs:
             if (n, c, k) in group:
                 break
             group.append((n, c, k))
         n_launch = len(recs) // max(len(group), 1)
-        traffic, traffic_src = pmc_traffic(group)
+        # Bytes the TIMED kernel moves, per launch and row type: the pixel rows in (C * s) + one 8-byte key per row out (the quantised
+        # rows are written by the gather kernel, not by this one) -- the figure `traffic` (PMC bytes of the same kernel) compares with.
+        # Per step the kernel runs 4 x on bf16 rows (training forwards) and 2 x on fp32 rows (pseudo-label forwards; all bf16 with --eval-amp).
+        n_bf16, n_f32 = ((6, 0) if args.eval_amp else (4, 2)) if args.dtype == "bf16" else (0, 6)
+        alg = {"bf16": round(sum(n * (c * 2.0 + 8) for n, c, k in group)), "f32": round(sum(n * (c * 4.0 + 8) for n, c, k in group))}
+        alg_avg = (n_bf16 * alg["bf16"] + n_f32 * alg["f32"]) / 6.0
+        hbm_gbs = alg_avg * n_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        tr, traffic_src = pmc_traffic(group)
+        traffic = round((n_bf16 * tr["bf16"] + n_f32 * tr["f32"]) / 6.0) if ("bf16" in tr and "f32" in tr) else (tr.get("bf16") if n_f32 == 0 else None)
+        per_shape = vq_per_level(device, group, bf16_rows=args.dtype == "bf16") if not args.no_extras else {}
         images = 2 * args.batch * world * args.steps
         line = {
             "metric": "train images/sec @512x512 vqreptunet1x1 K=512",
@@ -417,18 +445,21 @@ def main():
             "roofline": {"kernel": "vq_assign_f32_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_by_row_type": tr, "algorithmic_bytes_per_launch": round(alg_avg), "algorithmic_bytes_by_row_type": alg,
+                         "launch_mix_per_step": {"bf16 rows": n_bf16, "f32 rows": n_f32},
                          "other_roof": {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
-                                        "note": "algorithmic bytes (rows in + quantised rows out + index) over the same launch times: "
-                                                "the fp32 distance contraction sits far on the MFMA side of the ridge"},
+                                        "note": "algorithmic bytes of this kernel (rows in + one 8-byte key per row) over the same launch "
+                                                "times: the fp32 distance contraction sits far on the MFMA side of the ridge"},
                          "launches": n_launch, "levels_per_launch": len(group), "avg_launch_us": round(ms / max(n_launch, 1) * 1e3, 2),
-                         "algorithmic_bytes_per_launch": round(sum(n * (2.0 * c * elem + 8) for n, c, k in group)),
-                         "per_shape": {s: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2),
-                                           "tflops": round(v[2] / (v[1] / v[0] * 1e-3) / 1e12, 2)}
-                                       for s, v in per_shape.items()},
-                         "note": "algorithmic flops 2*N*K*C per launch / HIP-event time on the launch stream, "
-                                 "all launches inside the timed region; peak = fp32 MFMA (MI355X_MICROARCH.md); the three levels of "
-                                 "a forward share ONE launch (longest workgroups first): its time is apportioned to the levels by flops"},
+                         "at_held_clock": {"clock_mhz": 2142, "peak": round(FP32_MFMA_PEAK_TFLOPS * 2142 / 2400, 1),
+                                           "frac": round(achieved / (FP32_MFMA_PEAK_TFLOPS * 2142 / 2400), 4),
+                                           "source": "profiles/r03_vq_wg_timeline.md: s_memtime / s_memrealtime inside this kernel = 2.14 GHz "
+                                                     "(the 157.3 TF/s peak is quoted at 2.4 GHz); `frac` above stays against the nominal peak"},
+                         "per_shape": per_shape,
+                         "note": "algorithmic flops 2*N*K*C per launch / HIP-event time on the launch stream, all launches inside the "
+                                 "timed region; peak = fp32 MFMA (MI355X_MICROARCH.md); the three levels of a forward share ONE launch "
+                                 "(longest workgroups first); per_shape = each level ALONE in its own launch, after the timed region"},
         }
         if sup_s is not None:
             line["supervised_step"] = {"images_per_sec": round(args.batch * world / sup_s, 2), "ms_per_step": round(sup_s * 1e3, 2),

@@ -640,3 +640,50 @@ def test_wrong_element_types_raise_in_python_instead_of_faulting_on_the_gpu():
     with pytest.raises(E, match="bn.weight: expected torch.float32"):
         nnf.conv_bn_act(xf, conv, bn)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_one_launch_batchnorm_forms_match_the_two_launch_forms(dtype):
+    """The opt-in one-launch statistics merge + finalize / backward reduce + finalize (include/vqseg.h `sync`: last-workgroup
+    hand-over through device-coherent accesses; VQSEG_OPTS=py_bn_fused=1) against the default two-launch forms on a tall tensor
+    (enough conv-epilogue slots for the two-level merge, several row blocks per channel group): forward statistics, running
+    statistics and outputs bit-identical (same fold order); parameter / input gradients to 1e-5 (the row-block partition differs);
+    twice in a row (the hand-over counters must come back to zero)."""
+    from vq_seg_amd import _hip, nnf
+    torch.manual_seed(4)
+    d = dev()
+    x = synth.relu_features(31, (8, 64, 96, 96)).to(d).to(dtype).contiguous(memory_format=torch.channels_last)
+    g = synth.uniform(32, (8, 128, 96, 96), -1, 1).to(d).to(dtype).contiguous(memory_format=torch.channels_last)
+
+    def run(fused):
+        conv = nn.Conv2d(64, 128, 3, padding=1, bias=False).to(d)
+        bn = nn.BatchNorm2d(128).to(d)
+        with torch.no_grad():
+            conv.weight.copy_(synth.uniform(33, (128, 64, 3, 3), -0.05, 0.05).to(d))
+            bn.weight.copy_(synth.uniform(34, (128,), 0.5, 1.5).to(d))
+        _hip.lib()
+        prev = _hip.PY_OPTS.get("py_bn_fused")
+        _hip.PY_OPTS["py_bn_fused"] = int(fused)
+        outs = []
+        try:
+            for _ in range(2):
+                xx = x.clone().requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+                    y = nnf.conv_bn_act(xx, conv, bn, relu=True)
+                y.backward(g)
+                outs.append((y.detach().clone(), xx.grad.clone(), conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                             bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()))
+                conv.weight.grad = bn.weight.grad = bn.bias.grad = None
+        finally:
+            if prev is None:
+                _hip.PY_OPTS.pop("py_bn_fused")
+            else:
+                _hip.PY_OPTS["py_bn_fused"] = prev
+        if fused:
+            assert int(bn._vq_sync.abs().sum()) == 0                        # counters back to zero
+        return outs
+    two, one = run(False), run(True)
+    for a, b in zip(two, one):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[5], b[5]) and torch.equal(a[6], b[6]) and torch.equal(a[7], b[7])
+        for i in (1, 2, 3, 4):
+            assert rel(b[i].float(), a[i].float()) < 1e-5, i

@@ -15,7 +15,8 @@ for name in ("fetch", "write", "mfma"):
         mt = re.search(r"vq_assign_f32_kernel(?:<(\d+)|ILi(\d+)E)", r["Kernel_Name"])   # demangled or mangled (bf16 rows) name
         t = int(mt.group(1) or mt.group(2))
         wgs = int(r["Grid_Size"]) // 256
-        key = f"WG{wgs}_T{t}"                                   # r2: one launch serves the three levels of a forward -> keyed by its grid
+        rows = "bf16" if "DF16b" in r["Kernel_Name"] or "__bf16" in r["Kernel_Name"] or "bfloat" in r["Kernel_Name"] else "f32"
+        key = f"WG{wgs}_T{t}_{rows}"                            # one launch serves the three levels of a forward -> keyed by its grid and row type
         acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         acc[key]["ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 out = {}
@@ -31,7 +32,7 @@ json.dump({"kernel": "vq_assign_f32_kernel", "source": "rocprofv3 --pmc passes o
           open(dst + "_vq_assign_pmc.json", "w"), indent=1)
 with open(dst + "_vq_assign_pmc.md", "w") as f:
     f.write("# vq_assign_f32_kernel: PMC summary (per launch, averages)\n\n")
-    f.write("| launch (workgroups, tiles/wave) | launches | HBM fetch MB (x2 corrected) | HBM write MB | MFMA busy | cycles / XCD |\n|---|---|---|---|---|---|\n")
+    f.write("| launch (workgroups, tiles/wave, row type) | launches | HBM fetch MB (x2 corrected) | HBM write MB | MFMA busy | cycles / XCD |\n|---|---|---|---|---|---|\n")
     for k, e in out.items():
         f.write(f"| {k} | {e['launches_sampled']} | {e['fetch_bytes'] / 1e6:.1f} | {e['write_bytes'] / 1e6:.2f} | {e['mfma_busy_frac'] * 100:.1f} % | {e['cycles_per_xcd']:.0f} |\n")
 print(open(dst + "_vq_assign_pmc.md").read())

@@ -156,14 +156,25 @@ def tptr(t, name: str, dtype=None, numel: Optional[int] = None, bf: Optional[int
     suite can feed every wrapper the wrong type (tests/test_abi_cpu.py).  None passes through as a null pointer."""
     if t is None:
         return None
+    if bf is not None:
+        dtype = _BF_DTYPE[bf]
+    try:                                                     # fast path: everything in order (one short-circuit expression per launch argument)
+        if (dtype is None or t.dtype is dtype or (type(dtype) is tuple and t.dtype in dtype)) and t.is_cuda and \
+                (numel is None or (t.numel() >= numel if at_least else t.numel() == numel)) and \
+                (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
+            return t.data_ptr()
+    except AttributeError:
+        pass
+    return _tptr_report(t, name, dtype, numel, at_least)
 
+
+def _tptr_report(t, name, dtype, numel, at_least):
+    """slow path of tptr: say exactly what is wrong (type, density, size before the device)"""
     def bad(msg):
         _NOT_ON_GPU.clear()
         return HipLibraryError(f"{name}: {msg}")
     if not isinstance(t, torch.Tensor):
         raise bad(f"expected a tensor, got {type(t).__name__}")
-    if bf is not None:
-        dtype = _BF_DTYPE[int(bf)]
     if dtype is not None and (t.dtype not in dtype if isinstance(dtype, tuple) else t.dtype != dtype):
         raise bad(f"expected {dtype}, got {t.dtype}")
     if not t.is_contiguous() and not (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)):
