@@ -17,9 +17,9 @@ timed region.  Rank 0 prints ONE JSON line.  Extra objects:
   roofline     -- the hand-written distance+argmin kernel (vq_assign_f32_kernel): algorithmic flops
                   2*N*K*C of every launch inside the timed region / its HIP-event time, vs the fp32
                   MFMA peak (157.3 TF/s, MI355X_MICROARCH.md)
-  cpu_baseline -- the CPU oracle's restatement of the same iteration (the building blocks of
-                  oracle/cps_ref.py) timed on this host's cores on a bounded sample (4 full 512x512 images, composed as
-                  2 eval forwards + 4 training forward/backwards); a reported baseline, not the target.
+  cpu_baseline -- the CPU oracle's restatement of the same iteration (oracle/cps_ref.py::CPSReference.step) timed on this
+                  host's cores on a bounded sample (1 labelled + 1 unlabelled 512x512 image per iteration, 3 timed iterations);
+                  a reported baseline, not the target.
 """
 from __future__ import annotations
 
@@ -52,49 +52,32 @@ def model_cfg():
 
 
 def cpu_baseline():
-    """CPU oracle (fp32, the box's CPU share) on a BOUNDED sample of the same workload: the two building blocks of a
-    CPS iteration -- one eval forward and one training forward+backward of one vqreptunet1x1 on a batch of 2 full
-    512x512 images -- are timed and composed:  t(iteration on 2 labelled + 2 unlabelled images) = 2 t_eval + 4 t_train
-    (oracle/cps_ref.py runs exactly that sequence; the loss block and the Adam steps are < 2 % and left out)."""
-    from oracle import torch_ref as R
+    """The CPU oracle's CPS iteration itself (oracle/cps_ref.py::CPSReference.step: 2 eval forwards, 4 training forwards, one backward
+    through both networks, 2 Adam steps, the loss / pseudo-label block -- the reference trainer's loop body restated on torch CPU ops,
+    pinned to the reference by tests/golden/cps_iter_v1.npz) on a BOUNDED sample of the same workload: 1 labelled + 1 unlabelled
+    512x512 image per iteration, fp32, the box's CPU share; one warm-up iteration, then REPS timed ones."""
+    from oracle import cps_ref
     from tests import golden_io, synth
     # threads: the CPUs this process may run on, capped at the GPU box's per-GPU CPU share (16) -- asking for all 256
     # hardware threads of the host over-subscribes that share and is ~10x slower
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
-    sd = synth.synth_state_dict(golden_io.layout("vqreptunet1x1"), 77)
-    ks = (0, 0, K_CODES, K_CODES, K_CODES)
-    CS, NB, REPS = SIZE, 4, 3                           # bounded sample (~15 s): 4 full 512x512 images, 3 timed repeats after a warm-up
-    x, gt = synth.uniform(1, (NB, 3, CS, CS)), synth.blob_labels(2, NB, CS, cell=32)
-
-    def run_eval():
-        with torch.no_grad():
-            R.vq_unet_forward({k: v.clone() for k, v in sd.items()}, x, False, ks)
-
-    def run_train():
-        p = {k: v.clone() for k, v in sd.items()}
-        for k, v in p.items():
-            if v.is_floating_point() and "running" not in k and "codebook" not in k and not k.startswith("prototype_loss."):
-                v.requires_grad_(True)
-        logits, closs, _, proto, _ = R.vq_unet_forward(p, x, True, ks, gt=gt, version=1, percent=80.0)
-        (R.dice_loss(logits, gt) + closs.sum() + 0.01 * proto.float()).backward()
-
-    run_eval()                                          # warm-up (thread pool, primitive caches)
-    t0 = time.time()
+    lay = golden_io.layout("vqreptunet1x1")
+    ref = cps_ref.CPSReference([synth.synth_state_dict(lay, 77), synth.synth_state_dict(lay, 78)], num_embeddings=(0, 0, K_CODES, K_CODES, K_CODES))
+    NB, REPS = 1, 3
+    l_in, l_tg = synth.blob_images(1, NB, SIZE, cell=32)
+    ul_in, _ = synth.blob_images(2, NB, SIZE, cell=32)
+    ref.step(l_in, l_tg, ul_in)                         # warm-up (thread pool, primitive caches)
+    times = []
     for _ in range(REPS):
-        run_eval()
-    t_eval = (time.time() - t0) / REPS
-    print(f"[bench] cpu baseline: eval forward {t_eval:.2f}s", file=sys.stderr, flush=True)
-    t0 = time.time()
-    for _ in range(REPS):
-        run_train()
-    t_train = (time.time() - t0) / REPS
-    print(f"[bench] cpu baseline: train forward+backward {t_train:.2f}s", file=sys.stderr, flush=True)
-    dt = 2 * t_eval + 4 * t_train                       # NB labelled + NB unlabelled images
+        t0 = time.time()
+        out = ref.step(l_in, l_tg, ul_in)
+        times.append(time.time() - t0)
+        print(f"[bench] cpu baseline: CPS iteration on {NB}+{NB} images {times[-1]:.2f}s (loss {out['loss']:.4f})", file=sys.stderr, flush=True)
+    dt = sum(times) / len(times)
     return {"value": round(2.0 * NB / dt, 5), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle/torch_ref.py on {NB} images of {CS}x{CS}, fp32, {cores} threads, mean of {REPS} runs after a warm-up: "
-                      f"eval forward {t_eval:.2f}s, train forward+backward {t_train:.2f}s; composed as a CPS iteration on {NB} "
-                      f"labelled + {NB} unlabelled images = 2*eval + 4*train = {dt:.1f}s per {2 * NB} images"}
+            "sample": f"oracle/cps_ref.py::CPSReference.step (the whole CPS iteration, v1 recipe, K = {K_CODES}) on {NB} labelled + {NB} unlabelled "
+                      f"image of {SIZE}x{SIZE}, fp32, {cores} threads: mean of {REPS} iterations after a warm-up = {dt:.2f}s per {2 * NB} images"}
 
 
 def bn_roofline(device):
