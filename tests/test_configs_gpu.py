@@ -298,3 +298,54 @@ def test_bf16_argmin_mismatch_rate_is_reported():
     lines.append(f"logits: max |bf16 - fp32| = {rel:.2e} of scale; arg-max class agrees on {100 * agree:.2f} % of the pixels")
     print("\n".join(lines))
     assert rel < 0.2 and agree > 0.9
+
+
+def test_whole_model_with_live_kmeans_codebooks_matches_the_oracle():
+    """the model-level fixtures build their codebooks from copies of the model's own feature rows (well separated
+    winners by construction).  Here the calibrated network at 512^2 gets LIVE codebooks -- the package's 10-iteration k-means on its
+    own fp32 eval features, K = 512 at every level, no dead code -- and its no-grad eval forward (the split-3 path of the pseudo-label
+    passes) is compared with the CPU oracle on the same state: code indices of the three levels equal except rows whose two candidates
+    are within 1e-4 relative in float64 (the features themselves differ by ~1e-5 between the devices, so a near-tie below that may
+    legitimately flip; each such row is audited and counted), dead-code percentages equal, and -- when no index differs -- logits
+    within north_star's 1e-3 of scale."""
+    from oracle import torch_ref as R
+    from tests.test_model_gpu import build, rel_close
+    from vq_seg_amd import nnf
+    from vq_seg_amd.vector_quantizer.vq_img import kmeans
+    size = 512
+    model = build("vqreptunet1x1", 0.0, 1.0, 77, size=size)
+    x, _gt, _ = cases.model_inputs(s=size)
+    xd = x.to(dev()).contiguous(memory_format=torch.channels_last)
+    model.eval()
+    torch.manual_seed(11)
+    with torch.no_grad():
+        feats = model.encoder(xd)[1:]
+        for lvl in (2, 3, 4):
+            f = feats[lvl].float()
+            rows = f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]).contiguous()
+            k = min(512, rows.shape[0] // 2)
+            means, _bins = kmeans(rows, k, 10)
+            cb = model.codebook[lvl].codebook
+            w = cb.embedding.weight.data
+            w.copy_(means.repeat((512 + k - 1) // k, 1)[:512])          # K = 512 slots; levels with fewer rows repeat their means
+            cb.initted = True                                             # (duplicates: the LOWEST index must win, on both sides)
+        nnf.invalidate_weight_caches(model)
+        logits, _closs, usage, _proto = model(xd)
+        idx = [model.codebook[lvl](feats[lvl])[1].cpu() for lvl in (2, 3, 4)]
+    sd = {k_: v.detach().float().cpu() if v.is_floating_point() else v.cpu() for k_, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref_logits, _c, ref_usage, _p, aux = R.vq_unet_forward(sd, x, False, (0, 0, 512, 512, 512), version=1)
+    report, total_bad = [], 0
+    for got, want, lvl in zip(idx, aux["indices"], (2, 3, 4)):
+        f = feats[lvl].float()
+        rows = f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]).contiguous()
+        W = model.codebook[lvl].codebook.embedding.weight.detach()
+        n_bad, gap, excess = cases.near_tie_audit(rows, W, got.reshape(-1).to(dev()), want.reshape(-1).to(dev()))
+        total_bad += n_bad
+        report.append(f"level {lvl}: {rows.shape[0]} rows, index != oracle in {n_bad}" + (f" (fp64 gap of the two candidates <= {gap:.1e})" if n_bad else ""))
+        assert n_bad <= 3 and gap < 1e-4 and excess < 1e-4, report[-1]
+    assert torch.allclose(usage.double().cpu(), torch.stack([u.double() for u in ref_usage]).cpu(), atol=0.25)
+    if total_bad == 0:
+        rel_close(logits, ref_logits, 1e-3, "eval logits with live codebooks")
+    report.append(f"dead codes GPU {usage.tolist()} oracle {[float(u) for u in ref_usage]}; indices differing in total: {total_bad}")
+    print("\n".join(report))
