@@ -128,7 +128,7 @@ def test_dice_and_ce_dice_match_oracle(layout):
     xx = xg.clone().requires_grad_(True)
     got = ce_dice_loss(xx, t.to(dev()), 3, 0.5, None, 255)
     got.backward()
-    assert abs(float(got.detach()) - float(want)) <= 1e-5 * abs(float(want)) and rel(xx.grad, xc.grad) < 2e-5
+    assert abs(float(got.detach()) - float(want.detach())) <= 1e-5 * abs(float(want.detach())) and rel(xx.grad, xc.grad) < 2e-5
     assert (xx.grad[3] == 0).all()
 
 
