@@ -165,6 +165,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
         }
         return;
     }
+    // Whole tile inside the output (always for the 2-D pixel tiles of the patch kernel; every tile but the last one otherwise): the
+    // per-element row tests (a 64-bit compare + select each, twice per accumulator in the statistics, once per store) drop out.
+    // These epilogues are VALU-issue bound on the short-K layers (see the LIN note at conv_igemm_glds_kernel).
+    const bool full = !__is_same(RowMap, LinearRows) || m0 + TBM <= M;          // workgroup-uniform
     if (p.stat_partial && !(GLDS_ABL & 4)) {
         // one (mean, M2) partial per SLOT of RPS consecutive rows: 64 rows (two 32-row tiles) or 32 when the wave has one
         constexpr int TPS = (MT >= 2 && BN >= 64) ? 2 : 1, RPS = TPS * 32;   // vqseg_conv_stat_slots: 64 rows per slot from 64 output channels on, else 32
@@ -175,27 +179,42 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
 #pragma unroll
             for (int g = 0; g < MT / TPS; ++g) {
                 const long srow0 = wrow0 + g * RPS;
-                float sum = 0.0f;
+                float sum = 0.0f, mean, m2 = 0.0f;
+                if (full) {
 #pragma unroll
-                for (int a = g * TPS; a < (g + 1) * TPS; ++a)
+                    for (int a = g * TPS; a < (g + 1) * TPS; ++a)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (m < M) sum += acc[a][b][i];
-                    }
-                long cnt_l = M - srow0;
-                const float cnt = (float)(cnt_l < 0 ? 0 : (cnt_l > RPS ? RPS : cnt_l));
-                sum += __shfl_xor(sum, 32);
-                const float mean = cnt > 0.f ? sum / cnt : 0.f;
-                float m2 = 0.0f;
+                        for (int i = 0; i < 16; ++i) sum += acc[a][b][i];
+                    sum += __shfl_xor(sum, 32);
+                    mean = sum / (float)RPS;
 #pragma unroll
-                for (int a = g * TPS; a < (g + 1) * TPS; ++a)
+                    for (int a = g * TPS; a < (g + 1) * TPS; ++a)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        const float d = acc[a][b][i] - mean;
-                        if (m < M) m2 = __builtin_fmaf(d, d, m2);
-                    }
+                        for (int i = 0; i < 16; ++i) {
+                            const float d = acc[a][b][i] - mean;
+                            m2 = __builtin_fmaf(d, d, m2);
+                        }
+                } else {
+#pragma unroll
+                    for (int a = g * TPS; a < (g + 1) * TPS; ++a)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                            if (m < M) sum += acc[a][b][i];
+                        }
+                    long cnt_l = M - srow0;
+                    const float cnt = (float)(cnt_l < 0 ? 0 : (cnt_l > RPS ? RPS : cnt_l));
+                    sum += __shfl_xor(sum, 32);
+                    mean = cnt > 0.f ? sum / cnt : 0.f;
+#pragma unroll
+                    for (int a = g * TPS; a < (g + 1) * TPS; ++a)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const long m = wrow0 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                            const float d = acc[a][b][i] - mean;
+                            if (m < M) m2 = __builtin_fmaf(d, d, m2);
+                        }
+                }
                 m2 += __shfl_xor(m2, 32);
                 if (h == 0 && cok) {
                     const long slot = srow0 / RPS;                        // global slot index along M
@@ -232,6 +251,28 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
         }
         __syncthreads();
         constexpr int CPR = BN / O_EPC;                     // 16-byte chunks per tile row
+        if constexpr (__is_same(RowMap, LinearRows) && NTHR % CPR == 0 && (TBM * CPR) % NTHR == 0) {
+            if (full && !ep_res && !p.omap) {
+                // whole tile, plain rows: one base address per thread, then constant strides (the generic loop below spends ~25 VALU
+                // instructions per 16-byte store on row tests and 64-bit address arithmetic)
+                const int ch = tid % CPR, row0 = tid / CPR;
+                if (co0 + ch * O_EPC < p.Cout) {
+                    constexpr int ESZ = PRECISE ? 4 : 2;
+                    char* gp = reinterpret_cast<char*>(p.y) + ((m0 + row0) * (long)p.Cout + co0 + ch * O_EPC) * ESZ;
+                    const long gstep = (long)(NTHR / CPR) * p.Cout * ESZ;
+                    const char* lp = ot + ((size_t)row0 * OS + ch * O_EPC) * ESZ;
+#pragma unroll
+                    for (int it = 0; it < TBM * CPR / NTHR; ++it) {
+#if GLDS_ABL & 1
+                        if (it == 12345)
+#endif
+                        *reinterpret_cast<u32x4*>(gp) = *reinterpret_cast<const u32x4*>(lp + (size_t)it * (NTHR / CPR) * OS * ESZ);
+                        gp += gstep;
+                    }
+                }
+                return;
+            }
+        }
         for (int idx = tid; idx < TBM * CPR; idx += NTHR) {
             const int row = idx / CPR, ch = idx % CPR;
             const long m = row_to_m(row);
@@ -534,7 +575,11 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int TBM, int BN, int NW, int NBUF, int MINW = 1, bool S3 = false>
+// LIN: 1x1 / stride 1 / no padding, output pixel grid == input pixel grid: GEMM row m IS input pixel m.  The generic prologue
+// spends ~600 VALU instructions per wave on (image, row, column) splits and tap geometry that such a layer does not need -- and
+// these launches are VALU-ISSUE bound, not memory bound (rocprofv3 SQ_INSTS_VALU: 1544 per wave for a tile whose K loop is 16 MFMAs;
+// 16 resident waves per CU x 1544 x 4 cycles = 94 of the 111 us of the 64 -> 256 layer at 128^2; profiles/LEDGER.md, round 3).
+template <int TBM, int BN, int NW, int NBUF, int MINW = 1, bool S3 = false, bool LIN = false>
 __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const ConvArgs p) {
     constexpr int BK = 64;
     // wave grid WM x WN over the TBM x BN tile; wave tile (MT*32) x (NT*32)
@@ -573,18 +618,24 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
     const int slot = lane & 7;
     int a_n[A_INSTR], a_oh[A_INSTR], a_ow[A_INSTR], a_chunk[A_INSTR];
     bool a_ok[A_INSTR];
+    long a_pix[A_INSTR];                                   // pixel offset of this lane's rows for the current tap, -1 = zero
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
         const int trow = 8 * (A_INSTR * wave + i) + (lane >> 3);
         long m = m0 + trow;
         a_ok[i] = m < M;
-        if (!a_ok[i]) m = M - 1;
-        int n, rem;
-        split_row(m, p.Ho * p.Wo, M, n, rem);
-        a_n[i] = n;
-        a_oh[i] = rem / p.Wo;
-        a_ow[i] = rem - a_oh[i] * p.Wo;
         a_chunk[i] = slot ^ ((trow >> 1) & 7);           // channel chunk (8 bf16) this lane fetches for its slot
+        if constexpr (LIN) {
+            a_pix[i] = a_ok[i] ? m : -1;
+            a_n[i] = a_oh[i] = a_ow[i] = 0;
+        } else {
+            if (!a_ok[i]) m = M - 1;
+            int n, rem;
+            split_row(m, p.Ho * p.Wo, M, n, rem);
+            a_n[i] = n;
+            a_oh[i] = rem / p.Wo;
+            a_ow[i] = rem - a_oh[i] * p.Wo;
+        }
     }
     // ---- this lane's B rows (weights): wave w covers tile rows [w * BN/NW, (w+1) * BN/NW)
     // byte offset of (row, swizzled slot) inside the packed image, ~0u: no such row (zero page); the (tap, chunk) part of the
@@ -613,8 +664,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
     const int n_stage = n_taps * chunks_per_tap;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
-    long a_pix[A_INSTR];                                   // pixel offset of this lane's rows for the current tap, -1 = zero
-    int cur_tap = -1;
+    int cur_tap = LIN ? 0 : -1;                            // LIN: one tap, a_pix set above
     auto set_tap = [&](int tap) {
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
@@ -738,8 +788,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
 static int g_glds_pair = 4;                                 // layers with 2..this many Cout chunks: the chunks of an M tile share an XCD
                                                             // (1-D launch, see the kernel; measured -3..-6 % at 2-4 chunks, +5 % at 8)
 
+template <int TBM, int BN, int NW, int NBUF, int MINW = 1, bool LIN = false>
+static void launch_glds_lin(const ConvArgs& a, hipStream_t st);
+
+static int g_glds_lin = 1;                                  // 1x1 / stride 1 / pad 0 layers take the linear-pixel prologue (LIN)
 template <int TBM, int BN, int NW, int NBUF, int MINW = 1>
 static void launch_glds_t(const ConvArgs& a, hipStream_t st) {
+    const bool lin = g_glds_lin && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.pad_w == 0 && a.up == 1 && !a.omap &&
+                     a.Ho == a.H && a.Wo == a.W;
+    if (lin) launch_glds_lin<TBM, BN, NW, NBUF, MINW, true>(a, st);
+    else launch_glds_lin<TBM, BN, NW, NBUF, MINW, false>(a, st);
+}
+
+template <int TBM, int BN, int NW, int NBUF, int MINW, bool LIN>
+static void launch_glds_lin(const ConvArgs& a, hipStream_t st) {
     const int n_stage = a.KH * a.KW * (a.Cin / 64);
     // ring slots actually used: a short K loop (1x1 layers with 64..128 input channels) then leaves LDS for more
     // resident workgroups, whose loads overlap each other's epilogues
@@ -754,13 +816,13 @@ static void launch_glds_t(const ConvArgs& a, hipStream_t st) {
         b.pair_chunks = chunks;
         b.pair_tiles = (int)m_tiles;
         const dim3 grid1((unsigned)((m_tiles + 7) / 8 * 8 * chunks));
-        if (a.out_s3) hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW, true>), grid1, dim3(NW * 64), lds, st, b);
-        else hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW>), grid1, dim3(NW * 64), lds, st, b);
+        if (a.out_s3) hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW, true, LIN>), grid1, dim3(NW * 64), lds, st, b);
+        else hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW, false, LIN>), grid1, dim3(NW * 64), lds, st, b);
         return;
     }
     dim3 grid((unsigned)m_tiles, (unsigned)chunks);
-    if (a.out_s3) hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW, true>), grid, dim3(NW * 64), lds, st, a);
-    else hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW>), grid, dim3(NW * 64), lds, st, a);
+    if (a.out_s3) hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW, true, LIN>), grid, dim3(NW * 64), lds, st, a);
+    else hipLaunchKernelGGL((conv_igemm_glds_kernel<TBM, BN, NW, NBUF, MINW, false, LIN>), grid, dim3(NW * 64), lds, st, a);
 }
 
 // =====================================================================================================
@@ -1063,6 +1125,11 @@ int conv_set_option(const char* key, int value) {
     if (key && !strcmp(key, "conv3x3_patch_unroll")) {
         const int prev = g_patch_unroll;
         g_patch_unroll = value;
+        return prev;
+    }
+    if (key && !strcmp(key, "conv_linear_prologue")) {
+        const int prev = g_glds_lin;
+        g_glds_lin = value ? 1 : 0;
         return prev;
     }
     if (key && !strcmp(key, "conv_xcd_pair")) {
