@@ -687,3 +687,35 @@ def test_one_launch_batchnorm_forms_match_the_two_launch_forms(dtype):
         assert torch.equal(a[0], b[0]) and torch.equal(a[5], b[5]) and torch.equal(a[6], b[6]) and torch.equal(a[7], b[7])
         for i in (1, 2, 3, 4):
             assert rel(b[i].float(), a[i].float()) < 1e-5, i
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 8, 1, 4), (2, 128, 32, 8), (1, 1024, 2, 2)])
+def test_exact_2x_bilinear_kernels_are_bit_identical_to_the_generic_ones(shape, dtype):
+    """The decoder's resize to a skip of twice the size (align_corners = False) takes bilinear_up2_{fwd,bwd}_kernel on power-of-two
+    extents: same expressions, values and order as the generic kernels (`vqseg_set_option("bilinear_up2", 0)`), so forward and
+    backward must agree bit for bit -- borders (clamped taps folding onto one row / column, extents of 1 and 2) included -- and with
+    ATen's upsample_bilinear2d to the usual tolerance."""
+    from vq_seg_amd import _hip, nnf
+    L = _hip.lib()
+    n, c, h, w = shape
+    x = synth.uniform(41, shape, -2, 2).to(dev()).to(dtype).contiguous(memory_format=torch.channels_last)
+    g = synth.uniform(42, (n, c, 2 * h, 2 * w), -1, 1).to(dev()).to(dtype).contiguous(memory_format=torch.channels_last)
+
+    def run():
+        xx = x.clone().requires_grad_(True)
+        y = nnf.upsample_bilinear(xx, size=(2 * h, 2 * w), align_corners=False)
+        y.backward(g)
+        return y.detach().clone(), xx.grad.clone()
+    fast = run()
+    prev = L.vqseg_set_option(b"bilinear_up2", 0)
+    try:
+        generic = run()
+    finally:
+        L.vqseg_set_option(b"bilinear_up2", prev)
+    assert torch.equal(fast[0], generic[0]) and torch.equal(fast[1], generic[1])
+    xr = x.float().cpu().requires_grad_(True)
+    yr = F.interpolate(xr, size=(2 * h, 2 * w), mode="bilinear", align_corners=False)
+    yr.backward(g.float().cpu())
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel(fast[0].float(), yr) < tol and rel(fast[1].float(), xr.grad) < tol

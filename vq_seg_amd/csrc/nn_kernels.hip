@@ -823,6 +823,97 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Exact 2x up-sampling with align_corners = false (the decoder's resize to the next skip, decoder.py:35, whenever the skip is twice
+// the size -- every power-of-two input) on power-of-two extents.  The generic kernels above are VALU-ISSUE bound (rocprofv3
+// SQ_INSTS_VALU: issue time / kernel time 0.95 forward, 1.07 backward -- profiles/r03_step_valu_issue.txt): per vector they
+// spend three run-time integer divisions on the index split, and the backward searches 7 x 7 candidate output pixels through
+// bil_src() for the (at most) 4 x 4 that touch an input pixel.  At scale 2 the source coordinate of output o is o / 2 - 1/4:
+//   o = 2 i (> 0): taps (i - 1, i) with weights (1/4, 3/4);   o = 2 i + 1: taps (i, min(i + 1, in - 1)) with (3/4, 1/4);   o = 0: tap 0
+// -- all exactly representable, so these kernels evaluate the SAME expressions on the SAME values in the SAME order as the generic
+// ones (bit-identical; tests/test_nn_gpu.py compares them), with shifts for the index split.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void up2_src(int o, int in, int& i0, int& i1, float& l1) {
+    const int i = o >> 1;
+    if (o & 1) {
+        i0 = i;
+        i1 = i + (i < in - 1 ? 1 : 0);
+        l1 = 0.25f;
+    } else if (o == 0) {
+        i0 = 0;
+        i1 = in > 1 ? 1 : 0;
+        l1 = 0.0f;
+    } else {
+        i0 = i - 1;
+        i1 = i;
+        l1 = 0.75f;
+    }
+}
+
+template <typename T, int VC>
+__global__ __launch_bounds__(256) void bilinear_up2_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C, int lcv, int lwo, int lho,
+                                                               T* __restrict__ y) {
+    constexpr int V = VecN<T>::N;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long total = ((long)N << (lcv + lwo + lho));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = ((int)i & ((1 << lcv) - 1)) * VC;
+        const int ow = (int)(i >> lcv) & (Wo - 1), oh = (int)(i >> (lcv + lwo)) & (Ho - 1), n = (int)(i >> (lcv + lwo + lho));
+        int h0, h1, w0, w1;
+        float lh, lw;
+        up2_src(oh, H, h0, h1, lh);
+        up2_src(ow, W, w0, w1, lw);
+        const long b = (long)n * H;
+        float v00[V], v01[V], v10[V], v11[V], o[V];
+        ldc<T, VC>(x, ((b + h0) * W + w0) * C + c, v00);
+        ldc<T, VC>(x, ((b + h0) * W + w1) * C + c, v01);
+        ldc<T, VC>(x, ((b + h1) * W + w0) * C + c, v10);
+        ldc<T, VC>(x, ((b + h1) * W + w1) * C + c, v11);
+#pragma unroll
+        for (int e = 0; e < VC; ++e)
+            o[e] = (1.0f - lh) * ((1.0f - lw) * v00[e] + lw * v01[e]) + lh * ((1.0f - lw) * v10[e] + lw * v11[e]);
+        stc<T, VC>(y, i * VC, o);                             // i enumerates (n, oh, ow, c / VC): the output's own order
+    }
+}
+
+template <typename T, int VC>
+__global__ __launch_bounds__(256) void bilinear_up2_bwd_kernel(const T* __restrict__ g, int N, int H, int W, int C, int lcv, int lw_, int lh_,
+                                                               T* __restrict__ gx) {
+    constexpr int V = VecN<T>::N;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long total = ((long)N << (lcv + lw_ + lh_));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = ((int)i & ((1 << lcv) - 1)) * VC;
+        const int iw = (int)(i >> lcv) & (W - 1), ih = (int)(i >> (lcv + lw_)) & (H - 1), n = (int)(i >> (lcv + lw_ + lh_));
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < VC; ++e) acc[e] = 0.0f;
+        // output rows 2 ih - 1 .. 2 ih + 2 touch input row ih with weights 1/4, 3/4, 3/4, 1/4; at the borders the clamped neighbour folds
+        // onto the same row: output 0 gives row 0 weight 1, output 2 H - 1 gives row H - 1 weight 3/4 + 1/4 (the generic kernel's sums)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int oh = 2 * ih - 1 + a;
+            if (oh < 0 || oh >= Ho) continue;
+            float wh = (a == 0 || a == 3) ? 0.25f : 0.75f;
+            if (a == 1 && ih == 0) wh = 1.0f;
+            if (a == 2 && ih == H - 1) wh = 0.75f + 0.25f;
+#pragma unroll
+            for (int bq = 0; bq < 4; ++bq) {
+                const int ow = 2 * iw - 1 + bq;
+                if (ow < 0 || ow >= Wo) continue;
+                float ww = (bq == 0 || bq == 3) ? 0.25f : 0.75f;
+                if (bq == 1 && iw == 0) ww = 1.0f;
+                if (bq == 2 && iw == W - 1) ww = 0.75f + 0.25f;
+                float gv[V];
+                ldc<T, VC>(g, (((long)n * Ho + oh) * Wo + ow) * C + c, gv);
+#pragma unroll
+                for (int e = 0; e < VC; ++e) acc[e] += wh * ww * gv[e];
+            }
+        }
+        stc<T, VC>(gx, i * VC, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // 1x1 segmentation head (Cin <= 64 -> Cout <= 4, no bias): forward, data gradient, weight gradient
 // ---------------------------------------------------------------------------------------------
 // 8 consecutive channels of row `row` (Cin per row) as floats: T = float / __bf16 rows, or split-3 rows (S3Row tag: [hi | lo])
@@ -1261,6 +1352,10 @@ int nn_set_option(const char* key, int value) {
         g_debug_skip_small = value;
         return prev;
     }
+    if (key && !strcmp(key, "bilinear_up2")) {
+        extern int bilinear_up2_option(int);
+        return bilinear_up2_option(value);
+    }
     return -1;
 }
 
@@ -1384,9 +1479,30 @@ hipError_t launch_maxpool(int bf16, int backward, const void* x, const void* g, 
     return hipGetLastError();
 }
 
+static int g_bilinear_up2 = 1;                              // exact-2x fast kernels (bit-identical to the generic ones)
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+int bilinear_up2_option(int value) {
+    const int prev = g_bilinear_up2;
+    g_bilinear_up2 = value ? 1 : 0;
+    return prev;
+}
+
 template <typename T, int VC>
 static void bilinear_t(int backward, const void* src, int N, int H, int W, int C, int Ho, int Wo, int align, void* dst,
                        hipStream_t st_) {
+    const int cv = C / VC;
+    if (g_bilinear_up2 && VC > 1 && !align && Ho == 2 * H && Wo == 2 * W && is_pow2(cv) && is_pow2(H) && is_pow2(W) &&
+        (long)N * Ho * Wo * cv < (1L << 40)) {
+        if (!backward)
+            hipLaunchKernelGGL((bilinear_up2_fwd_kernel<T, VC>), dim3(grid_for((long)N * Ho * Wo * cv)), dim3(256), 0, st_, (const T*)src, N, H,
+                               W, C, ilog2(cv), ilog2(Wo), ilog2(Ho), (T*)dst);
+        else
+            hipLaunchKernelGGL((bilinear_up2_bwd_kernel<T, VC>), dim3(grid_for((long)N * H * W * cv)), dim3(256), 0, st_, (const T*)src, N, H, W,
+                               C, ilog2(cv), ilog2(W), ilog2(H), (T*)dst);
+        return;
+    }
     if (!backward)
         hipLaunchKernelGGL((bilinear_fwd_kernel<T, VC>), dim3(grid_for((long)N * Ho * Wo * (C / VC))), dim3(256), 0, st_, (const T*)src, N,
                            H, W, C, Ho, Wo, align, (T*)dst);
