@@ -159,3 +159,20 @@ def test_eval_forward_with_widths_the_split3_kernels_reject_falls_back_to_the_pr
                 _hip.PY_OPTS["py_s3_eval"] = prev
     assert got.shape == want.shape == (2, 3, 64, 64) and torch.isfinite(got).all()
     assert rel(got, want) < 2e-4, rel(got, want)
+
+
+def test_split3_exact_2x_resize_is_bit_identical_to_the_generic_kernel():
+    """s3_bilinear_up2_kernel (2x, align_corners = False, power-of-two extents) against s3_bilinear_kernel (`bilinear_up2` = 0)."""
+    from vq_seg_amd import _hip, nnf
+    L = _hip.lib()
+    for shape in ((2, 64, 16, 16), (1, 8, 1, 2), (2, 256, 4, 32)):
+        x = (synth.uniform(5, shape, -3, 3) * synth.uniform(6, shape, 0, 1) ** 3).to(dev()).contiguous(memory_format=torch.channels_last)
+        s = nnf.to_s3(x)
+        size = (2 * shape[2], 2 * shape[3])
+        fast = nnf.upsample_bilinear(s, size=size, align_corners=False).rows.clone()
+        prev = L.vqseg_set_option(b"bilinear_up2", 0)
+        try:
+            generic = nnf.upsample_bilinear(s, size=size, align_corners=False).rows.clone()
+        finally:
+            L.vqseg_set_option(b"bilinear_up2", prev)
+        assert torch.equal(fast, generic)

@@ -1882,7 +1882,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             if (ci >= Cin_out) continue;
         }
         double s = 0.0;
-        for (int z = 0; z < slabs; ++z) s += (double)partial[(long)z * slab + i];
+        int z = 0;
+        for (; z + 3 < slabs; z += 4) {                     // four slabs' values in flight (latency bound), added in slab order
+            const float v0 = partial[(long)z * slab + i], v1 = partial[(long)(z + 1) * slab + i];
+            const float v2 = partial[(long)(z + 2) * slab + i], v3 = partial[(long)(z + 3) * slab + i];
+            s += (double)v0;
+            s += (double)v1;
+            s += (double)v2;
+            s += (double)v3;
+        }
+        for (; z < slabs; ++z) s += (double)partial[(long)z * slab + i];
         float* dst = gw + (((long)co * Cin_out + ci) * KH + kh) * KW + kw;
         *dst = accumulate ? *dst + (float)s : (float)s;
     }

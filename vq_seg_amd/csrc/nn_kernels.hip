@@ -85,8 +85,32 @@ __device__ __forceinline__ PowerSums fold_slots(const float* partial, long s0, l
     const int ty = threadIdx.x >> 6, cl = threadIdx.x & 63;
     PowerSums a{0.0, 0.0};
     auto rd = [&](long idx) { return COHERENT ? ld_agent(partial + idx) : partial[idx]; };
+    long i_first = s0 + ty * step;
+    if (c < C && merged) {
+        // level-2 fold (bn_finalize): up to 32 dependent-free iterations of four loads each were issued one iteration at a time
+        // (16 us for a kernel of C / 64 workgroups on the critical path conv -> statistics -> apply); four iterations' loads in
+        // flight, added in the same order
+        for (; i_first + 12 * step + 1 < s1; i_first += 16 * step) {
+            float u[4], v[4], ul[4], vl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long i = i_first + 4 * step * q;
+                u[q] = rd((i * 2 + 0) * C + c);
+                v[q] = rd((i * 2 + 1) * C + c);
+                ul[q] = rd((i * 2 + 2) * C + c);
+                vl[q] = rd((i * 2 + 3) * C + c);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a.s1 += (double)u[q];
+                a.s2 += (double)v[q];
+                a.s1 += (double)ul[q];
+                a.s2 += (double)vl[q];
+            }
+        }
+    }
     if (c < C)
-        for (long i = s0 + ty * step; i < s1; i += 4 * step) {
+        for (long i = i_first; i < s1; i += 4 * step) {
             const double u = (double)rd((i * 2 + 0) * C + c), v = (double)rd((i * 2 + 1) * C + c);
             if (merged) {
                 a.s1 += u;
@@ -449,7 +473,21 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     const int c = blockIdx.x;
     __shared__ double r0[256], r1[256];
     double a = 0.0, b = 0.0;
-    for (long i = threadIdx.x; i < n_blocks; i += 256) {
+    long i = threadIdx.x;
+    for (; i + 768 < n_blocks; i += 1024) {                // four row blocks' partials in flight (latency bound), same order of adds
+        float va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            va[u] = partial[((i + 256 * u) * 2 + 0) * C + c];
+            vb[u] = partial[((i + 256 * u) * 2 + 1) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a += (double)va[u];
+            b += (double)vb[u];
+        }
+    }
+    for (; i < n_blocks; i += 256) {
         a += (double)partial[(i * 2 + 0) * C + c];
         b += (double)partial[(i * 2 + 1) * C + c];
     }
@@ -738,6 +776,15 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 // bilinear resize (NHWC), both corner conventions (ATen upsample_bilinear2d semantics)
 //   align_corners: src = dst * (in-1)/(out-1);  else src = max((dst+0.5)*in/out - 0.5, 0)
 // ---------------------------------------------------------------------------------------------
+// (1 - lh) * ((1 - lw) * v00 + lw * v01) + lh * ((1 - lw) * v10 + lw * v11) with the multiply-adds spelled out: the generic and the
+// exact-2x kernels (and their split-3 forms) must round identically, and the compiler's own choice of which product of a sum to fuse
+// differs between kernels whose weights are run-time values and kernels whose weights are constants
+__device__ __forceinline__ float bil_mix(float v00, float v01, float v10, float v11, float lh, float lw) {
+    const float top = __builtin_fmaf(lw, v01, (1.0f - lw) * v00);
+    const float bot = __builtin_fmaf(lw, v11, (1.0f - lw) * v10);
+    return __builtin_fmaf(lh, bot, (1.0f - lh) * top);
+}
+
 __device__ __forceinline__ void bil_src(int d, int in, int out, int align, int& i0, int& i1, float& l1) {
     float s;
     if (align) s = out > 1 ? (float)d * ((float)(in - 1) / (float)(out - 1)) : 0.0f;
@@ -773,7 +820,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__
         ldc<T, VC>(x, ((b + h1) * W + w1) * C + c, v11);
 #pragma unroll
         for (int e = 0; e < VC; ++e)
-            o[e] = (1.0f - lh) * ((1.0f - lw) * v00[e] + lw * v01[e]) + lh * ((1.0f - lw) * v10[e] + lw * v11[e]);
+            o[e] = bil_mix(v00[e], v01[e], v10[e], v11[e], lh, lw);
         stc<T, VC>(y, (((long)n * Ho + oh) * Wo + ow) * C + c, o);
     }
 }
@@ -815,7 +862,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
                 float gv[V];
                 ldc<T, VC>(g, (((long)n * Ho + oh) * Wo + ow) * C + c, gv);
 #pragma unroll
-                for (int e = 0; e < VC; ++e) acc[e] += wh * ww * gv[e];
+                for (int e = 0; e < VC; ++e) acc[e] = __builtin_fmaf(wh * ww, gv[e], acc[e]);
             }
         }
         stc<T, VC>(gx, (((long)n * H + ih) * W + iw) * C + c, acc);
@@ -870,7 +917,7 @@ __global__ __launch_bounds__(256) void bilinear_up2_fwd_kernel(const T* __restri
         ldc<T, VC>(x, ((b + h1) * W + w1) * C + c, v11);
 #pragma unroll
         for (int e = 0; e < VC; ++e)
-            o[e] = (1.0f - lh) * ((1.0f - lw) * v00[e] + lw * v01[e]) + lh * ((1.0f - lw) * v10[e] + lw * v11[e]);
+            o[e] = bil_mix(v00[e], v01[e], v10[e], v11[e], lh, lw);
         stc<T, VC>(y, i * VC, o);                             // i enumerates (n, oh, ow, c / VC): the output's own order
     }
 }
@@ -906,7 +953,7 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd_kernel(const T* __restri
                 float gv[V];
                 ldc<T, VC>(g, (((long)n * Ho + oh) * Wo + ow) * C + c, gv);
 #pragma unroll
-                for (int e = 0; e < VC; ++e) acc[e] += wh * ww * gv[e];
+                for (int e = 0; e < VC; ++e) acc[e] = __builtin_fmaf(wh * ww, gv[e], acc[e]);
             }
         }
         stc<T, VC>(gx, i * VC, acc);
@@ -1057,6 +1104,22 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     const bool vec = (n & 3) == 0 && i + 3 < n;      // 16-byte aligned slab rows
     if (i < n) {
         long b = rowl;
+        // the slab sums are latency bound (a thread's loads are its only work): four independent 16-byte loads in flight per
+        // thread, added in the SAME order as the two-load loop below (s0: slabs b, b + 8, ...; s1: b + 4, b + 12, ...)
+        if (vec)
+            for (; b + 12 < n_blocks; b += 16) {
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(partial + b * n + i);
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(partial + (b + 4) * n + i);
+                const f32x4 u1 = *reinterpret_cast<const f32x4*>(partial + (b + 8) * n + i);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(partial + (b + 12) * n + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s0[e] += (double)u0[e];
+                    s1[e] += (double)v0[e];
+                    s0[e] += (double)u1[e];
+                    s1[e] += (double)v1[e];
+                }
+            }
         for (; b + 4 < n_blocks; b += 8) {
             if (vec) {
                 const f32x4 u = *reinterpret_cast<const f32x4*>(partial + b * n + i);
@@ -1290,7 +1353,32 @@ __global__ __launch_bounds__(256) void s3_bilinear_kernel(const unsigned short* 
         s3_load8(x + ((b + h1) * W + w1) * 2 * C, C, c, v11);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            o[e] = (1.0f - lh) * ((1.0f - lw) * v00[e] + lw * v01[e]) + lh * ((1.0f - lw) * v10[e] + lw * v11[e]);
+            o[e] = bil_mix(v00[e], v01[e], v10[e], v11[e], lh, lw);
+        s3_store8(y + (((long)n * Ho + oh) * Wo + ow) * 2 * C, C, c, o);
+    }
+}
+
+// exact 2x / align_corners = false / power-of-two extents: see bilinear_up2_fwd_kernel (same values, expressions and order)
+__global__ __launch_bounds__(256) void s3_bilinear_up2_kernel(const unsigned short* __restrict__ x, int N, int H, int W, int C, int lcv, int lwo,
+                                                              int lho, unsigned short* __restrict__ y) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long total = ((long)N << (lcv + lwo + lho));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = ((int)i & ((1 << lcv) - 1)) * 8;
+        const int ow = (int)(i >> lcv) & (Wo - 1), oh = (int)(i >> (lcv + lwo)) & (Ho - 1), n = (int)(i >> (lcv + lwo + lho));
+        int h0, h1, w0, w1;
+        float lh, lw;
+        up2_src(oh, H, h0, h1, lh);
+        up2_src(ow, W, w0, w1, lw);
+        const long b = (long)n * H;
+        float v00[8], v01[8], v10[8], v11[8], o[8];
+        s3_load8(x + ((b + h0) * W + w0) * 2 * C, C, c, v00);
+        s3_load8(x + ((b + h0) * W + w1) * 2 * C, C, c, v01);
+        s3_load8(x + ((b + h1) * W + w0) * 2 * C, C, c, v10);
+        s3_load8(x + ((b + h1) * W + w1) * 2 * C, C, c, v11);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            o[e] = bil_mix(v00[e], v01[e], v10[e], v11[e], lh, lw);
         s3_store8(y + (((long)n * Ho + oh) * Wo + ow) * 2 * C, C, c, o);
     }
 }
@@ -1570,6 +1658,12 @@ hipError_t launch_s3_maxpool(const void* x, int N, int H, int W, int C, void* y,
     return hipGetLastError();
 }
 hipError_t launch_s3_bilinear(const void* x, int N, int H, int W, int C, int Ho, int Wo, int align, void* y, hipStream_t st_) {
+    const int cv = C / 8;
+    if (g_bilinear_up2 && !align && Ho == 2 * H && Wo == 2 * W && is_pow2(cv) && is_pow2(H) && is_pow2(W) && (long)N * Ho * Wo * cv < (1L << 40)) {
+        hipLaunchKernelGGL(s3_bilinear_up2_kernel, dim3(grid_for((long)N * Ho * Wo * cv)), dim3(256), 0, st_, (const unsigned short*)x, N, H, W, C,
+                           ilog2(cv), ilog2(Wo), ilog2(Ho), (unsigned short*)y);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(s3_bilinear_kernel, dim3(grid_for((long)N * Ho * Wo * (C / 8))), dim3(256), 0, st_, (const unsigned short*)x, N, H,
                        W, C, Ho, Wo, align, (unsigned short*)y);
     return hipGetLastError();
