@@ -115,7 +115,12 @@ def test_miou_parity_run(tmp_path):
     assert abs(a[-1] - b[-1]) <= 0.002, (a, b)                       # 0.2 mIoU points at the end
     assert np.abs(a - b).max() <= 0.03, (a, b)                       # and never far apart on the way (steep phase: 0.05 per step)
     assert b[-1] > b[0] + 0.1                                        # the run learns (so the comparison means something)
-    assert np.allclose(got["sup_loss_1"][:3], fx["sup_loss_1"].numpy()[:3], rtol=1e-3)
+    # the first losses: iteration 0 sees identical weights (1e-4); every later one comes after Adam steps whose first updates are
+    # ~ lr * sign(g) (lr = 1e-3 here), so a last-bit difference of ANY forward kernel (r3: the bilinear kernels' spelled-out fma order)
+    # moves iteration 2 by ~1e-3 -- the CPU oracle against itself under a 1e-5 input perturbation moves more
+    # (tests/diagnostics/cps_mask_sensitivity.py); the end of the curve above carries the bar that matters
+    for i, tol in enumerate((1e-4, 1e-3, 5e-3)):
+        assert abs(got["sup_loss_1"][i] - fx["sup_loss_1"].numpy()[i]) <= tol * abs(fx["sup_loss_1"].numpy()[i]), (i, got["sup_loss_1"][:3], fx["sup_loss_1"][:3])
 
 
 def test_miou_parity_run_bf16_autocast(tmp_path):
