@@ -58,6 +58,9 @@ __device__ __forceinline__ void stv(T* p, long i, const float (&v)[VecN<T>::N]) 
     *reinterpret_cast<u32x4*>(p + i) = raw;
 }
 
+#ifndef BN_UNROLL
+#define BN_UNROLL 1               // vectors in flight per thread in the streaming BatchNorm loops (A/B builds: make ab ABFLAGS=-DBN_UNROLL=2)
+#endif
 // ---------------------------------------------------------------------------------------------
 // BatchNorm forward statistics
 // ---------------------------------------------------------------------------------------------
@@ -276,6 +279,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
             sc[e] = scale[c + e];
             sh[e] = shift[c + e];
         }
+#pragma unroll BN_UNROLL
         for (long i = i0; i < total; i += (long)gridDim.x * 256 * V) {
             float v[V], r[V];
             ldv(y, i, v);
@@ -362,6 +366,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 sc[e] = MASK == 2 ? fsc[c0 + cv + e] : 0.0f;
                 sf[e] = MASK == 2 ? fsh[c0 + cv + e] : 0.0f;
             }
+#pragma unroll BN_UNROLL
             for (int rr = rl; rr < BNB_ROWS; rr += lanes) {
                 const long m = row0 + rr;
                 if (m >= M) break;
@@ -532,6 +537,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             sc[e] = MASK == 2 ? fsc[c + e] : 0.0f;
             sf[e] = MASK == 2 ? fsh[c + e] : 0.0f;
         }
+#pragma unroll BN_UNROLL
         for (long i = i0; i < total; i += (long)gridDim.x * 256 * V) {
             float g[V], o[V], yy[V], r[V];
             ldv(g_out, i, g);
