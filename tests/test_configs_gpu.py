@@ -10,6 +10,7 @@ Also: one decoder block at the benchmark's own channel / pixel counts against th
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from tests import cases, golden_io, synth
 
@@ -349,3 +350,52 @@ def test_whole_model_with_live_kmeans_codebooks_matches_the_oracle():
         rel_close(logits, ref_logits, 1e-3, "eval logits with live codebooks")
     report.append(f"dead codes GPU {usage.tolist()} oracle {[float(u) for u in ref_usage]}; indices differing in total: {total_bad}")
     print("\n".join(report))
+
+
+def test_config_1_plain_unet_at_its_own_size_matches_the_oracle():
+    """BASELINE config #1 (`config/CWFID_Unet.json`, plain UNet, 256 x 256, batch 2 -- "on CPU" in the reference; this repository has
+    no CPU path by design, so the configuration runs on the MI355X and the CPU side is the ORACLE): eval and train-mode forward at
+    256^2 against oracle/torch_ref.py::unet_forward on the same state (logits 1e-3 of scale), and one step of the intended
+    supervised recipe (deprecated/train_baseline.py:128-140: loss = Dice + 0.5 CE, Adam) -- loss within 1e-4 of the oracle's, the
+    sampled weight gradients within the model-level bar, every parameter finite after the step."""
+    from oracle import torch_ref as R
+    from tests.test_model_gpu import close, grad_close, rel_close
+    from vq_seg_amd.loss import make_loss
+    from vq_seg_amd.models.networks import make_model
+    size, batch = 256, 2
+    model = make_model({"name": "unet", "params": {"encoder_name": "resnet50", "num_classes": 3, "depth": 5, "encoder_weights": "imagenet_swsl"}})
+    sd = synth.synth_state_dict(golden_io.layout("unet"), 91)
+    model.load_state_dict(sd)
+    model = model.to(dev())
+    x, gt, _ = cases.model_inputs(b=batch, s=size, seed=6700)
+    cases.set_bn_momentum(model, 1.0)                                 # calibrate the running statistics on the batch (as the fixtures do)
+    model.train()
+    with torch.no_grad():
+        model(x.to(dev()))
+    cases.set_bn_momentum(model, 0.1)
+    state = {k: (v.detach().float().cpu() if v.is_floating_point() else v.cpu()) for k, v in model.state_dict().items()}
+    model.eval()
+    with torch.no_grad():
+        y_eval = model(x.to(dev()))
+        ref_eval = R.unet_forward({k: v.clone() for k, v in state.items()}, x, False)
+    assert y_eval.shape == (batch, 3, size, size)
+    rel_close(y_eval, ref_eval, 1e-3, "config 1 eval logits at 256^2")
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    y = model(x.to(dev()))
+    loss = make_loss("dice_loss", 3, ignore_index=255)(y, gt.to(dev())) + 0.5 * F.cross_entropy(y, gt.to(dev()), ignore_index=255)
+    p = {k: v.clone() for k, v in state.items()}
+    probes = ["segmentation_head.0.weight", "encoder.conv1.weight", "decoder.blocks.4.1.0.weight"]
+    for k in probes:
+        p[k].requires_grad_(True)
+    ref_y = R.unet_forward(p, x, True)
+    ref_loss = R.dice_loss(ref_y, gt) + 0.5 * F.cross_entropy(ref_y, gt, ignore_index=255)
+    rel_close(y, ref_y, 1e-3, "config 1 train logits at 256^2")
+    close(loss, ref_loss, rtol=1e-4, what="Dice + 0.5 CE")
+    loss.backward()
+    ref_loss.backward()
+    named = dict(model.named_parameters())
+    for k in probes:
+        grad_close(golden_io.probe(named[k].grad), golden_io.probe(p[k].grad), 3e-2, 0.15, "grad " + k)
+    opt.step()
+    assert all(torch.isfinite(v).all() for v in model.parameters())
