@@ -101,7 +101,8 @@ struct LinearRows {                                          // tile row -> outp
     __device__ __forceinline__ long operator()(int row) const { return m0 + row; }
 };
 
-template <int TBM, int BN, bool PRECISE, int MT, int NTT, int NT, int NTHR, typename RowMap = LinearRows, bool S3 = false>
+// FAST: compile the whole-tile fast paths (the register-staged conv_igemm_kernel opts out: they cost it 24 VGPRs = half its occupancy)
+template <int TBM, int BN, bool PRECISE, int MT, int NTT, int NT, int NTHR, typename RowMap = LinearRows, bool S3 = false, bool FAST = true>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const ConvArgs& p, char* smem, long M, long m0, int co0,
                                               int wm, int wn, int r, int h, int tid, RowMap row_to_m = LinearRows{-1}) {
     if constexpr (__is_same(RowMap, LinearRows)) row_to_m.m0 = m0;
@@ -168,7 +169,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
     // Whole tile inside the output (always for the 2-D pixel tiles of the patch kernel; every tile but the last one otherwise): the
     // per-element row tests (a 64-bit compare + select each, twice per accumulator in the statistics, once per store) drop out.
     // These epilogues are VALU-issue bound on the short-K layers (see the LIN note at conv_igemm_glds_kernel).
-    const bool full = !__is_same(RowMap, LinearRows) || m0 + TBM <= M;          // workgroup-uniform
+    const bool full = FAST && (!__is_same(RowMap, LinearRows) || m0 + TBM <= M);          // workgroup-uniform
     if (p.stat_partial && !(GLDS_ABL & 4)) {
         // one (mean, M2) partial per SLOT of RPS consecutive rows: 64 rows (two 32-row tiles) or 32 when the wave has one
         constexpr int TPS = (MT >= 2 && BN >= 64) ? 2 : 1, RPS = TPS * 32;   // vqseg_conv_stat_slots: 64 rows per slot from 64 output channels on, else 32
@@ -251,7 +252,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
         }
         __syncthreads();
         constexpr int CPR = BN / O_EPC;                     // 16-byte chunks per tile row
-        if constexpr (__is_same(RowMap, LinearRows) && NTHR % CPR == 0 && (TBM * CPR) % NTHR == 0) {
+        if constexpr (FAST && __is_same(RowMap, LinearRows) && NTHR % CPR == 0 && (TBM * CPR) % NTHR == 0) {
             if (full && !ep_res && !p.omap) {
                 // whole tile, plain rows: one base address per thread, then constant strides (the generic loop below spends ~25 VALU
                 // instructions per 16-byte store on row tests and 64-bit address arithmetic)
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         __syncthreads();
     }
 
-    conv_epilogue<BM, BN, PRECISE, MT, NTT, NT, 256, LinearRows, S3>(acc, p, smem, M, m0, co0, wm, wn, r, h, tid);
+    conv_epilogue<BM, BN, PRECISE, MT, NTT, NT, 256, LinearRows, S3, false>(acc, p, smem, M, m0, co0, wm, wn, r, h, tid);
 }
 
 // =====================================================================================================
