@@ -243,6 +243,16 @@ int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, 
                          int ho, int wo, int cout, int kh, int kw, int stride, int pad, int reflect, int precise,
                          int cin_out, int im2col, int accumulate, void* workspace, size_t workspace_bytes, float* gw,
                          void* stream);
+/* The same weight gradient summed over TWO uses of the layer in one launch: (gy, x, x2) with n images and (gy_b, x_b, x2_b) with
+ * n_b images of the same geometry form a virtual batch of n + n_b images.  In a cross-pseudo-supervision step every weight is
+ * used by two training forwards per network (labelled and unlabelled batch: train_vqreptunet1x1v2.py:153-156, one backward
+ * :199): the caller queues the first use's (gy, x) and issues one launch over both -- twice the contraction length per
+ * workgroup, half the slab sums.  n_b == 0: identical to vqseg_conv2d_wgrad_f.  Workspace: vqseg_conv2d_wgrad_workspace_bytes
+ * with n + n_b images. */
+int vqseg_conv2d_wgrad2_f(const void* gy, const void* x, const void* x2, int n, const void* gy_b, const void* x_b, const void* x2_b,
+                          int n_b, int c1, int h, int w, int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad,
+                          int reflect, int precise, int cin_out, int im2col, int accumulate, void* workspace, size_t workspace_bytes,
+                          float* gw, void* stream);
 
 /* nn.BatchNorm2d (+ fused residual add and ReLU).  Training: batch statistics merged from the conv
  * epilogue partials (Welford/Chan, double, fixed order), running stats updated like nn.BatchNorm2d
@@ -395,6 +405,36 @@ int vqseg_confusion_counts_f(const float* logits, int64_t stride_b, int64_t stri
 size_t vqseg_order_stats_workspace_bytes(void);
 int vqseg_order_stats_f(const float* x, int64_t n, int64_t k, void* workspace, size_t workspace_bytes, float* out2,
                         void* stream);
+
+/* ---------------------------------------------------------------------------------- *
+ * The optimiser step: torch.optim.Adam(model.parameters(), lr, betas=(0.9, 0.999)) created at train_vqreptunet1x1v2.py:106-107
+ * and stepped at :200-201 (eps 1e-8, no weight decay, no amsgrad), for ALL parameters of a network in ONE launch, with the
+ * kernel-side bf16 images of the k x k convolution weights (the three images of vqseg_conv_pack_all_f32) rewritten in the same
+ * pass from the freshly updated values.  fp32 arithmetic in the operation order of torch/optim/adam.py::_single_tensor_adam:
+ *     m = fma(1 - b1, g - m, m);  v = fma((1 - b2) g, g, v b2);  p = p + (-(lr / (1 - b1^t)) m) / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * (`step` = t >= 1, the value AFTER this step's increment; the scalars are evaluated in double like torch's Python floats).
+ *   params_dev [n_params] VqsegAdamParam records in DEVICE memory; items_dev [n_items][2] int32 (parameter index, tile index) in
+ *   DEVICE memory: for every parameter its vqseg_adam_work_items() tiles 0 .. count-1, in any order.
+ *   k = 0: plain parameter, tiles are flat chunks of VQSEG_ADAM_CHUNK elements;
+ *   k = 1 / 3: nn.Conv2d weight [cout][cin][k][k], tiles of 32 output x 128 / 32 input channels; fwd / tr / s3 (each nullable):
+ *   the images [cout][k][k][cin^32], [cin][k][k flipped][cout^32], [cout][k][k][3 cin] ([w_hi | w_hi | w_lo] per concat segment
+ *   split at c1; needs cin % 32 == 0 and c1 % 32 == 0) -- bit-identical to vqseg_conv_pack_all_f32 of the updated weight.
+ * ---------------------------------------------------------------------------------- */
+#define VQSEG_ADAM_CHUNK 4096
+typedef struct VqsegAdamParam {
+    float* p;            /* parameter        [numel] f32, updated in place */
+    const float* g;      /* gradient         [numel] f32 */
+    float* m;            /* exp_avg          [numel] f32, updated in place */
+    float* v;            /* exp_avg_sq       [numel] f32, updated in place */
+    int64_t numel;
+    int32_t k, cout, cin, c1;
+    void* fwd;
+    void* tr;
+    void* s3;
+} VqsegAdamParam;
+int64_t vqseg_adam_work_items(int64_t numel, int k, int cout, int cin);
+int vqseg_adam_step_f32(const VqsegAdamParam* params_dev, const int32_t* items_dev, int n_items, double lr, double beta1,
+                        double beta2, double eps, int64_t step, void* stream);
 
 #ifdef __cplusplus
 }

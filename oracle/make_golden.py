@@ -558,6 +558,19 @@ def gen_curve(ref):
                               source="tests/cps_loop.py::run_curve on the reference's modules (v1 recipe, fp32 CPU)"), **out)
 
 
+def gen_curve128(ref):
+    """r4: the thicker mIoU-parity run: 128x128, K = 512 at the three levels, 200 v1 iterations on the
+    reference's modules, test mIoU every 25 steps."""
+    from tests import cps_loop
+    import time
+    t0 = time.time()
+    out = cps_loop.run_curve(_ref_ns(ref), torch.device("cpu"), to_cfg=ref.AttrDict, prepare=prepare_model, k=cps_loop.K128,
+                             spec=cps_loop.CURVE128)
+    print(f"  curve128: {time.time() - t0:.0f}s  test mIoU {out['test_miou']}")
+    save("cps_curve_v1_128", dict(spec=cps_loop.CURVE128, k=list(cps_loop.K128),
+                                  source="tests/cps_loop.py::run_curve on the reference's modules (v1 recipe, fp32 CPU)"), **out)
+
+
 def probe(t, limit=16384, take=4096):
     """Large tensors are stored as a strided sample (fixtures stay small)."""
     flat = t.detach().reshape(-1)
@@ -577,7 +590,7 @@ def main():
     ref = ref_harness.ref_modules()
     which = set(sys.argv[1:]) or {"vq", "kmeans", "decoder", "proto", "losses", "models", "models128", "unet", "cps", "curve", "block"}
     for tag, fn in (("vq", gen_vq), ("kmeans", gen_kmeans), ("decoder", gen_decoder), ("proto", gen_proto),
-                    ("losses", gen_losses), ("models", gen_models), ("models128", gen_models128), ("unet", gen_unet), ("cps", gen_cps), ("curve", gen_curve), ("block", gen_decoder_block), ("vqbig", gen_vq_big)):
+                    ("losses", gen_losses), ("models", gen_models), ("models128", gen_models128), ("unet", gen_unet), ("cps", gen_cps), ("curve", gen_curve), ("curve128", gen_curve128), ("block", gen_decoder_block), ("vqbig", gen_vq_big)):
         if tag in which:
             print(f"[{tag}]")
             fn(ref)

@@ -235,6 +235,9 @@ def run_iterations(ns, version: int, device, n_iters: int = 2, backward: bool = 
 
 
 CURVE = dict(size=64, batch=4, steps=40, eval_every=10, eval_images=16, learning_rate=1e-3)
+# r4: the thicker mIoU-parity run -- 128x128, the shipped codebook size K = 512 at all three levels, 200 steps
+CURVE128 = dict(size=128, batch=4, steps=200, eval_every=25, eval_images=16, learning_rate=1e-3)
+K128 = (0, 0, 512, 512, 512)
 
 
 def run_curve(ns, device, to_cfg=lambda d: d, prepare=None, half: bool = False, amp_dtype=torch.float16, k=(0, 0, 64, 64, 64),

@@ -169,3 +169,22 @@ def test_nnf_kernels_refuse_wrong_types_before_touching_a_device():
         nnf._strided_f32(torch.zeros(1, 3, 4, 4), "logits", 96)
     with pytest.raises(E, match="no CPU fallback"):
         nnf.softmax_stats(torch.zeros(1, 3, 4, 4), True, True)       # all types right on a CPU tensor: the device error surfaces
+
+
+def test_hip_adam_has_no_cpu_path_and_keeps_torch_adams_layout():
+    """optim.HipAdam (r4): a torch.optim.Adam whose step is the HIP kernel -- CPU parameters are refused (no fallback), the
+    argument checks of the entry point and the work-item count are host-side."""
+    from vq_seg_amd.optim import HipAdam
+    p = torch.nn.Parameter(torch.ones(4, 4))
+    opt = HipAdam([p], lr=0.1)
+    assert isinstance(opt, torch.optim.Adam) and opt.defaults["betas"] == (0.9, 0.999) and opt.defaults["eps"] == 1e-8
+    p.grad = torch.ones(4, 4)
+    with pytest.raises(_hip.HipLibraryError, match="no CPU fallback"):
+        opt.step()
+    assert torch.equal(p.detach(), torch.ones(4, 4))              # nothing was updated behind the error
+    L = _hip.lib()
+    assert L.vqseg_adam_work_items(4096 * 3 + 1, 0, 0, 0) == 4
+    assert L.vqseg_adam_work_items(64 * 32 * 9, 3, 64, 32) == 2 and L.vqseg_adam_work_items(256 * 64, 1, 256, 64) == 8
+    assert L.vqseg_adam_step_f32(None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1, None) == -1
+    # the second source of a two-use weight gradient must come with its tensors
+    assert L.vqseg_conv2d_wgrad2_f(None, None, None, 1, None, None, None, 1, 8, 4, 4, 8, 4, 4, 8, 3, 3, 1, 1, 0, 0, 8, 0, 0, None, 0, None, None) == -1

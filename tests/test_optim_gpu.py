@@ -1,0 +1,239 @@
+"""Round-4 step-level kernels through the C ABI:
+  * vqseg_adam_step_f32 / optim.HipAdam against torch.optim.Adam (non-fused, single-tensor) on the CPU in fp32 -- the reference's
+    optimiser call (train_vqreptunet1x1v2.py:106-107, :200-201): parameters and both moments within 1e-7 of scale after several
+    steps; the weight images written in the same pass bit-identical to vqseg_conv_pack_all_f32 of the updated weight;
+  * vqseg_conv2d_wgrad2_f (one weight-gradient launch over the two uses of a layer in a training step) against fp64 on the same
+    bf16 values, for every weight-gradient kernel family."""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+ADAM_SHAPES = [(64, 32, 3, 3), (40, 24, 3, 3), (256, 64, 1, 1), (96, 200, 1, 1), (128, 192, 3, 3), (64,), (3,), (5001,), (3, 32), (64, 3, 7, 7),
+               (32, 160, 1, 1)]
+
+
+def _params(device, with_kinds):
+    ps = []
+    for i, shp in enumerate(ADAM_SHAPES):
+        p = nn.Parameter(synth.uniform(100 + i, shp, -0.2, 0.2).to(device))
+        if with_kinds and len(shp) == 4 and shp[2] in (1, 3):
+            cin = shp[1]
+            p._vq_kinds = {"fwd", "tr"} | ({("s3", 128 if cin == 192 else cin)} if cin % 32 == 0 else set())
+        ps.append(p)
+    return ps
+
+
+def _grads(step, device):
+    return [(synth.uniform(1000 + 50 * step + i, shp, -1.0, 1.0) * (10.0 ** ((i % 5) - 3))).to(device) for i, shp in enumerate(ADAM_SHAPES)]
+
+
+def test_hip_adam_matches_torch_adam_on_the_cpu_and_rewrites_the_weight_images():
+    from vq_seg_amd import nnf
+    from vq_seg_amd.optim import HipAdam
+    cpu_p, gpu_p = _params("cpu", False), _params(dev(), True)
+    # gradient storage as the trainer's buckets hand it out: views into ONE flat buffer at offsets that are not 16-byte multiples
+    flat = torch.zeros(sum(p.numel() for p in gpu_p) + 1, device=dev())
+    off = 1
+    for p in gpu_p:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    ref = torch.optim.Adam(cpu_p, lr=3e-3, betas=(0.9, 0.999), foreach=False, fused=False)
+    opt = HipAdam(gpu_p, lr=3e-3, betas=(0.9, 0.999))
+    for step in range(6):
+        lr = 3e-3 * (1.0 - 0.1 * step)
+        for o in (ref, opt):
+            o.param_groups[0]["lr"] = lr
+        for p, q, g in zip(cpu_p, gpu_p, _grads(step, "cpu")):
+            p.grad = g.clone()
+            q.grad.copy_(g)
+        ref.step()
+        opt.step()
+        torch.cuda.synchronize()
+        for i, (p, q) in enumerate(zip(cpu_p, gpu_p)):
+            for a, b, what in ((q, p, "param"), (opt.state[q]["exp_avg"], ref.state[p]["exp_avg"], "exp_avg"),
+                               (opt.state[q]["exp_avg_sq"], ref.state[p]["exp_avg_sq"], "exp_avg_sq")):
+                # moments: the same fma chain -> 1e-7 of scale; parameters: 2.5e-7 (<= 3 ulp at the tensor's scale) -- ATen's vectorised
+                # CPU sqrt is not correctly rounded (its own scalar path differs from it by an ulp), the kernel's IEEE sqrt / div are
+                assert rel(a, b) <= (2.5e-7 if what == "param" else 1e-7), (step, ADAM_SHAPES[i], what, rel(a, b))
+            assert float(opt.state[q]["step"]) == float(ref.state[p]["step"]) == step + 1
+    # the images installed by the step == a fresh pack of the updated weight, bit for bit; no pack launch is needed afterwards
+    for q in gpu_p:
+        if getattr(q, "_vq_kinds", None):
+            cache = q._vq_pack
+            assert "all" in cache and "fresh" not in cache              # the post-step hook consumed the mark and kept the images
+            fresh = nn.Parameter(q.detach().clone())
+            fresh._vq_kinds = set(q._vq_kinds)
+            for kind in q._vq_kinds:
+                want = nnf._pack_all(fresh, kind)
+                got = nnf._pack_all(q, kind)
+                if want is None:
+                    assert got is None
+                    continue
+                assert got is cache["all"][kind], "the conv kernels must read the image the optimiser wrote"
+                assert torch.equal(got, want), (tuple(q.shape), kind)
+    # state_dict layout == torch.optim.Adam's: loads both ways
+    plain = torch.optim.Adam(_params(dev(), False), lr=1e-3)
+    plain.load_state_dict(opt.state_dict())
+    opt2 = HipAdam(_params(dev(), False), lr=1e-3)
+    opt2.load_state_dict(plain.state_dict())
+    assert torch.equal(opt2.state[opt2.param_groups[0]["params"][0]]["exp_avg"], opt.state[gpu_p[0]]["exp_avg"])
+
+
+def test_convolution_after_a_hip_adam_step_sees_the_new_weights():
+    """the twin of tests/test_wcache.py::test_fused_adam_step_reaches_the_conv_kernels for optim.HipAdam"""
+    from vq_seg_amd import nnf
+    from vq_seg_amd.optim import HipAdam
+    torch.manual_seed(0)
+    for k, dtype in ((3, torch.bfloat16), (1, torch.bfloat16), (3, torch.float32)):
+        conv, bn = nn.Conv2d(32, 64, k, padding=k // 2, bias=False).to(dev()), nn.BatchNorm2d(64).to(dev())
+        x = torch.rand(2, 32, 16, 16, device=dev()).contiguous(memory_format=torch.channels_last).to(dtype).requires_grad_(True)
+        opt = HipAdam(list(conv.parameters()) + list(bn.parameters()), lr=0.05)
+        for _ in range(2):
+            y0 = nnf.conv_bn_act(x, conv, bn)
+            y0.float().square().mean().backward()
+            opt.step()
+            opt.zero_grad()
+        y1 = nnf.conv_bn_act(x, conv, bn)
+        fresh_c, bn2 = copy.deepcopy(conv), copy.deepcopy(bn)
+        fresh_c.weight._vq_pack = None
+        assert torch.equal(y1, nnf.conv_bn_act(x, fresh_c, bn2)), (k, dtype)
+        assert not torch.equal(y1, y0)
+
+
+def test_hip_adam_skips_parameters_without_a_gradient_and_refuses_other_adam_variants():
+    from vq_seg_amd.optim import HipAdam
+    a, b = nn.Parameter(torch.ones(8, device=dev())), nn.Parameter(torch.ones(8, device=dev()))
+    opt = HipAdam([a, b], lr=0.1)
+    a.grad = torch.full_like(a, 2.0)
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(b.detach().cpu(), torch.ones(8)) and b not in opt.state        # torch.optim.Adam's rule: no grad, no state
+    assert torch.allclose(a.detach().cpu(), torch.full((8,), 0.9), atol=1e-6)             # first step: lr * sign(g)
+    opt.param_groups[0]["amsgrad"] = True
+    with pytest.raises(NotImplementedError):
+        opt.step()
+
+
+# ------------------------------------------------------------------------------------------------ two-use weight gradient
+PAIR_CASES = [
+    # k, stride, pad, reflect, n_a, n_b, c1, c2, cout, h, w, precise
+    (3, 1, 1, False, 2, 2, 64, 0, 128, 8, 32, 0),           # nine-tap kernel
+    (3, 1, 1, True, 1, 3, 128, 64, 64, 12, 16, 0),          # ... concat, reflect, different image counts
+    (3, 1, 1, False, 2, 1, 32, 0, 32, 16, 48, 0),
+    (1, 1, 0, False, 2, 2, 128, 0, 256, 16, 16, 0),         # 1x1 kernel
+    (1, 2, 0, False, 1, 2, 256, 0, 512, 15, 9, 0),          # ... stride 2, ragged
+    (1, 1, 0, False, 3, 2, 64, 0, 256, 9, 7, 0),
+    (3, 2, 1, True, 2, 2, 128, 0, 128, 16, 16, 0),          # per-tap kernel (stride-2 3x3)
+    (3, 1, 1, False, 2, 3, 24, 16, 40, 9, 11, 0),           # ... odd channel counts, concat
+    (3, 1, 1, False, 1, 2, 32, 0, 64, 8, 8, 1),             # ... precise (fp32 activations)
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_wgrad_over_two_uses_in_one_launch(case):
+    from vq_seg_amd import _hip
+    k, stride, pad, reflect, na, nb, c1, c2, cout, h, w, precise = case
+    cin = c1 + c2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    L = _hip.lib()
+    dt = torch.float32 if precise else torch.bfloat16
+    seed = sum(case)
+    xs = [synth.uniform(seed + i, (n, h, w, cin), -1, 1).to(dt) for i, n in enumerate((na, nb))]
+    gys = [synth.uniform(seed + 7 + i, (n, ho, wo, cout), -1, 1).to(dt) for i, n in enumerate((na, nb))]
+    ref = 0
+    for x, gy in zip(xs, gys):
+        xp = x.double().permute(0, 3, 1, 2)
+        if pad:
+            xp = F.pad(xp, (pad,) * 4, mode="reflect" if reflect else "constant")
+        ref = ref + torch.nn.grad.conv2d_weight(xp, (cout, cin, k, k), gy.double().permute(0, 3, 1, 2), stride=stride)
+    d = dev()
+    xa = [x[..., :c1].contiguous().to(d) for x in xs]
+    xb = [x[..., c1:].contiguous().to(d) if c2 else None for x in xs]
+    gd = [g.to(d) for g in gys]
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(na + nb, h, w, cin, ho, wo, cout, k, k)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
+    gw = torch.full((cout, cin, k, k), float("nan"), dtype=torch.float32, device=d)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = L.vqseg_conv2d_wgrad2_f(ptr(gd[0]), ptr(xa[0]), ptr(xb[0]), na, ptr(gd[1]), ptr(xa[1]), ptr(xb[1]), nb, c1, h, w, cin, ho, wo, cout, k, k,
+                                 stride, pad, int(reflect), precise, cin, 0, 0, ws.data_ptr(), nbytes, gw.data_ptr(), st)
+    assert rc == 0, L.vqseg_last_error()
+    torch.cuda.synchronize()
+    tol = 2e-4 if precise else 2e-5
+    assert rel(gw, ref) < tol
+    # == the two single-use launches accumulated (different slab partition: rounding-level agreement)
+    gw2 = torch.zeros_like(gw)
+    for i, n in enumerate((na, nb)):
+        nb1 = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, k, k)
+        ws1 = torch.empty(nb1, dtype=torch.uint8, device=d)
+        rc = L.vqseg_conv2d_wgrad_f(ptr(gd[i]), ptr(xa[i]), ptr(xb[i]), c1, n, h, w, cin, ho, wo, cout, k, k, stride, pad, int(reflect), precise,
+                                    cin, 0, 1, ws1.data_ptr(), nb1, gw2.data_ptr(), st)
+        assert rc == 0, L.vqseg_last_error()
+    torch.cuda.synchronize()
+    assert rel(gw, gw2) < 2e-6
+    # a second source without its tensors is refused
+    assert L.vqseg_conv2d_wgrad2_f(ptr(gd[0]), ptr(xa[0]), ptr(xb[0]), na, None, None, None, nb, c1, h, w, cin, ho, wo, cout, k, k, stride, pad,
+                                   int(reflect), precise, cin, 0, 0, ws.data_ptr(), nbytes, gw.data_ptr(), st) != 0
+
+
+@pytest.mark.parametrize("mode", ["fast", "precise"])
+def test_two_use_weight_gradients_pair_up_in_backward_and_nothing_stays_queued(mode):
+    """nnf: with gradient sinks a layer used twice in one graph queues its first use and issues ONE launch at the second;
+    results agree with the unpaired path, the callback fires once, a use that never meets a partner is flushed."""
+    from vq_seg_amd import nnf, _hip
+    dt = torch.float32 if mode == "precise" else torch.bfloat16
+    torch.manual_seed(0)
+    convs = [nn.Conv2d(64, 64, 3, 1, 1, bias=False), nn.Conv2d(64, 128, 1, 1, 0, bias=False), nn.Conv2d(64, 64, 3, 2, 1, bias=False, padding_mode="reflect")]
+    xa = synth.uniform(1, (2, 64, 16, 16), -1, 1).to(dev()).contiguous(memory_format=torch.channels_last).to(dt)
+    xb = synth.uniform(2, (3, 64, 16, 16), -1, 1).to(dev()).contiguous(memory_format=torch.channels_last).to(dt)
+    for conv in convs:
+        conv = conv.to(dev())
+        bn = nn.BatchNorm2d(conv.out_channels).to(dev())
+        results = []
+        for pair in (1, 0):
+            c2, b2 = copy.deepcopy(conv), copy.deepcopy(bn)
+            fired = []
+            for p_ in list(c2.parameters()) + list(b2.parameters()):
+                p_.grad = torch.zeros_like(p_)
+                p_._vq_grad_sink = lambda q: fired.append(id(q))
+            _hip.PY_OPTS["py_wgrad_pair"] = pair
+            try:
+                (nnf.conv_bn_act(xa, c2, b2).float().square().sum() + nnf.conv_bn_act(xb, c2, b2).float().sum()).backward()
+                assert not nnf._PENDING_WGRADS and getattr(c2.weight, "_vq_wgrad_pending", None) is None
+            finally:
+                _hip.PY_OPTS.pop("py_wgrad_pair", None)
+            assert sorted(fired) == sorted(id(q) for q in list(c2.parameters()) + list(b2.parameters()))
+            results.append(c2.weight.grad.clone())
+        assert rel(results[0], results[1]) < (1e-5 if mode == "precise" else 1e-5)
+        # a queued use whose partner never comes: flushed on demand, same gradient as the direct launch
+        c3, b3 = copy.deepcopy(conv), copy.deepcopy(bn)
+        for p_ in list(c3.parameters()) + list(b3.parameters()):
+            p_.grad = torch.zeros_like(p_)
+            p_._vq_grad_sink = None
+        ya, yb = nnf.conv_bn_act(xa, c3, b3), nnf.conv_bn_act(xb, c3, b3)          # two uses counted, only one reaches the loss
+        ya.float().square().sum().backward()
+        assert c3.weight in nnf._PENDING_WGRADS and float(c3.weight.grad.abs().sum()) == 0.0
+        assert nnf.flush_pending_wgrads() == 1 and not nnf._PENDING_WGRADS
+        c4, b4 = copy.deepcopy(conv), copy.deepcopy(bn)
+        nnf.conv_bn_act(xa, c4, b4).float().square().sum().backward()
+        assert rel(c3.weight.grad, c4.weight.grad) < 1e-6
+        del yb

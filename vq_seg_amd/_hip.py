@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 from typing import Optional, Tuple
 
 import torch
@@ -58,6 +58,8 @@ SYMBOLS = {
                               [c_int] * 13 + [c_void_p]),
     "vqseg_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int] * 9),
     "vqseg_conv2d_wgrad_f": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 17 + [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "vqseg_conv2d_wgrad2_f": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int] + [c_int] * 16 +
+                              [c_void_p, c_size_t, c_void_p, c_void_p]),
     "vqseg_bn_sync_ints": (c_int, [c_int]),
     "vqseg_bn_finalize_f": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -100,6 +102,8 @@ SYMBOLS = {
     "vqseg_s3_merge_f": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "vqseg_s3_maxpool3x3s2_f": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vqseg_s3_bilinear_f": (c_int, [c_void_p] + [c_int] * 7 + [c_void_p, c_void_p]),
+    "vqseg_adam_work_items": (c_int64, [c_int64, c_int, c_int, c_int]),
+    "vqseg_adam_step_f32": (c_int, [c_void_p, c_void_p, c_int, c_double, c_double, c_double, c_double, c_int64, c_void_p]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

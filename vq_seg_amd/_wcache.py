@@ -5,7 +5,8 @@ counter alone is NOT enough: `torch.optim.Adam(fused=True).step()` rewrites the 
 torch 2.10: `_version` stays put across a fused step), and neither do writes through `.data` (the reference's own idiom
 `embedding.weight.data.copy_(...)`, vq_img.py:185) nor `dist.broadcast(p.data)`.  So:
   * every optimiser step drops the images of that optimiser's parameters (a global `register_optimizer_step_post_hook`,
-    which also fires under `GradScaler.step(optimizer)` -- the reference trainers' call);
+    which also fires under `GradScaler.step(optimizer)` -- the reference trainers' call) -- except the images `optim.HipAdam`
+    has just rewritten from the updated values inside its own step (it marks that cache "fresh" for exactly one hook call);
   * code that writes parameter storage behind autograd's back calls `invalidate(...)` (this package does so after its own
     broadcast / k-means / EMA writes); `load_state_dict` and ordinary in-place ops bump the version counter and need nothing.
 """
@@ -38,7 +39,10 @@ def invalidate(*objs) -> None:
 def _after_optimizer_step(optimizer, args, kwargs):
     for group in optimizer.param_groups:
         for p in group["params"]:
-            if getattr(p, "_vq_pack", None) is not None:
+            cache = getattr(p, "_vq_pack", None)
+            if cache is not None:
+                if cache.pop("fresh", False):               # optim.HipAdam rewrote the images from the NEW values inside its step
+                    continue
                 p._vq_pack = None
 
 

@@ -41,6 +41,13 @@ struct WgradArgs {
     float* partial;             // [slabs][Cout][KH*KW][Cin] fp32
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, reflect;
     int per_tap_only;           // 1: x is an im2col patch matrix whose padded columns are dropped by the reduction
+    // Second source (r4, "two-use" weight gradients): images [Na, N) of the virtual batch come from gy_b / x_b / x2_b (their image
+    // index n - Na), images [0, Na) from gy / x / x2.  A weight used by two forwards of a training step (the labelled and the
+    // unlabelled batch) gets ONE launch over both uses: twice the K extent per workgroup, half the slab sums.  Na == N: one source.
+    const void* gy_b = nullptr;
+    const void* x_b = nullptr;
+    const void* x2_b = nullptr;
+    int Na = 0;
 };
 
 hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st);

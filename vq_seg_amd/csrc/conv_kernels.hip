@@ -1682,6 +1682,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     const int co0 = blockIdx.y * (TM * 32);
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
     const long M = (long)p.N * p.Ho * p.Wo;
+    const long Ma = (long)p.Na * p.Ho * p.Wo;               // rows of the first source (== M without a second one)
     long mz = (M + gridDim.z - 1) / gridDim.z;
     mz = (mz + BKM - 1) / BKM * BKM;
     const long m_begin = (long)blockIdx.z * mz;
@@ -1735,7 +1736,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
                 const int row = idx / G_CPR, ch = idx % G_CPR;
                 const long m = mb + row;
                 const int co = co0 + ch * EPC;
-                if (m < m_end && co < p.Cout) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.gy) + (m * p.Cout + co) * (PRECISE ? 4 : 2));
+                if (m < m_end && co < p.Cout) {
+                    const bool sb = m >= Ma;                         // second source of a two-use launch
+                    v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(sb ? p.gy_b : p.gy) + ((sb ? m - Ma : m) * p.Cout + co) * (PRECISE ? 4 : 2));
+                }
             }
             g_reg[i] = v;
         }
@@ -1748,11 +1752,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
                 const long m = mb + row;
                 const int cg = ci0 + ch * EPC;                       // global input channel of this chunk
                 const bool second = cg >= p.C1;
-                const char* xsrc = reinterpret_cast<const char*>(second ? p.x2 : p.x);
+                const bool sb = pn[i] >= p.Na;
+                const char* xsrc = reinterpret_cast<const char*>(second ? (sb ? p.x2_b : p.x2) : (sb ? p.x_b : p.x));
                 const int csrc = second ? (p.Cin - p.C1) : p.C1;
                 const int cbase = second ? (cg - p.C1) : cg;
                 if (m < m_end && cg < p.Cin) {
-                    const int n = pn[i], oh = poh[i], ow = pow_[i];    // tracked incrementally (advance_rows)
+                    const int n = sb ? pn[i] - p.Na : pn[i], oh = poh[i], ow = pow_[i];    // tracked incrementally (advance_rows)
                     int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
                     if (p.reflect) {
                         ih = reflect_idx(ih, p.H);
@@ -1968,10 +1973,12 @@ __global__ __launch_bounds__((Wg3<COT, CIT>::NW * 64)) void conv_wgrad3x3_kernel
     const int ns = b_end > b_begin ? b_end - b_begin : 0;
 
     const bool second = ci0 >= p.C1;
-    const char* xsrc = reinterpret_cast<const char*>(second ? p.x2 : p.x);
+    const char* xsrc_a = reinterpret_cast<const char*>(second ? p.x2 : p.x);
+    const char* xsrc_b = reinterpret_cast<const char*>(second ? p.x2_b : p.x_b);     // second source (two-use launch), images >= Na
     const int csrc = second ? (p.Cin - p.C1) : p.C1;
     const int cbase = second ? (ci0 - p.C1) : ci0;
-    const char* gsrc = reinterpret_cast<const char*>(p.gy);
+    const char* gsrc_a = reinterpret_cast<const char*>(p.gy);
+    const char* gsrc_b = reinterpret_cast<const char*>(p.gy_b);
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
     // ---- stage-invariant lane roles of the DMA instructions
@@ -2021,7 +2028,11 @@ __global__ __launch_bounds__((Wg3<COT, CIT>::NW * 64)) void conv_wgrad3x3_kernel
         char* Gs = smem + buf * C::STAGE;
         char* Ps = Gs + C::G_BYTES;
         const int oh0 = iby * 4, ow0 = ibx * 16;
-        const long gbase = (((long)in_ * p.Ho + oh0) * p.Wo + ow0) * p.Cout;
+        const bool sb = in_ >= p.Na;                        // wave-uniform: the block's image belongs to the second source
+        const int img = sb ? in_ - p.Na : in_;
+        const char* gsrc = sb ? gsrc_b : gsrc_a;
+        const char* xsrc = sb ? xsrc_b : xsrc_a;
+        const long gbase = (((long)img * p.Ho + oh0) * p.Wo + ow0) * p.Cout;
 #pragma unroll
         for (int i = 0; i < C::G_PER; ++i) glds16(gsrc + (gbase + g_rel[i]) * 2, Gs + (wave + C::NW * i) * 1024);
 #pragma unroll
@@ -2032,7 +2043,7 @@ __global__ __launch_bounds__((Wg3<COT, CIT>::NW * 64)) void conv_wgrad3x3_kernel
                 iw = reflect_idx(iw, p.W);
             }
             const bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            const long off = (((long)in_ * p.H + ih) * p.W + iw) * csrc + p_ch[i];
+            const long off = (((long)img * p.H + ih) * p.W + iw) * csrc + p_ch[i];
             glds16(ok ? xsrc + off * 2 : zero, Ps + (wave + C::NW * i) * 1024);
         }
         if (++ibx == bw) {
@@ -2174,8 +2185,11 @@ __global__ __launch_bounds__(512) void conv_wgrad1x1_kernel(const WgradArgs p, i
     long s_end = s_begin + stages_per_slab;
     if (s_end > n_stage_all) s_end = n_stage_all;
     const int ns = s_end > s_begin ? (int)(s_end - s_begin) : 0;
-    const char* gsrc = reinterpret_cast<const char*>(p.gy);
-    const char* xsrc = reinterpret_cast<const char*>(p.x);
+    const char* gsrc_a = reinterpret_cast<const char*>(p.gy);
+    const char* gsrc_b = reinterpret_cast<const char*>(p.gy_b);       // second source (two-use launch): rows >= Ma / images >= Na
+    const char* xsrc_a = reinterpret_cast<const char*>(p.x);
+    const char* xsrc_b = reinterpret_cast<const char*>(p.x_b);
+    const long Ma = (long)p.Na * p.Ho * p.Wo;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
     // ---- lane roles of the DMA instructions: instruction j covers tile rows j * (1024 / RB) ...
@@ -2218,14 +2232,16 @@ __global__ __launch_bounds__(512) void conv_wgrad1x1_kernel(const WgradArgs p, i
 #pragma unroll
         for (int i = 0; i < C::G_PER; ++i) {
             const long m = issue_m0 + g_row[i];
-            glds16(m < M ? gsrc + (m * p.Cout + g_col[i]) * 2 : zero, Gs + (wave + C::NW * i) * 1024);
+            const bool sb = m >= Ma;
+            glds16(m < M ? (sb ? gsrc_b : gsrc_a) + ((sb ? m - Ma : m) * p.Cout + g_col[i]) * 2 : zero, Gs + (wave + C::NW * i) * 1024);
         }
 #pragma unroll
         for (int i = 0; i < C::A_PER; ++i) {
             const long m = issue_m0 + a_row[i];
             const bool ok = a_row[i] < 64 && m < M;
-            const long pix = ((long)a_n[i] * p.H + a_oh[i] * p.stride) * p.W + a_ow[i] * p.stride;
-            glds16(ok ? xsrc + (pix * p.Cin + a_col[i]) * 2 : zero, As + (wave + C::NW * i) * 1024);
+            const bool sb = a_n[i] >= p.Na;
+            const long pix = ((long)(sb ? a_n[i] - p.Na : a_n[i]) * p.H + a_oh[i] * p.stride) * p.W + a_ow[i] * p.stride;
+            glds16(ok ? (sb ? xsrc_b : xsrc_a) + (pix * p.Cin + a_col[i]) * 2 : zero, As + (wave + C::NW * i) * 1024);
             a_ow[i] += 64;                                  // this lane's row of the next stage
             while (a_ow[i] >= p.Wo) {
                 a_ow[i] -= p.Wo;

@@ -133,17 +133,21 @@ size_t vqseg_conv2d_wgrad_workspace_bytes(int n, int h, int w, int cin, int ho, 
     return (size_t)vqseg::wgrad_slabs_max(a) * cout * kh * kw * cin * sizeof(float);
 }
 
-int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, int n, int h, int w, int cin, int ho, int wo,
-                         int cout, int kh, int kw, int stride, int pad, int reflect, int precise, int cin_out, int im2col,
-                         int accumulate, void* workspace, size_t workspace_bytes, float* gw, void* stream) {
+int vqseg_conv2d_wgrad2_f(const void* gy, const void* x, const void* x2, int n, const void* gy_b, const void* x_b, const void* x2_b,
+                          int n_b, int c1, int h, int w, int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad,
+                          int reflect, int precise, int cin_out, int im2col, int accumulate, void* workspace, size_t workspace_bytes,
+                          float* gw, void* stream) {
     if (!gy || !x || !workspace || !gw) return bad("conv2d_wgrad: null pointer");
+    if (n <= 0 || n_b < 0) return bad("conv2d_wgrad: bad image count");
+    if (n_b > 0 && (!gy_b || !x_b)) return bad("conv2d_wgrad: second source missing");
     const int epc = precise ? 4 : 8;
     if (cin % epc || cout % epc) return bad("conv2d_wgrad: Cin and Cout must be multiples of 4 (f32) / 8 (bf16)");
-    if (c1 <= 0 || c1 > cin || (c1 < cin && (!x2 || c1 % epc || (cin - c1) % epc))) return bad("conv2d_wgrad: bad channel split");
+    if (c1 <= 0 || c1 > cin || (c1 < cin && (!x2 || (n_b > 0 && !x2_b) || c1 % epc || (cin - c1) % epc))) return bad("conv2d_wgrad: bad channel split");
     vqseg::WgradArgs a;
     const int kkh = im2col ? 1 : kh, kkw = im2col ? 1 : kw;     // a patch matrix is convolved 1x1
     a.gy = gy; a.x = x; a.x2 = x2; a.C1 = c1; a.partial = static_cast<float*>(workspace);
-    a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Ho = ho; a.Wo = wo; a.Cout = cout; a.KH = kkh; a.KW = kkw;
+    a.gy_b = gy_b; a.x_b = x_b; a.x2_b = x2_b; a.Na = n;
+    a.N = n + n_b; a.H = h; a.W = w; a.Cin = cin; a.Ho = ho; a.Wo = wo; a.Cout = cout; a.KH = kkh; a.KW = kkw;
     a.stride = stride; a.pad = pad; a.reflect = reflect; a.per_tap_only = im2col;
     const int slabs = vqseg::wgrad_slabs(a, precise);
     if (workspace_bytes < (size_t)slabs * cout * kkh * kkw * cin * sizeof(float)) return vqseg_set_error(VQSEG_ENOSPC, "conv2d_wgrad: workspace too small");
@@ -156,6 +160,13 @@ int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, 
     else if (im2col) e = vqseg::launch_wgrad_reduce(a.partial, slabs, cout, cin, cin_out, kh, kw, 1, accumulate, gw, st);   // kh,kw = ORIGINAL taps here
     else e = vqseg::launch_wgrad_reduce(a.partial, slabs, cout, cin, cin_out, kh, kw, 0, accumulate, gw, st);
     return e == hipSuccess ? 0 : hipfail(e, "wgrad_reduce_kernel");
+}
+
+int vqseg_conv2d_wgrad_f(const void* gy, const void* x, const void* x2, int c1, int n, int h, int w, int cin, int ho, int wo,
+                         int cout, int kh, int kw, int stride, int pad, int reflect, int precise, int cin_out, int im2col,
+                         int accumulate, void* workspace, size_t workspace_bytes, float* gw, void* stream) {
+    return vqseg_conv2d_wgrad2_f(gy, x, x2, n, nullptr, nullptr, nullptr, 0, c1, h, w, cin, ho, wo, cout, kh, kw, stride, pad, reflect,
+                                 precise, cin_out, im2col, accumulate, workspace, workspace_bytes, gw, stream);
 }
 
 int vqseg_bn_sync_ints(int c) { return c > 0 ? (c + 63) / 64 : 0; }

@@ -204,6 +204,63 @@ def py_opt(key: str, default: int) -> int:
     return _hip.PY_OPTS.get(key, default)
 
 
+# Parameters with a queued first use of a two-use weight gradient (see _ConvBNAct.backward); flush_pending_wgrads() launches
+# whatever is still queued (a forward whose output did not reach the loss) -- trainers call it after backward().
+_PENDING_WGRADS: set = set()
+
+
+def _wgrad_launch(geom, a, b, gw, accumulate, stream):
+    """vqseg_conv2d_wgrad2_f over use `a` = (g_y, x, x2, n) [and use `b`] into gw; `stream`: the stream a queued use belongs to."""
+    h, w, c1, cin, ho, wo, cout, kh, kw, stride, pad, reflect, precise, patches_of = geom
+    g_y, xr, x2r, n = a
+    gb, xb, x2b, nb = b if b is not None else (None, None, None, 0)
+    L = lib()
+    dev = g_y.device
+    bf = 0 if precise else 1
+    m = n * ho * wo
+    with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+        if patches_of:
+            okh, okw, ocin = patches_of[0], patches_of[1], patches_of[2]
+            wkh = wkw = 1
+            im2col, cin_out, st_, pd_, rf_ = 1, ocin, 1, 0, 0
+            gnum = cout * ocin * okh * okw
+        else:
+            okh, okw, wkh, wkw = kh, kw, kh, kw
+            im2col, cin_out, st_, pd_, rf_ = 0, cin, stride, pad, reflect
+            gnum = cout * cin * kh * kw
+        nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n + nb, h, w, cin, ho, wo, cout, wkh, wkw)
+        wsw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with _hip.on_device(dev):
+            _check(L.vqseg_conv2d_wgrad2_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), _T(xr, "conv input", bf=bf, numel=n * h * w * c1),
+                                           _T(x2r, "conv input 2", bf=bf, numel=n * h * w * (cin - c1)), n,
+                                           _T(gb, "conv output gradient (second use)", bf=bf, numel=nb * ho * wo * cout),
+                                           _T(xb, "conv input (second use)", bf=bf, numel=nb * h * w * c1),
+                                           _T(x2b, "conv input 2 (second use)", bf=bf, numel=nb * h * w * (cin - c1)), nb,
+                                           c1, h, w, cin, ho, wo, cout, okh, okw, st_, pd_, rf_, int(precise), cin_out, im2col, int(accumulate),
+                                           _T(wsw, "wgrad workspace", dtype=torch.uint8, numel=nbytes), nbytes,
+                                           _f32(gw, "weight gradient", gnum), _stream()), "vqseg_conv2d_wgrad2_f")
+
+
+def flush_pending_wgrads() -> int:
+    """Launch every queued first use that never met its second (returns how many).  After this no Parameter holds activations."""
+    n = 0
+    for p in list(_PENDING_WGRADS):
+        pend = getattr(p, "_vq_wgrad_pending", None)
+        p._vq_wgrad_pending = None
+        if pend is not None:
+            _wgrad_launch(pend[0], pend[1], None, p.grad, True, pend[2])
+            n += 1
+    _PENDING_WGRADS.clear()
+    return n
+
+
+def drop_pending_wgrads() -> None:
+    """forget queued uses without launching them (start of a step: whatever an aborted backward left behind)"""
+    for p in list(_PENDING_WGRADS):
+        p._vq_wgrad_pending = None
+    _PENDING_WGRADS.clear()
+
+
 class GradLink:
     """Carries the gradient of a block's identity branch from the backward of its LAST conv (`link_out`: where the
     residual add happened) to the backward of its FIRST conv (`link_in`), whose data-gradient kernel adds it in its
@@ -516,26 +573,24 @@ class _ConvBNAct(torch.autograd.Function):
             for t_ in (g_y, xr, x2r):
                 if t_ is not None:
                     t_.record_stream(wside)                                     # allocator: not reusable before the side stream is done
-        with (torch.cuda.stream(wside) if wside is not None else contextlib.nullcontext()):
-            if patches_of:
-                okh, okw, ocin = patches_of[0], patches_of[1], patches_of[2]
-                nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, 1, 1)
-                wsw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                with _hip.on_device(dev):
-                    _check(L.vqseg_conv2d_wgrad_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), _T(xr, "stem patches", bf=bf, numel=n * h * w * cin),
-                                                  None, cin, n, h, w, cin, ho, wo, cout, okh, okw, 1, 0, 0, int(precise), ocin, 1, int(sink_w),
-                                                  _T(wsw, "wgrad workspace", dtype=torch.uint8, numel=nbytes), nbytes,
-                                                  _f32(gw, "weight gradient", cout * ocin * okh * okw), _stream()),
-                           "vqseg_conv2d_wgrad_f")
-            else:
-                nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, kh, kw)
-                wsw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                with _hip.on_device(dev):
-                    _check(L.vqseg_conv2d_wgrad_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), _T(xr, "conv input", bf=bf, numel=n * h * w * c1),
-                                                  _T(x2r, "conv input 2", bf=bf, numel=n * h * w * (cin - c1)), c1, n, h, w, cin, ho, wo, cout, kh, kw,
-                                                  stride, pad, int(reflect), int(precise), cin, 0, int(sink_w),
-                                                  _T(wsw, "wgrad workspace", dtype=torch.uint8, numel=nbytes), nbytes,
-                                                  _f32(gw, "weight gradient", cout * cin * kh * kw), _stream()), "vqseg_conv2d_wgrad_f")
+        geom = (h, w, c1, cin, ho, wo, cout, kh, kw, stride, pad, int(reflect), int(precise), patches_of)
+        use = (g_y, xr, x2r, n)
+        # ---- two-use weights (r4): a weight used by two training forwards of the step (the labelled and the unlabelled batch of a
+        # CPS iteration) gets ONE launch over both uses -- the first use is queued on the Parameter, the second runs
+        # vqseg_conv2d_wgrad2_f over the virtual batch: twice the contraction length per workgroup, half the slab sums
+        pend = getattr(p_w, "_vq_wgrad_pending", None) if sink_w else None
+        if pend is not None:
+            p_w._vq_wgrad_pending = None
+            _PENDING_WGRADS.discard(p_w)
+        if pend is not None and (pend[0] != geom or pend[2] != torch.cuda.current_stream(dev) or wside is not None):
+            _wgrad_launch(pend[0], pend[1], None, p_w.grad, True, pend[2])      # not pairable after all: the queued use on its own
+            pend = None
+        if sink_w and pend is None and wside is None and getattr(p_w, "_vq_uses", 1) >= 2 and py_opt("py_wgrad_pair", 1):
+            p_w._vq_wgrad_pending = (geom, use, torch.cuda.current_stream(dev))
+            _PENDING_WGRADS.add(p_w)
+        else:
+            with (torch.cuda.stream(wside) if wside is not None else contextlib.nullcontext()):
+                _wgrad_launch(geom, pend[1] if pend is not None else use, use if pend is not None else None, gw, sink_w, None)
         if sink_w:
             _sink_done(p_w)
         # ---- data gradient(s): the same implicit-GEMM kernel on g_y with tap-flipped, transposed weights

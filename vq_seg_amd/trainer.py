@@ -25,6 +25,7 @@ from .measurement import confusion_matrix_device, miou_device
 from . import nnf
 from .models import init_weight
 from .models.networks import make_model
+from .optim import HipAdam
 from .utils.ckpoints import load_training_state, restore_initted, save_ckpoints
 from .utils.lr_schedulers import CosineAnnealingLR
 
@@ -266,7 +267,10 @@ class CPSTrainer:
         for b, s_, w_ in zip(self.buckets, self._streams, self._wgrad_streams):
             b.producer_streams.append(w_)
         self._pending_sides = set()
-        self.opts = [torch.optim.Adam(m.parameters(), lr=cfg.learning_rate, betas=(0.9, 0.999), fused=self.device.type == "cuda")
+        # the reference's optimiser (train_vqreptunet1x1v2.py:106-107) on the HIP step kernel: Adam + the convolution kernels' weight
+        # images in one launch per network (optim.HipAdam IS a torch.optim.Adam: same state / state_dict layout)
+        self.opts = [HipAdam(m.parameters(), lr=cfg.learning_rate, betas=(0.9, 0.999)) if self.device.type == "cuda" and nnf.py_opt("py_hip_adam", 1)
+                     else torch.optim.Adam(m.parameters(), lr=cfg.learning_rate, betas=(0.9, 0.999), fused=self.device.type == "cuda")
                      for m in self.models]
         self.sched = CosineAnnealingLR(cfg.learning_rate, cfg.min_lr, cfg.total_iters, cfg.warmup_steps)
         self.ce = nn.CrossEntropyLoss(ignore_index=255)
@@ -368,6 +372,7 @@ class CPSTrainer:
         m1, m2 = self.models
         for b in self.buckets:
             b.zero()
+        nnf.drop_pending_wgrads()
         if l_input.is_cuda:
             # one layout conversion per batch instead of one per forward, and one stem patch matrix per batch for the six
             # forwards of the step (nnf.stem_share_*): the two networks and the two passes over the unlabelled batch see
@@ -428,16 +433,31 @@ class CPSTrainer:
             loss.backward()
         finally:
             self._wgrad_sides(False)
-        if self._two_streams:                                           # the sinks wrote p.grad on the per-model (and side) streams
-            for s_ in self._streams + self._wgrad_streams:
-                torch.cuda.current_stream().wait_stream(s_)
-        for b in self.buckets:
-            b.finish()
-        for o in self.opts:
-            o.step()
+        nnf.flush_pending_wgrads()                                      # two-use weight gradients whose second use never came (none, normally)
+        if self._two_streams and nnf.py_opt("py_opt_streams", 1):
+            # each network's gradient reduction + optimiser step on ITS stream (the sinks wrote p.grad there): the two Adam launches
+            # overlap each other and the metric kernels below; the caller's stream joins both before the step returns
+            main = torch.cuda.current_stream()
+            for i, (b, o, s_) in enumerate(zip(self.buckets, self.opts, self._streams)):
+                s_.wait_stream(main)                                    # backward's leaf streams are joined into `main` by autograd
+                if self._wgrad_streams:
+                    s_.wait_stream(self._wgrad_streams[i])
+                with torch.cuda.stream(s_):
+                    b.finish()
+                    o.step()
+                self._pending_sides.add(s_)
+        else:
+            if self._two_streams:                                       # the sinks wrote p.grad on the per-model (and side) streams
+                for s_ in self._streams + self._wgrad_streams:
+                    torch.cuda.current_stream().wait_stream(s_)
+            for b in self.buckets:
+                b.finish()
+            for o in self.opts:
+                o.step()
         self.iter += 1
         with torch.no_grad():
             miou, _ = miou_device(confusion_matrix_device(ps1, l_target, cfg.num_classes))
+        self._join()
         return {"loss": loss.detach(), "sup_loss_1": sup_1.detach(), "sup_loss_2": sup_2.detach(), "cps_loss": cps.detach(),
                 "commitment_loss": commitment.detach().sum(), "prototype_loss": prototype.detach(), "miou": miou,
                 "lr": torch.tensor(lr)}
@@ -501,6 +521,7 @@ class CPSTrainer:
         pred = pred.float()
         loss = self._ce_dice(pred, l_target) + closs.sum() + 0.01 * ploss.float()
         loss.backward()
+        nnf.flush_pending_wgrads()
         if self._two_streams:
             torch.cuda.current_stream().wait_stream(self._streams[0])
         self.buckets[0].finish()
