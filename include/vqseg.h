@@ -300,6 +300,14 @@ int vqseg_head1x1_forward_f(int bf16, const void* x, const float* w, int64_t m_r
 size_t vqseg_head1x1_backward_workspace_floats(int64_t m_rows, int cin, int cout);
 int vqseg_head1x1_backward_f(int bf16, const void* x, const float* w, const float* g, int64_t m_rows, int cin,
                              int cout, void* gx, float* gw, float* workspace, void* stream);
+/* Fan-in forms (r4): the tensor whose gradient these produce has a second consumer whose gradient `gx_add` (same shape and type;
+ * NULL: none) is added on the way out -- rounded as autograd's own add of the two tensors would round (each to the activation
+ * type first).  head: the decoder output feeds the head AND the prototype loss (net.py:1193-1203); max-pool: the stem output feeds
+ * the pool AND the last decoder block (resnet.py:164-171, decoder.py:35-37). */
+int vqseg_head1x1_backward_add_f(int bf16, const void* x, const float* w, const float* g, int64_t m_rows, int cin,
+                                 int cout, void* gx, float* gw, float* workspace, const void* gx_add, void* stream);
+int vqseg_maxpool3x3s2_backward_add_f(int bf16, const void* g, const unsigned char* idx, const void* gx_add, int n, int h, int w,
+                                      int c, void* gx, void* stream);
 
 /* Stem support: patch matrix of the 7x7/2 convolution (resnet.py:122-125; zero or reflect padding),
  * columns (kh, kw, ci) padded with zeros to kp; gradient fold of reflect padding 1; f32 <-> bf16 cast. */
@@ -334,8 +342,11 @@ int vqseg_conv_pack_weights_s3_f32(const float* w, int cout, int cin, int c1, in
 int vqseg_conv_pack_all_f32(const float* w, int cout, int cin, int k, int c1, void* fwd, void* tr, void* s3, void* stream);
 size_t vqseg_conv_packed_s2_elems(int cout, int cin, int k);
 int vqseg_conv_pack_weights_s2_f32(const float* w, int cout, int cin, int k, void* hi, void* lo, void* stream);
+/* `accumulate` (k == 1 only, r4): gx already holds the gradient the tensor received from its OTHER consumer (an encoder feature feeds
+ * the next stage AND the decoder / VQ layer); the data gradient is added to it in place at the pixels it touches -- no memset and no
+ * separate add pass (bit-identical to adding the two tensors). */
 int vqseg_conv2d_dgrad_s2_f(const void* gy, const void* w_hi, const void* w_lo, void* gx, int n, int ho, int wo, int cout, int cin,
-                            int k, int oh, int ow, int precise, void* stream);
+                            int k, int oh, int ow, int precise, int accumulate, void* stream);
 int vqseg_s3_split_f(const float* x, int64_t rows, int channels, void* y, void* stream);
 int vqseg_s3_merge_f(const void* x, int64_t rows, int channels, float* y, void* stream);
 int vqseg_s3_maxpool3x3s2_f(const void* x, int n, int h, int w, int c, void* y, void* stream);

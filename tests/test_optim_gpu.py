@@ -237,3 +237,99 @@ def test_two_use_weight_gradients_pair_up_in_backward_and_nothing_stays_queued(m
         nnf.conv_bn_act(xa, c4, b4).float().square().sum().backward()
         assert rel(c3.weight.grad, c4.weight.grad) < 1e-6
         del yb
+
+
+# ------------------------------------------------------------------------------------------------ fan-in fusion
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_fanin_kernels_are_bit_identical_to_a_separate_add(dtype):
+    """The three kernels that absorb a second consumer's gradient (stride-2 1x1 data gradient in place, max-pool backward, head
+    backward) against the same kernels followed by autograd's add of the two tensors."""
+    from vq_seg_amd import _hip, nnf
+    L = _hip.lib()
+    d = dev()
+    st = torch.cuda.current_stream().cuda_stream
+    bf = int(dtype == torch.bfloat16)
+    # -- stride-2 1x1 projection: gx (n, h, w, cin) += data gradient at the even pixels
+    n, h, w, cin, cout = 2, 15, 9, 64, 128
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    wt = nn.Parameter(synth.uniform(5, (cout, cin, 1, 1), -0.3, 0.3).to(d))
+    s_hi, s_lo = nnf._s2_weights(wt, dtype == torch.float32)
+    gy = synth.uniform(6, (n, ho, wo, cout), -1, 1).to(d).to(dtype)
+    other = synth.uniform(7, (n, h, w, cin), -1, 1).to(d).to(dtype)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    plain = torch.empty((n, h, w, cin), dtype=dtype, device=d)
+    assert L.vqseg_conv2d_dgrad_s2_f(ptr(gy), ptr(s_hi), ptr(s_lo), ptr(plain), n, ho, wo, cout, cin, 1, h, w, 1 - bf, 0, st) == 0, L.vqseg_last_error()
+    acc = other.clone()
+    assert L.vqseg_conv2d_dgrad_s2_f(ptr(gy), ptr(s_hi), ptr(s_lo), ptr(acc), n, ho, wo, cout, cin, 1, h, w, 1 - bf, 1, st) == 0, L.vqseg_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(acc, plain + other)
+    assert L.vqseg_conv2d_dgrad_s2_f(ptr(gy), ptr(s_hi), ptr(s_lo), ptr(acc), n, ho, wo, cout, cin, 3, h + 2, w + 2, 1 - bf, 1, st) != 0     # k = 3: refused
+    # -- max-pool backward with an addend
+    x = synth.uniform(8, (2, 64, 16, 20), -1, 1).to(d).contiguous(memory_format=torch.channels_last).to(dtype).requires_grad_(True)
+    y = nnf.max_pool_3x3_s2(x)
+    g = synth.uniform(9, tuple(y.shape), -1, 1).to(d).contiguous(memory_format=torch.channels_last).to(dtype)
+    (gx_plain,) = torch.autograd.grad(y, x, g, retain_graph=True)
+    add = synth.uniform(10, (2, 16, 20, 64), -1, 1).to(d).to(dtype)
+    prev = nnf.set_fanin_fusion(True)
+    try:
+        x2 = x.detach().clone().requires_grad_(True)
+        nnf.fanin_tag(x2)
+        y2 = nnf.max_pool_3x3_s2(x2)
+        assert nnf._fanin_deposit(x2._vq_fanin, add)
+        (gx_add,) = torch.autograd.grad(y2, x2, g)
+        nnf.check_fanin_consumed()
+    finally:
+        nnf.set_fanin_fusion(prev)
+    assert torch.equal(gx_add, gx_plain + add.permute(0, 3, 1, 2))
+    # -- head backward with an addend (the prototype loss's gradient of the decoder output)
+    xh = synth.uniform(11, (2, 32, 8, 8), -1, 1).to(d).contiguous(memory_format=torch.channels_last).to(dtype).requires_grad_(True)
+    wh = nn.Parameter(synth.uniform(12, (3, 32, 1, 1), -0.5, 0.5).to(d))
+    gl = synth.uniform(13, (2, 3, 8, 8), -1, 1).to(d)
+    (g_plain,) = torch.autograd.grad(nnf.head_conv1x1(xh, wh), xh, gl)
+    addh = synth.uniform(14, (2, 8, 8, 32), -1, 1).to(d).to(dtype)
+    prev = nnf.set_fanin_fusion(True)
+    try:
+        xh2 = xh.detach().clone().requires_grad_(True)
+        nnf.fanin_tag(xh2)
+        out = nnf.head_conv1x1(xh2, wh)
+        assert nnf._fanin_deposit(xh2._vq_fanin, addh)
+        (g_add,) = torch.autograd.grad(out, xh2, gl)
+        nnf.check_fanin_consumed()
+        # a deposit nobody absorbs is reported, not lost silently
+        xh3 = xh.detach().clone().requires_grad_(True)
+        nnf.fanin_tag(xh3)
+        assert nnf._fanin_deposit(xh3._vq_fanin, addh)
+        with pytest.raises(RuntimeError, match="never absorbed"):
+            nnf.check_fanin_consumed()
+    finally:
+        nnf.set_fanin_fusion(prev)
+    assert torch.equal(g_add, g_plain + addh.permute(0, 3, 1, 2))
+
+
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_trainer_step_with_fanin_fusion_matches_the_unfused_step(amp):
+    """CPSTrainer with the five fan-in adds of a backward pass inside the consumers' kernels vs autograd's separate adds: the adds
+    at the pool / head are bit-identical, the encoder features' three-way sums associate differently ((a + b) + c vs a + (b + c)):
+    rounding-level agreement of the step's terms and of the parameters after two steps."""
+    from tests import cps_loop
+    from vq_seg_amd import _hip
+    from vq_seg_amd.trainer import CPSConfig, CPSTrainer
+    outs = []
+    for fan in (1, 0):
+        _hip.PY_OPTS["py_fanin"] = fan
+        try:
+            cfg = CPSConfig(model=cps_loop.model_cfg(1, (0, 0, 32, 32, 32)), recipe="v1", total_iters=10, amp_dtype=amp, seed=3)
+            tr = CPSTrainer(cfg, dev())
+            res = []
+            for i, (l_in, l_tg, ul_in) in enumerate(cps_loop.batches(2, 64, 2)):
+                o = tr.step(l_in.to(dev()), l_tg.to(dev()), ul_in.to(dev()))
+                res.append({k: float(v) for k, v in o.items()})
+            probe = torch.cat([p.detach().float().reshape(-1)[:64] for p in tr.models[0].parameters()]).cpu()
+            outs.append((res, probe))
+        finally:
+            _hip.PY_OPTS.pop("py_fanin", None)
+    tol = 2e-2 if amp is not None else 2e-4
+    for a, b in zip(outs[0][0], outs[1][0]):
+        for k in ("loss", "sup_loss_1", "cps_loss", "commitment_loss", "prototype_loss"):
+            assert abs(a[k] - b[k]) <= tol * abs(b[k]) + 1e-6, (k, a[k], b[k])
+    assert rel(outs[0][1], outs[1][1]) < (5e-2 if amp is not None else 1e-3)

@@ -96,7 +96,10 @@ SYMBOLS = {
     "vqseg_conv_pack_all_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqseg_conv_packed_s2_elems": (c_size_t, [c_int, c_int, c_int]),
     "vqseg_conv_pack_weights_s2_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "vqseg_conv2d_dgrad_s2_f": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "vqseg_conv2d_dgrad_s2_f": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "vqseg_head1x1_backward_add_f": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_void_p]),
+    "vqseg_maxpool3x3s2_backward_add_f": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vqseg_conv_pack_weights_s3_f32": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p, c_void_p]),
     "vqseg_s3_split_f": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "vqseg_s3_merge_f": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),

@@ -31,6 +31,8 @@ struct ConvArgs {
     // strided output placement: GEMM row (n, oh, ow) -> pixel (n, 2 oh + omap_ph, 2 ow + omap_pw) of an omap_h x omap_w grid
     int omap = 0, omap_h = 0, omap_w = 0, omap_ph = 0, omap_pw = 0;
     int prof_k = 0;             // kernel size the launch is filed under by the convolution profile (0: KH)
+    int ep_res_out = 0;         // 1: ep_res is indexed like the OUTPUT (through omap) instead of by GEMM row -- in-place accumulation
+                                // into a tensor of the output's geometry (launch_dgrad_s2 with `accumulate`)
 };
 
 struct WgradArgs {
@@ -67,7 +69,7 @@ hipError_t launch_pack_all(const float* w, int Cout, int Cin, int K, int C1, uns
                            hipStream_t st);
 hipError_t launch_pack_weights_s2(const float* w, int Cout, int Cin, int K, unsigned short* hi, unsigned short* lo, hipStream_t st);
 hipError_t launch_dgrad_s2(const void* gy, const unsigned short* w_hi, const unsigned short* w_lo, void* gx, int N, int Ho, int Wo,
-                           int Cout, int Cin, int K, int OH, int OW, int precise, hipStream_t st);
+                           int Cout, int Cin, int K, int OH, int OW, int precise, int accumulate, hipStream_t st);
 hipError_t launch_pack_weights_s3(const float* w, int Cout, int Cin, int C1, int KH, int KW, unsigned short* out, hipStream_t st);
 
 }  // namespace vqseg

@@ -280,8 +280,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
             const int co = co0 + ch * O_EPC;
             if (m < M && co < p.Cout) {
                 u32x4 v = *reinterpret_cast<const u32x4*>(ot + ((size_t)row * OS + ch * O_EPC) * (PRECISE ? 4 : 2));
+                const long mo = out_row(p, m);
                 if (ep_res) {                               // residual add (+ ReLU) on the way out
-                    const u32x4 rv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.ep_res) + (m * p.Cout + co) * (PRECISE ? 4 : 2));
+                    const long mr = p.ep_res_out ? mo : m;
+                    const u32x4 rv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.ep_res) + (mr * p.Cout + co) * (PRECISE ? 4 : 2));
                     if (PRECISE) {
                         f32x4 a4 = __builtin_bit_cast(f32x4, v);
                         const f32x4 r4 = __builtin_bit_cast(f32x4, rv);
@@ -305,7 +307,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
 #if GLDS_ABL & 1
                 if (v[0] == 0x12345678u)
 #endif
-                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.y) + (out_row(p, m) * p.Cout + co) * (PRECISE ? 4 : 2)) = v;
+                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.y) + (mo * p.Cout + co) * (PRECISE ? 4 : 2)) = v;
             }
         }
     } else {
@@ -320,16 +322,17 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
                     const long m = row_to_m((int)(mv - m0));
                     if (mv < M && co < p.Cout) {
                         float v = acc[a][b][i];
+                        const long mo = out_row(p, m);
                         if (p.ep_scale) {
                             v = __builtin_fmaf(v, p.ep_scale[co], p.ep_shift[co]);
                             if (p.ep_res) {
+                                const long mr = p.ep_res_out ? mo : m;
                                 if (!PRECISE) v = (float)((__bf16)v);       // same rounding points as the staged path
-                                v += PRECISE ? reinterpret_cast<const float*>(p.ep_res)[m * p.Cout + co]
-                                             : (float)reinterpret_cast<const __bf16*>(p.ep_res)[m * p.Cout + co];
+                                v += PRECISE ? reinterpret_cast<const float*>(p.ep_res)[mr * p.Cout + co]
+                                             : (float)reinterpret_cast<const __bf16*>(p.ep_res)[mr * p.Cout + co];
                             }
                             if (p.ep_relu && !(v > 0.0f)) v = 0.0f;
                         }
-                        const long mo = out_row(p, m);
                         if (PRECISE) reinterpret_cast<float*>(p.y)[mo * p.Cout + co] = v;
                         else reinterpret_cast<__bf16*>(p.y)[mo * p.Cout + co] = (__bf16)v;
                     }
@@ -1579,10 +1582,30 @@ hipError_t launch_pack_weights_s2(const float* w, int Cout, int Cin, int K, unsi
 
 // gx (n, OH, OW, Cin) = data gradient of a stride-2 K x K convolution (K = 3: padded-input grid OH = H + 2 with the reflect /
 // zero fold left to the caller; K = 1: the input grid itself) from gy (n, Ho, Wo, Cout) and conv_pack_weights_s2's sub-images
+// per-channel unit scale / zero shift for launches that use the fused epilogue only for its residual add
+constexpr int UNIT_AFFINE_MAX = 4096;
+struct UnitAffine {
+    float one[UNIT_AFFINE_MAX];
+    float zero[UNIT_AFFINE_MAX];
+    constexpr UnitAffine() : one(), zero() {
+        for (int i = 0; i < UNIT_AFFINE_MAX; ++i) one[i] = 1.0f;
+    }
+};
+__device__ __attribute__((used)) UnitAffine g_unit_affine{};       // not `const`: a const namespace-scope object has internal linkage and is
+                                                                    // not registered with the runtime (hipGetSymbolAddress aborts on it)
+
+// `accumulate` (K == 1 only): gx already holds a gradient of the same tensor (the OTHER consumer's contribution to a fan-in);
+// the data gradient is added to it in place at the pixels it touches -- no memset, no separate add pass.
 hipError_t launch_dgrad_s2(const void* gy, const unsigned short* w_hi, const unsigned short* w_lo, void* gx, int N, int Ho, int Wo,
-                           int Cout, int Cin, int K, int OH, int OW, int precise, hipStream_t st) {
+                           int Cout, int Cin, int K, int OH, int OW, int precise, int accumulate, hipStream_t st) {
     const int Cp = (Cout + 31) / 32 * 32;
-    if (K == 1) {
+    if (accumulate && (K != 1 || Cin > UNIT_AFFINE_MAX)) return hipErrorInvalidValue;
+    static const UnitAffine* ua = nullptr;                   // one device per process (one process per GPU)
+    if (accumulate && !ua) {
+        hipError_t e = hipGetSymbolAddress((void**)&ua, HIP_SYMBOL(g_unit_affine));
+        if (e != hipSuccess) return e;
+    }
+    if (K == 1 && !accumulate) {
         hipError_t e = hipMemsetAsync(gx, 0, (size_t)N * OH * OW * Cin * (precise ? 4 : 2), st);
         if (e != hipSuccess) return e;
     }
@@ -1598,6 +1621,9 @@ hipError_t launch_dgrad_s2(const void* gy, const unsigned short* w_hi, const uns
         a.Ho = (OH - ph + 1) / 2; a.Wo = (OW - pw + 1) / 2;              // output pixels of this parity class
         a.stride = 1; a.pad = K == 3 ? (ph ? 0 : 1) : 0; a.pad_w = K == 3 ? (pw ? 0 : 1) : 0; a.reflect = 0; a.up = 1;
         a.ep_scale = nullptr; a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_relu = 0;
+        if (accumulate) {
+            a.ep_scale = ua->one; a.ep_shift = ua->zero; a.ep_res = gx; a.ep_res_out = 1;
+        }
         a.omap = 1; a.omap_h = OH; a.omap_w = OW; a.omap_ph = ph; a.omap_pw = pw;
         a.prof_k = K;
         if ((long)a.N * a.Ho * a.Wo >= (1L << 31)) return hipErrorInvalidValue;

@@ -246,8 +246,24 @@ int vqseg_head1x1_backward_f(int bf16, const void* x, const float* w, const floa
                              float* gw, float* workspace, void* stream) {
     if (!x || !w || !g || !gx || !gw || !workspace || cout > 4 || cout <= 0 || cin <= 0 || cin * cout > 256 || cin % 8 || cin > 64 || !a16(x) || !a16(gx))
         return bad("head1x1 backward: bad argument (Cout <= 4, Cin % 8 == 0, Cin <= 64, 16-byte aligned rows)");
-    hipError_t e = vqseg::launch_head_bwd(bf16, x, w, g, m_rows, cin, cout, gx, gw, workspace, static_cast<hipStream_t>(stream));
+    hipError_t e = vqseg::launch_head_bwd(bf16, x, w, g, m_rows, cin, cout, gx, gw, workspace, nullptr, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hipfail(e, "head_bwd");
+}
+
+int vqseg_head1x1_backward_add_f(int bf16, const void* x, const float* w, const float* g, int64_t m_rows, int cin, int cout, void* gx,
+                                 float* gw, float* workspace, const void* gx_add, void* stream) {
+    if (!x || !w || !g || !gx || !gw || !workspace || cout > 4 || cout <= 0 || cin <= 0 || cin * cout > 256 || cin % 8 || cin > 64 || !a16(x) || !a16(gx) ||
+        !a16(gx_add))
+        return bad("head1x1 backward: bad argument (Cout <= 4, Cin % 8 == 0, Cin <= 64, 16-byte aligned rows)");
+    hipError_t e = vqseg::launch_head_bwd(bf16, x, w, g, m_rows, cin, cout, gx, gw, workspace, gx_add, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "head_bwd");
+}
+
+int vqseg_maxpool3x3s2_backward_add_f(int bf16, const void* g, const unsigned char* idx, const void* gx_add, int n, int h, int w, int c,
+                                      void* gx, void* stream) {
+    if (!g || !idx || !gx || n <= 0 || h <= 0 || w <= 0 || c <= 0) return bad("maxpool backward: null pointer or bad size");
+    hipError_t e = vqseg::launch_maxpool(bf16, gx_add ? 2 : 1, gx_add, g, n, h, w, c, gx, const_cast<unsigned char*>(idx), static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "maxpool");
 }
 
 int vqseg_im2col_f(int out_bf16, const float* x, int n, int h, int w, int cin, int kh, int kw, int stride, int pad, int reflect,
@@ -279,7 +295,8 @@ int vqseg_conv_pack_weights_s2_f32(const float* w, int cout, int cin, int k, voi
 }
 
 int vqseg_conv2d_dgrad_s2_f(const void* gy, const void* w_hi, const void* w_lo, void* gx, int n, int ho, int wo, int cout, int cin, int k,
-                            int oh, int ow, int precise, void* stream) {
+                            int oh, int ow, int precise, int accumulate, void* stream) {
+    if (accumulate && k != 1) return bad("conv2d_dgrad_s2: accumulate is implemented for k == 1");
     if (!gy || !w_hi || !gx || (precise && !w_lo)) return bad("conv2d_dgrad_s2: null pointer");
     if (n <= 0 || ho <= 0 || wo <= 0 || cout <= 0 || cin <= 0 || oh <= 0 || ow <= 0 || (k != 1 && k != 3)) return bad("conv2d_dgrad_s2: bad dimension");
     const int epc = precise ? 4 : 8;
@@ -288,7 +305,7 @@ int vqseg_conv2d_dgrad_s2_f(const void* gy, const void* w_hi, const void* w_lo, 
     // the grid must be the one the forward layer's geometry implies: k = 3 -> padded input (2 ho + 1 or 2 ho + 2 rows), k = 1 -> 2 ho - 1 or 2 ho
     if (oh < 2 * ho - 1 || oh > 2 * ho + 2 || ow < 2 * wo - 1 || ow > 2 * wo + 2) return bad("conv2d_dgrad_s2: output grid does not match a stride-2 layer");
     hipError_t e = vqseg::launch_dgrad_s2(gy, static_cast<const unsigned short*>(w_hi), static_cast<const unsigned short*>(w_lo), gx, n, ho, wo,
-                                          cout, cin, k, oh, ow, precise, static_cast<hipStream_t>(stream));
+                                          cout, cin, k, oh, ow, precise, accumulate, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hipfail(e, "conv2d_dgrad_s2");
 }
 

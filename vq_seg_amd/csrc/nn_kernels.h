@@ -27,7 +27,7 @@ hipError_t launch_bilinear(int bf16, int backward, const void* src, int N, int H
 hipError_t launch_head_fwd(int bf16, const void* x, const float* w, long M, int Cin, int Cout, float* y, hipStream_t st);
 long head_bwd_blocks(long M);
 hipError_t launch_head_bwd(int bf16, const void* x, const float* w, const float* g, long M, int Cin, int Cout, void* gx,
-                           float* gw, float* partial, hipStream_t st);
+                           float* gw, float* partial, const void* gx_add, hipStream_t st);
 hipError_t launch_reduce_partials(const float* partial, long n_blocks, long n, float* out, int accumulate, hipStream_t st);
 hipError_t launch_im2col_stem(int out_bf16, const float* x, int N, int H, int W, int Cin, int KH, int KW, int stride, int pad,
                               int reflect, int Ho, int Wo, int Kp, void* out, hipStream_t st);

@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 // backward from the saved window positions: an input pixel gathers g of the (at most four) windows whose maximum it is
 template <typename T, int VC>
 __global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const unsigned char* __restrict__ idx, const T* __restrict__ g, int N,
-                                                              int H, int W, int C, int Ho, int Wo, T* __restrict__ gx) {
+                                                              int H, int W, int C, int Ho, int Wo, T* __restrict__ gx, const T* __restrict__ gx_add) {
     constexpr int V = VecN<T>::N;
     const int cv = C / VC;
     const long total = (long)N * H * W * cv;
@@ -720,6 +720,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const unsigned cha
                 for (int e = 0; e < VC; ++e)
                     if (pos[e] == me) acc[e] += gv[e];
             }
+        }
+        if (gx_add) {                                       // fan-in: the pooled tensor's other consumer (autograd's add: both rounded to T first)
+            float ad[V];
+            ldc<T, VC>(gx_add, (((long)n * H + ih) * W + iw) * C + c, ad);
+#pragma unroll
+            for (int e = 0; e < VC; ++e) acc[e] = (float)(T)acc[e] + ad[e];
         }
         stc<T, VC>(gx, (((long)n * H + ih) * W + iw) * C + c, acc);
     }
@@ -1020,7 +1026,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
 // data gradient: thread = (row, 8-channel chunk), one 16-byte (bf16) / two 16-byte (f32) stores
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restrict__ g, const float* __restrict__ w, long M,
-                                                            int Cin, int Cout, T* __restrict__ gx) {
+                                                            int Cin, int Cout, T* __restrict__ gx, const T* __restrict__ gx_add) {
     __shared__ float ws[4 * 64];
     for (int i = threadIdx.x; i < Cout * Cin; i += 256) ws[i] = w[i];
     __syncthreads();
@@ -1039,6 +1045,24 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restr
             for (int o = 0; o < 4; ++o)
                 if (o < Cout) a = __builtin_fmaf(gv[o], ws[o * Cin + c + e], a);
             out[e] = a;
+        }
+        if (gx_add) {
+            // fan-in: the other consumer's gradient of the same tensor, added the way autograd would add the two (each rounded to T first)
+            float ad[8];
+            if constexpr (sizeof(T) == 2) {
+                const u32x4 r = *reinterpret_cast<const u32x4*>(gx_add + m * Cin + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ad[2 * e] = __builtin_bit_cast(float, r[e] << 16);
+                    ad[2 * e + 1] = __builtin_bit_cast(float, r[e] & 0xFFFF0000u);
+                }
+            } else {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(gx_add + m * Cin + c), a1 = *reinterpret_cast<const f32x4*>(gx_add + m * Cin + c + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ad[e] = a0[e], ad[4 + e] = a1[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = (float)(T)out[e] + ad[e];
         }
         if constexpr (sizeof(T) == 2) {
             u32x4 r;
@@ -1554,7 +1578,7 @@ static void maxpool_t(int backward, const void* x, const void* g, int N, int H, 
                            W, C, Ho, Wo, (T*)out, idx);
     else if (idx)
         hipLaunchKernelGGL((maxpool_bwd_idx_kernel<T, VC>), dim3(grid_for((long)N * H * W * (C / VC))), dim3(256), 0, st_, idx,
-                           (const T*)g, N, H, W, C, Ho, Wo, (T*)out);
+                           (const T*)g, N, H, W, C, Ho, Wo, (T*)out, (const T*)(backward == 2 ? x : nullptr));
     else
         hipLaunchKernelGGL((maxpool_bwd_kernel<T, VC>), dim3(grid_for((long)N * H * W * (C / VC))), dim3(256), 0, st_, (const T*)x,
                            (const T*)g, N, H, W, C, Ho, Wo, (T*)out);
@@ -1631,10 +1655,10 @@ hipError_t launch_head_fwd(int bf16, const void* x, const float* w, long M, int 
 long head_bwd_blocks(long M) { return (M + HEAD_ROWS - 1) / HEAD_ROWS; }
 
 hipError_t launch_head_bwd(int bf16, const void* x, const float* w, const float* g, long M, int Cin, int Cout, void* gx,
-                           float* gw, float* partial, hipStream_t st_) {
+                           float* gw, float* partial, const void* gx_add, hipStream_t st_) {
     const unsigned gr = grid_for(M * (Cin / 8));
-    DISPATCH_T(bf16, hipLaunchKernelGGL(head_bwd_data_kernel<float>, dim3(gr), dim3(256), 0, st_, g, w, M, Cin, Cout, (float*)gx),
-               hipLaunchKernelGGL(head_bwd_data_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, g, w, M, Cin, Cout, (__bf16*)gx));
+    DISPATCH_T(bf16, hipLaunchKernelGGL(head_bwd_data_kernel<float>, dim3(gr), dim3(256), 0, st_, g, w, M, Cin, Cout, (float*)gx, (const float*)gx_add),
+               hipLaunchKernelGGL(head_bwd_data_kernel<__bf16>, dim3(gr), dim3(256), 0, st_, g, w, M, Cin, Cout, (__bf16*)gx, (const __bf16*)gx_add));
     const long nb = head_bwd_blocks(M);
     const size_t lds = (size_t)(256 / (Cin / 8)) * Cout * Cin * sizeof(float);
     DISPATCH_T(bf16, hipLaunchKernelGGL(head_bwd_weight_kernel<float>, dim3((unsigned)nb), dim3(256), lds, st_, (const float*)x, g, M, Cin, Cout, partial),

@@ -60,8 +60,10 @@ class Bottleneck(nn.Module):
         if self.downsample is None:
             return nnf.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=x, link_out=link)
         # the projection runs AFTER conv2 so that its backward comes before conv1's (autograd runs later nodes first)
+        # (a tagged block input -- an encoder feature that also feeds the decoder / a VQ layer -- has the other consumer's gradient
+        # absorbed by this projection's data gradient: nnf fan-in fusion)
         idt = nnf.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False,
-                              link_x=link if nnf.py_opt("py_link_projection", 1) else None)
+                              link_x=link if nnf.py_opt("py_link_projection", 1) else None, absorb_fanin=True)
         return nnf.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=idt)
 
 
@@ -116,12 +118,16 @@ class ResNetEncoder(nn.Module):
     def forward(self, x):
         """-> [x, stem (C64, /2), layer1 (/4), layer2 (/8), layer3 (/16), layer4 (/32)][: depth + 1]"""
         feats = [x]
-        y = nnf.stem_conv_bn_act(x, self.conv1, self.bn1)
+        y = nnf.fanin_tag(nnf.stem_conv_bn_act(x, self.conv1, self.bn1))      # two consumers: the pool and the decoder's last block
         feats.append(y)
         y = nnf.max_pool_3x3_s2(y)
-        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+        layers = (self.layer1, self.layer2, self.layer3, self.layer4)
+        for li, layer in enumerate(layers):
             for blk in layer:
                 y = blk(y)
+            nxt = layers[li + 1][0] if li + 1 < len(layers) else None
+            if isinstance(nxt, Bottleneck) and nxt.downsample is not None and li + 1 <= self._depth - 1:
+                nnf.fanin_tag(y)                                  # the next stage's projection absorbs the decoder-side gradient
             feats.append(y)
         return feats[: self._depth + 1]
 

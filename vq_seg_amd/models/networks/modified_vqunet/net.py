@@ -90,6 +90,8 @@ class _VQRePTUnet1x1Base(nn.Module):
 
     def decode(self, feats):
         decoder_out = self.decoder(*feats)
+        if self.training:                                    # two consumers in training mode: the head and the prototype loss
+            nnf.fanin_tag(decoder_out)
         return decoder_out, self.segmentation_head(decoder_out)
 
     def _trunk(self, x):

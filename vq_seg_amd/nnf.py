@@ -269,11 +269,82 @@ class GradLink:
     Projection shortcut: the shortcut's convolution sends the gradient of ITS input (`link_x`) the same way.  Its backward
     has no dependency on the first conv's, so the order is the autograd engine's choice: a producer that arrives after the
     consumer has run (`closed`) simply returns its gradient to autograd."""
-    __slots__ = ("g", "closed")
+    __slots__ = ("g", "closed", "leftover", "__weakref__")
 
     def __init__(self):
         self.g = None
         self.closed = False
+        self.leftover = None
+
+
+# ------------------------------------------------------------------------------------------------
+# Fan-in fusion (r4).  A tensor with TWO consumers (an encoder feature feeds the next encoder stage AND the decoder / its VQ layer;
+# the decoder output feeds the head AND the prototype loss) gets two gradients that autograd adds in a separate pass over the
+# tensor (5 such adds per backward pass, ~2 ms per training step).  With fusion on, the producer of the tensor tags it with a
+# GradLink (`t._vq_fanin`); the consumer whose backward runs FIRST deposits its gradient there (and returns nothing to autograd),
+# the one that runs LAST adds it inside its own kernel: the stride-2 1x1 projection's data gradient accumulates in place
+# (vqseg_conv2d_dgrad_s2_f accumulate), the max-pool and head backward kernels take an addend.  Results are bit-identical to
+# autograd's add.  Order is a data dependency for the encoder features (the decoder's backward is upstream of the encoder's) and
+# the engine's priority order for the decoder output; a depositor that comes after the absorber (`closed`) returns its gradient
+# to autograd as usual.  A deposit that nobody absorbs would be a lost gradient: only callers that check for it after backward
+# (trainer.CPSTrainer: check_fanin_consumed) switch the fusion on.
+# ------------------------------------------------------------------------------------------------
+_FANIN_ON = False
+_FANIN_OPEN: set = set()                                  # links holding a deposited, not yet absorbed gradient
+
+
+def set_fanin_fusion(on: bool) -> bool:
+    global _FANIN_ON
+    prev = _FANIN_ON
+    _FANIN_ON = bool(on) and py_opt("py_fanin", 1) == 1
+    return prev
+
+
+def fanin_tag(t):
+    """producer side: mark `t` (a tensor with two consumers) for fan-in fusion in the coming backward"""
+    if _FANIN_ON and torch.is_tensor(t) and t.requires_grad and torch.is_grad_enabled():
+        t._vq_fanin = GradLink()
+    return t
+
+
+def _fanin_of(t):
+    return getattr(t, "_vq_fanin", None) if (_FANIN_ON and torch.is_tensor(t)) else None
+
+
+def _fanin_deposit(link, g_rows) -> bool:
+    """first consumer: hand the gradient (NHWC rows) to the link; False: the absorber has already run"""
+    if link is None or link.closed or link.g is not None:
+        return False
+    link.g = g_rows
+    _FANIN_OPEN.add(link)
+    return True
+
+
+def _fanin_take(link, shape, dtype):
+    """last consumer: the deposited gradient if it fits (shape, dtype, dense), else None; either way the link is closed.
+    A deposit that does not fit is returned through `link.leftover` for a plain add."""
+    if link is None:
+        return None
+    link.closed = True
+    g, link.g = link.g, None
+    _FANIN_OPEN.discard(link)
+    if g is None:
+        return None
+    if tuple(g.shape) == tuple(shape) and g.dtype == dtype and g.is_contiguous():
+        return g
+    link.leftover = g
+    return None
+
+
+def check_fanin_consumed() -> None:
+    """after backward: every deposited gradient must have been absorbed (else it never reached its tensor)"""
+    if _FANIN_OPEN:
+        n = len(_FANIN_OPEN)
+        for l_ in list(_FANIN_OPEN):
+            l_.g = None
+        _FANIN_OPEN.clear()
+        raise RuntimeError(f"fan-in fusion: {n} deposited gradient(s) were never absorbed -- a consumer's backward did not run; "
+                           f"switch the fusion off (VQSEG_OPTS=py_fanin=0) for graphs that use only part of the model's outputs")
 
 
 _UNIT_AFFINE = {}
@@ -457,7 +528,7 @@ def _conv_bn_act_s3(x: "S3", x2, residual, conv, bn, relu, kernel_1x1_cols: int 
 class _ConvBNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x2, residual, weight, gamma, beta, bn, stride, pad, reflect, relu, patches_of, fuse_eval=False,
-                link_in=None, link_out=None, link_x=None):
+                link_in=None, link_out=None, link_x=None, fan_x=None, fan_x2=None):
         """x (N,C1,H,W) [+ x2 (N,C2,H,W)] -> out (N,Cout,Ho,Wo).  `patches_of` = (kh, kw, cin, stride, pad, reflect,
         H, W) when x is an im2col patch matrix of the stem (then the convolution itself is 1x1)."""
         xr = _rows(x)
@@ -523,6 +594,7 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.params = (weight, gamma, beta)                                  # the Parameter objects (see grad sinks)
         ctx.bn = bn
         ctx.links = (link_in, link_out, link_x)
+        ctx.fans = (fan_x, fan_x2)                                          # fan-in links: absorb into x's gradient / deposit x2's
         ctx.cfg = (stride, pad, bool(reflect), bool(relu), training, residual is not None, patches_of, (n, h, w, c1, cin, cout,
                                                                                                          kh, kw, ho, wo))
         return _nchw(out)
@@ -627,12 +699,16 @@ class _ConvBNAct(torch.autograd.Function):
                     # stride-2 layer: parity classes of the output pixel instead of a dilated gradient grid (vqseg_conv2d_dgrad_s2_f)
                     s_hi, s_lo = _s2_weights(weight, precise)
                     gh, gw_ = (h + 2, w + 2) if kh == 3 else (h, w)          # k = 3: the padded input's grid
-                    gp = torch.empty((n, gh, gw_, c_cnt), dtype=g_y.dtype, device=dev)
+                    # fan-in (1x1 projection of a stage's first block): the input's OTHER consumer (decoder skip / VQ layer) has
+                    # deposited its gradient; this data gradient accumulates into it in place -- no memset, no add pass
+                    acc_g = _fanin_take(fan_x, (n, gh, gw_, c_cnt), g_y.dtype) if (kh == 1 and c_cnt <= 4096) else None
+                    gp = acc_g if acc_g is not None else torch.empty((n, gh, gw_, c_cnt), dtype=g_y.dtype, device=dev)
                     with _hip.on_device(dev):
                         sneed = L.vqseg_conv_packed_s2_elems(cout, c_cnt, kh)
                         _check(L.vqseg_conv2d_dgrad_s2_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), _w16(s_hi, "parity-class image", sneed),
                                                          _w16(s_lo, "parity-class image (lo)", sneed), _T(gp, "input gradient", bf=bf, numel=n * gh * gw_ * c_cnt),
-                                                         n, ho, wo, cout, c_cnt, kh, gh, gw_, int(precise), _stream()), "vqseg_conv2d_dgrad_s2_f")
+                                                         n, ho, wo, cout, c_cnt, kh, gh, gw_, int(precise), int(acc_g is not None), _stream()),
+                               "vqseg_conv2d_dgrad_s2_f")
                     if kh == 3 and not reflect:                              # zero padding: the gradient of the padded border is dropped
                         return gp[:, 1:h + 1, 1:w + 1, :].contiguous()
                 else:
@@ -648,20 +724,31 @@ class _ConvBNAct(torch.autograd.Function):
                                                   _T(gxx, "input gradient", bf=bf, numel=n * h * w * c_cnt), _stream()), "vqseg_reflect_fold_f")
                 return gxx
 
+            fan_x, fan_x2 = ctx.fans
             if need1:
                 g1 = dgrad(0, c1)
                 if extra is not None:                                       # link not fusable here: plain add
                     g1 = g1 + extra
                     extra = None
+                if fan_x is not None:                                       # a deposit the kernel path above could not absorb
+                    rest = _fanin_take(fan_x, g1.shape, g1.dtype)
+                    rest = rest if rest is not None else fan_x.leftover
+                    fan_x.leftover = None
+                    if rest is not None:
+                        g1 = g1 + rest.reshape(g1.shape).to(g1.dtype)
                 if link_x is not None and not link_x.closed and x2r is None:
                     link_x.g = g1                                           # the block's first conv adds it (GradLink)
                 else:
                     gx = _nchw(g1)
             if need2 and x2r is not None:
-                gx2 = _nchw(dgrad(c1, cin - c1))
+                g2 = dgrad(c1, cin - c1)
+                if g2.dtype == x2r.dtype and _fanin_deposit(fan_x2, g2):    # x2's other consumer adds it inside its own kernel
+                    gx2 = None
+                else:
+                    gx2 = _nchw(g2)
         g_res_out = _nchw(g_res) if (has_res and link_out is None) else None
         return (gx, gx2, g_res_out, None if sink_w else gw, None if sink_bn else dgb[0],
-                None if sink_bn else dgb[1], None, None, None, None, None, None, None, None, None, None)
+                None if sink_bn else dgb[1], None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def _s2_weights(weight, precise):
@@ -697,7 +784,7 @@ def _stem_weights(weight, precise, kp):
     return cache[k]
 
 
-def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None, link_in=None, link_out=None, link_x=None):
+def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None, link_in=None, link_out=None, link_x=None, absorb_fanin=False):
     """Conv2d (no bias; zero or reflect padding) -> BatchNorm2d -> [+ residual] -> [ReLU] on the HIP kernels.
     `x2`: second input whose channels follow x's (the decoder's concat).  `training` is ignored: the
     BatchNorm module's own mode decides (nn.BatchNorm2d semantics)."""
@@ -717,9 +804,11 @@ def conv_bn_act(x, conv, bn, training=None, relu=True, residual=None, x2=None, l
         raise _hip.HipLibraryError(f"the HIP path needs 'cuda' (ROCm) tensors, got {x.device}; there is no CPU fallback")
     pad = conv.padding[0]
     _sink_use(conv.weight, bn.weight, bn.bias)
+    # fan-in links (see set_fanin_fusion): `absorb_fanin` -- this convolution's data gradient takes in the gradient x's other
+    # consumer deposited; a tagged x2 (the decoder's skip input) gets ITS gradient deposited instead of returned to autograd
     return _ConvBNAct.apply(x, x2, residual, conv.weight, bn.weight, bn.bias, bn, conv.stride[0], pad,
                             conv.padding_mode == "reflect" and pad > 0, relu, None, not bn.training and not torch.is_grad_enabled(),
-                            link_in, link_out, link_x)
+                            link_in, link_out, link_x, _fanin_of(x) if absorb_fanin else None, _fanin_of(x2))
 
 
 # Within ONE training step the same image tensor goes through several stems: both networks of a CPS pair see the same
@@ -799,7 +888,7 @@ def stem_conv_bn_act(x, conv, bn):
 # ------------------------------------------------------------------------------------------------
 class _MaxPool(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, fan=None):
         xr = _rows(x)
         n, h, w, c = xr.shape
         ho, wo = _out_size(h, 3, 2, 1), _out_size(w, 3, 2, 1)
@@ -812,6 +901,7 @@ class _MaxPool(torch.autograd.Function):
                                               _T(idx, "pool argmax", dtype=torch.uint8, numel=n * ho * wo * c), _stream()), "vqseg_maxpool3x3s2_f")
         ctx.save_for_backward(idx)                          # window position of every maximum: the input is not kept
         ctx.cfg = (n, h, w, c, xr.dtype)
+        ctx.fan = fan
         return _nchw(y)
 
     @staticmethod
@@ -821,11 +911,21 @@ class _MaxPool(torch.autograd.Function):
         gr = _rows(g).to(dt)
         gx = torch.empty((n, h, w, c), dtype=dt, device=gr.device)
         bf = int(dt == torch.bfloat16)
+        add = _fanin_take(ctx.fan, (n, h, w, c), dt)       # the pooled tensor's other consumer deposited its gradient: added in the kernel
         with _hip.on_device(gr.device):
-            _check(lib().vqseg_maxpool3x3s2_f(bf, 1, None, _T(gr, "pool output gradient", bf=bf, numel=idx.numel()), n, h, w, c,
-                                              _T(gx, "pool input gradient", bf=bf, numel=n * h * w * c),
-                                              _T(idx, "pool argmax", dtype=torch.uint8), _stream()), "vqseg_maxpool3x3s2_f")
-        return _nchw(gx)
+            if add is not None:
+                _check(lib().vqseg_maxpool3x3s2_backward_add_f(bf, _T(gr, "pool output gradient", bf=bf, numel=idx.numel()),
+                                                               _T(idx, "pool argmax", dtype=torch.uint8), _T(add, "fan-in gradient", bf=bf, numel=n * h * w * c),
+                                                               n, h, w, c, _T(gx, "pool input gradient", bf=bf, numel=n * h * w * c), _stream()),
+                       "vqseg_maxpool3x3s2_backward_add_f")
+            else:
+                _check(lib().vqseg_maxpool3x3s2_f(bf, 1, None, _T(gr, "pool output gradient", bf=bf, numel=idx.numel()), n, h, w, c,
+                                                  _T(gx, "pool input gradient", bf=bf, numel=n * h * w * c),
+                                                  _T(idx, "pool argmax", dtype=torch.uint8), _stream()), "vqseg_maxpool3x3s2_f")
+        if ctx.fan is not None and ctx.fan.leftover is not None:
+            gx = gx + ctx.fan.leftover.reshape(gx.shape).to(dt)
+            ctx.fan.leftover = None
+        return _nchw(gx), None
 
 
 def max_pool_3x3_s2(x):
@@ -837,7 +937,7 @@ def max_pool_3x3_s2(x):
             _check(lib().vqseg_s3_maxpool3x3s2_f(_T(x.rows, "split-3 pool input", bf=2, numel=n * h * w * 2 * x.c), n, h, w, x.c,
                                                  _T(y, "split-3 pool output", bf=2, numel=n * ho * wo * 2 * x.c), _stream()), "vqseg_s3_maxpool3x3s2_f")
         return S3(y, x.c)
-    return _MaxPool.apply(x)
+    return _MaxPool.apply(x, _fanin_of(x))
 
 
 class _Bilinear(torch.autograd.Function):
@@ -882,7 +982,8 @@ class _Head1x1(torch.autograd.Function):
     """nn.Conv2d(Cin, num_classes <= 4, 1, bias=False): fp32 logits whatever the activation dtype."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, fan=None):
+        ctx.fan = fan
         xr = _rows(x)
         n, h, w, cin = xr.shape
         cout = weight.shape[0]
@@ -905,12 +1006,17 @@ class _Head1x1(torch.autograd.Function):
         gx = torch.empty_like(xr)
         gw = torch.empty((cout, cin), dtype=torch.float32, device=xr.device)
         ws = torch.empty(lib().vqseg_head1x1_backward_workspace_floats(m, cin, cout), dtype=torch.float32, device=xr.device)
+        add = _fanin_take(ctx.fan, xr.shape, xr.dtype)      # the prototype loss's gradient of the same decoder output, if it came first
         with _hip.on_device(xr.device):
             bf = _is_bf16(xr)
-            _check(lib().vqseg_head1x1_backward_f(bf, _T(xr, "head input", bf=bf, numel=m * cin), _f32(wt, "head weight", cout * cin),
-                                                  _f32(gr, "logit gradient", m * cout), m, cin, cout, _T(gx, "head input gradient", bf=bf, numel=m * cin),
-                                                  _f32(gw, "head weight gradient", cout * cin), _f32(ws, "head workspace"), _stream()), "vqseg_head1x1_backward_f")
-        return _nchw(gx), gw.reshape(cout, cin, 1, 1)
+            _check(lib().vqseg_head1x1_backward_add_f(bf, _T(xr, "head input", bf=bf, numel=m * cin), _f32(wt, "head weight", cout * cin),
+                                                      _f32(gr, "logit gradient", m * cout), m, cin, cout, _T(gx, "head input gradient", bf=bf, numel=m * cin),
+                                                      _f32(gw, "head weight gradient", cout * cin), _f32(ws, "head workspace"),
+                                                      _T(add, "fan-in gradient", bf=bf, numel=m * cin), _stream()), "vqseg_head1x1_backward_add_f")
+        if ctx.fan is not None and ctx.fan.leftover is not None:
+            gx = gx + ctx.fan.leftover.reshape(gx.shape).to(gx.dtype)
+            ctx.fan.leftover = None
+        return _nchw(gx), gw.reshape(cout, cin, 1, 1), None
 
 
 def head_conv1x1(x, weight):
@@ -923,7 +1029,7 @@ def head_conv1x1(x, weight):
             _check(lib().vqseg_head1x1_forward_f(2, _T(x.rows, "split-3 head input", bf=2, numel=n * h * w * 2 * x.c), _f32(wt, "head weight", cout * x.c),
                                                  n * h * w, x.c, cout, _f32(y, "logits", n * h * w * cout), _stream()), "vqseg_head1x1_forward_f")
         return _nchw(y)
-    return _Head1x1.apply(from_s3(x), weight)
+    return _Head1x1.apply(from_s3(x), weight, _fanin_of(x))
 
 
 class _Cast(torch.autograd.Function):
@@ -961,7 +1067,8 @@ def cast_act(x, dtype):
 # ------------------------------------------------------------------------------------------------
 class _ProtoLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, proto, labels, keep, conf, variant, scale, margin, easy_margin):
+    def forward(ctx, x, proto, labels, keep, conf, variant, scale, margin, easy_margin, fan=None):
+        ctx.fan = fan
         xr = _rows(x)
         n, h, w, c = xr.shape
         m, k = n * h * w, proto.shape[0]
@@ -1001,7 +1108,9 @@ class _ProtoLoss(torch.autograd.Function):
                                                  _f32(conf, "confidence", m), m, c, k, variant, scale, margin, easy, _f32(g32, "loss gradient", 1),
                                                  _T(gx, "feature gradient", bf=bf, numel=m * c), _f32(gproto, "prototype gradient", k * c),
                                                  _T(ws, "workspace", dtype=torch.uint8, numel=nbytes), nbytes, _stream()), "vqseg_proto_loss_backward_f")
-        return _nchw(gx), gproto, None, None, None, None, None, None, None
+        if _fanin_deposit(ctx.fan, gx):                      # the head's backward (same decoder output) adds it in its kernel
+            return None, gproto, None, None, None, None, None, None, None, None
+        return _nchw(gx), gproto, None, None, None, None, None, None, None, None
 
 
 def proto_loss_supported(x, num_classes: int) -> bool:
@@ -1012,7 +1121,7 @@ def proto_loss_supported(x, num_classes: int) -> bool:
 def proto_loss(x, proto, labels, keep=None, conf=None, variant=1, scale=1.0, margin=0.0, easy_margin=True):
     """-mean( log( exp(S) / (sum_c exp(z_c) + 1e-7) + 1e-7 ) * w ) of the reliable prototype losses (float64 scalar);
     x (N, C, H, W) decoder features, proto (K, C) L2-normalised, labels / keep / conf per pixel in (n, h, w) order."""
-    return _ProtoLoss.apply(x, proto, labels, keep, conf, variant, scale, margin, easy_margin)
+    return _ProtoLoss.apply(x, proto, labels, keep, conf, variant, scale, margin, easy_margin, _fanin_of(x))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -381,9 +381,11 @@ class CPSTrainer:
             ul_input = ul_input.contiguous(memory_format=torch.channels_last)
             if nnf.py_opt("py_stem_share", 1):
                 nnf.stem_share_begin()
+        prev = nnf.set_fanin_fusion(True)                              # fan-in adds inside the consumers' kernels; checked after backward
         try:
             return self._step(l_input, l_target, ul_input, epoch_frac)
         finally:
+            nnf.set_fanin_fusion(prev)
             nnf.stem_share_end()
 
     def _step(self, l_input, l_target, ul_input, epoch_frac):
@@ -434,6 +436,7 @@ class CPSTrainer:
         finally:
             self._wgrad_sides(False)
         nnf.flush_pending_wgrads()                                      # two-use weight gradients whose second use never came (none, normally)
+        nnf.check_fanin_consumed()
         if self._two_streams and nnf.py_opt("py_opt_streams", 1):
             # each network's gradient reduction + optimiser step on ITS stream (the sinks wrote p.grad there): the two Adam launches
             # overlap each other and the metric kernels below; the caller's stream joins both before the step returns

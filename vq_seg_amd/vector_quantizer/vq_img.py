@@ -19,6 +19,7 @@ import torch
 from torch import nn
 
 from .. import _hip
+from .. import nnf
 from .._wcache import cache_of as _cache_of, invalidate as _invalidate
 from ..dist import collectives_on as _collectives_on, broadcast0 as _broadcast0, all_reduce_sum as _all_reduce_sum
 
@@ -62,8 +63,9 @@ class _VQGroupFunction(torch.autograd.Function):
     per level exactly _VQFunction's outputs and gradient."""
 
     @staticmethod
-    def forward(ctx, training, weights, n, *tensors):
+    def forward(ctx, training, weights, n, fans, *tensors):
         rows, codebooks, prepared = tensors[:n], tensors[n:2 * n], tensors[2 * n:3 * n]
+        ctx.fans = fans                                      # per level: (fan-in link of the feature map, its (b, h, w, c)) or None
         outs = _hip.vq_forward_group(list(rows), list(codebooks), list(prepared), training, weights)
         ctx.n, ctx.training, ctx.weights = n, bool(training), [float(w) for w in weights]
         ctx.bf16 = rows[0].dtype == torch.bfloat16
@@ -82,7 +84,7 @@ class _VQGroupFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         n = ctx.n
-        none = (None, None, None) + (None,) * (3 * n)
+        none = (None, None, None, None) + (None,) * (3 * n)
         if not ctx.training:
             return none
         saved = ctx.saved_tensors
@@ -99,7 +101,10 @@ class _VQGroupFunction(torch.autograd.Function):
                 rows, quant = saved[2 * i:2 * i + 2]
                 g_quant = torch.zeros_like(rows) if g_quant is None else g_quant.contiguous()
                 gxs.append(_hip.vq_backward(g_quant, gl, rows, quant, w))
-        return (None, None, None) + tuple(gxs) + (None,) * (2 * n)
+            fan = ctx.fans[i] if ctx.fans is not None else None
+            if fan is not None and gxs[-1].dtype == fan[2] and nnf._fanin_deposit(fan[0], gxs[-1].reshape(fan[1])):
+                gxs[-1] = None                               # the feature map's other consumer (the next encoder stage) adds it in its kernel
+        return (None, None, None, None) + tuple(gxs) + (None,) * (2 * n)
 
 
 def quantize_group(vqs, feats):
@@ -118,7 +123,17 @@ def quantize_group(vqs, feats):
         return None
     n = len(vqs)
     weights = [float(vq.commitment_weight) for vq in vqs]
-    flat = _VQGroupFunction.apply(vqs[0].training, weights, n, *rows, *[vq.codebook.embedding.weight.detach() for vq in vqs],
+    fans = None
+    if vqs[0].training and torch.is_grad_enabled():
+        fans = []
+        for f, r in zip(feats, rows):
+            link = nnf._fanin_of(f)
+            b, c, h, w = f.shape
+            # rows must be a VIEW of the feature map (same dtype, channels_last): then the gradient of the rows IS the gradient of f
+            fans.append((link, (b, h, w, c), f.dtype) if (link is not None and r.dtype == f.dtype and r.data_ptr() == f.data_ptr()) else None)
+        if not any(fans):
+            fans = None
+    flat = _VQGroupFunction.apply(vqs[0].training, weights, n, fans, *rows, *[vq.codebook.embedding.weight.detach() for vq in vqs],
                                   *[vq.codebook.prepared() for vq in vqs])
     outs = []
     for i, f in enumerate(feats):
