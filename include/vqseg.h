@@ -45,6 +45,10 @@ const char* vqseg_kernel_name(const char* entry_point);
  *   "conv3x3_patch_unroll", "conv3x3_patch_wide_tile"   variants of that kernel (tap loop unrolled; 256-channel tile)
  *   "vq_max_tiles_per_wave"         cap (8, 4, 2, 1) on the 32-code accumulator tiles a wave of the VQ distance kernel
  *                                   holds (default 8; 4 measured equal within 2 % on every benchmark shape)
+ *   "vq_bf16_filter"                1 (default): bf16 rows of layers with K % 256 == 0 and C % 32 == 0 take the bf16-MFMA candidate
+ *                                   filter + exact re-score (same indices and distances as the exact kernel); 0: exact kernel on every row.
+ *                                   "vq_filter_force_all" = 1 (tests): the filter decides nothing, every row is re-scored;
+ *                                   "vq_filter_launches": returns the number of launches that took the filter so far, sets the counter
  *   "conv_xcd_pair"                 implicit-GEMM layers with 2..value Cout chunks launch 1-D so that the chunks of an
  *                                   M tile run on the same XCD and share the input rows through its L2 (default 4; 0: off)
  *   "conv3x3_patch_chunk_stage"     1 (default): 3x3 layers with 32-channel K chunks and <= 64 outputs (or 32 inputs) load all nine
@@ -68,7 +72,8 @@ int vqseg_set_option(const char* key, int value);
  * disables recording and returns the number of records (>= 0).  Not thread safe. */
 int vqseg_profile_begin(int capacity);
 int vqseg_profile_collect(int max_records, int64_t* n_rows_host, int* channels_host,
-                          int* n_codes_host, float* ms_host);
+                          int* n_codes_host, float* ms_host,
+                          int* kind_host /* nullable; 0: exact fp32-MFMA kernel on f32 rows, 1: on bf16 rows, 2: bf16 candidate filter + exact re-score */);
 
 /* The same for the convolution kernels (forward, data gradient, fused-epilogue and split-3 launches of vqseg_conv2d_*): per launch
  * the ALGORITHMIC flops 2 * KH * KW * Cin * Cout * output pixels (logical channels for split-3; forward-layer pixels for the
@@ -111,6 +116,12 @@ int vqseg_vq_forward_group(int n_levels, int bf16, const void* const* x, const f
                            int training, const float* commitment_weight, void* const* quant, int64_t* const* idx,
                            float* const* loss, float* const* dead_pct, void* const* workspace,
                            const size_t* workspace_bytes, void* stream);
+
+/* Diagnostics of the bf16 candidate filter (option "vq_bf16_filter"): byte offset, inside the workspace of a bf16 call of this shape,
+ * of the 64 int32 counters (one per sub-list; their sum = the (row, code) candidate pairs the filter handed to the exact re-score;
+ * valid after the call's stream work has finished; a 65th int is the overflow flag: the exact kernel served the level); 0 if the shape does not take the filter
+ * (needs n_codes % 256 == 0 and channels % 32 == 0). */
+size_t vqseg_vq_filter_counter_offset(int64_t n_rows, int channels, int n_codes);
 
 /* Assignment only (no gather): used by k-means and by tests. */
 int vqseg_vq_assign_f32(const float* x, const float* codebook, const void* prepared,

@@ -23,10 +23,11 @@ SYMBOLS = {
     "vqseg_kernel_name": (c_char_p, [c_char_p]),
     "vqseg_set_option": (c_int, [c_char_p, c_int]),
     "vqseg_profile_begin": (c_int, [c_int]),
-    "vqseg_profile_collect": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vqseg_profile_collect": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqseg_conv_profile_begin": (c_int, [c_int]),
     "vqseg_conv_profile_collect": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqseg_vq_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "vqseg_vq_filter_counter_offset": (c_size_t, [c_int64, c_int, c_int]),
     "vqseg_vq_forward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vqseg_vq_forward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p,
@@ -142,6 +143,7 @@ def lib() -> ctypes.CDLL:
 
 
 PY_OPTS: dict = {}
+FILTER_DIAG = None            # set to a list to collect (n, c, k, open-row counter) of every bf16 grouped VQ forward (diagnostics only)
 
 
 def _check(rc: int, what: str) -> None:
@@ -302,11 +304,23 @@ def vq_forward_group(rows_list, codebooks, prepared_list, training: bool, commit
                                       ks.ctypes.data, int(bool(training)), cw.ctypes.data, ptr(quants), ptr(idxs), loss_p, dead_p,
                                       ptr(wss), ctypes.cast(wsb, c_void_p), _stream())
     _check(rc, "vqseg_vq_forward_group")
+    if FILTER_DIAG is not None and bf16:                     # diagnostics (tools/vq_filter_diag.py): per level (rows, channels, codes, counter of candidate pairs)
+        for r, w, ws_ in zip(rows_list, codebooks, wss):
+            off = L.vqseg_vq_filter_counter_offset(r.shape[0], r.shape[1], w.shape[0])
+            FILTER_DIAG.append((r.shape[0], r.shape[1], w.shape[0], ws_[off:off + 256].view(torch.int32) if off else None))
     return [(q, i, s[0:1], s[1]) for q, i, s in zip(quants, idxs, scals)]
 
 
+def set_option(key: str, value: int) -> int:
+    """vqseg_set_option: returns the previous value"""
+    prev = lib().vqseg_set_option(key.encode(), int(value))
+    if prev < 0:
+        raise HipLibraryError(f"vqseg_set_option: unknown option {key!r} or bad value {value}")
+    return prev
+
+
 def vq_assign(rows: torch.Tensor, codebook: torch.Tensor, want_dmin: bool = False,
-              prepared: Optional[torch.Tensor] = None):
+              prepared: Optional[torch.Tensor] = None, want_filter_count: bool = False):
     L = lib()
     n, c = rows.shape
     k = codebook.shape[0]
@@ -322,6 +336,10 @@ def vq_assign(rows: torch.Tensor, codebook: torch.Tensor, want_dmin: bool = Fals
         rc = fn(xp, wp, tptr(prepared, "prepared codebook", dtype=torch.uint8, numel=L.vqseg_vq_prepared_bytes(c, k)), n, c, k,
                 idx.data_ptr(), dmin.data_ptr() if want_dmin else None, ws.data_ptr(), nbytes, _stream())
     _check(rc, "vqseg_vq_assign_bf16" if bf16 else "vqseg_vq_assign_f32")
+    if want_filter_count:                                    # diagnostics: candidate pairs the bf16 filter handed to the exact re-score (None: no filter)
+        off = L.vqseg_vq_filter_counter_offset(n, c, k) if bf16 else 0
+        amb = ws[off:off + 256].view(torch.int32).sum() if off else None      # 64 sub-list counters
+        return (idx, dmin, amb) if want_dmin else (idx, amb)
     return (idx, dmin) if want_dmin else idx
 
 
@@ -456,14 +474,18 @@ def conv_profile_collect(capacity: int = 65536, with_shape: bool = False):
     return [(float(fl[i]), int(kd[i]), float(ms[i])) for i in range(cnt)]
 
 
-def profile_collect(capacity: int = 4096):
-    """-> list of (n_rows, channels, n_codes, milliseconds) for every assign launch since profile_begin."""
+def profile_collect(capacity: int = 4096, with_kind: bool = False):
+    """-> list of (n_rows, channels, n_codes, milliseconds[, kind]) for every assign launch since profile_begin
+    (kind 0: exact kernel on f32 rows, 1: exact kernel on bf16 rows, 2: bf16 candidate filter + exact re-score)."""
     import numpy as np
     n = np.zeros(capacity, dtype=np.int64)
     c = np.zeros(capacity, dtype=np.int32)
     k = np.zeros(capacity, dtype=np.int32)
     ms = np.zeros(capacity, dtype=np.float32)
-    cnt = lib().vqseg_profile_collect(capacity, n.ctypes.data, c.ctypes.data, k.ctypes.data, ms.ctypes.data)
+    kd = np.zeros(capacity, dtype=np.int32)
+    cnt = lib().vqseg_profile_collect(capacity, n.ctypes.data, c.ctypes.data, k.ctypes.data, ms.ctypes.data, kd.ctypes.data)
     if cnt < 0:
         _check(cnt, "vqseg_profile_collect")
+    if with_kind:
+        return [(int(n[i]), int(c[i]), int(k[i]), float(ms[i]), int(kd[i])) for i in range(cnt)]
     return [(int(n[i]), int(c[i]), int(k[i]), float(ms[i])) for i in range(cnt)]

@@ -85,6 +85,45 @@ __global__ __launch_bounds__(64) void vq_code_norms(const float* __restrict__ W,
     enorm[k] = s;
 }
 
+// bf16 hi / lo split of the codebook for the candidate filter: Eb[hl][c / 8][k][8]  (hl = 0: bf16(e), 1: bf16(e - hi)); zero for
+// k >= K.  One thread per (c8, k): two 16-byte loads, two 16-byte stores.
+__global__ __launch_bounds__(256) void vq_pack_codebook_bf16(const float* __restrict__ W, int K, int C, int Kp, unsigned short* __restrict__ Eb) {
+    const long total = (long)(C / 8) * Kp;
+    const size_t half = (size_t)C * Kp;                          // elements per (hi | lo) image
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % Kp);
+        const int c = (int)(i / Kp) * 8;
+        u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+        if (k < K) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(W + (size_t)k * C + c), v1 = *reinterpret_cast<const f32x4*>(W + (size_t)k * C + c + 4);
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const __bf16 h0 = (__bf16)v[2 * e], h1 = (__bf16)v[2 * e + 1];
+                const __bf16 l0 = (__bf16)(v[2 * e] - (float)h0), l1 = (__bf16)(v[2 * e + 1] - (float)h1);
+                hi[e] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                lo[e] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+            }
+        }
+        *reinterpret_cast<u32x4*>(Eb + (size_t)i * 8) = hi;
+        *reinterpret_cast<u32x4*>(Eb + half + (size_t)i * 8) = lo;
+    }
+}
+
+// max_k |e_k|^2 over the real codes (one workgroup; the padding entries of enorm are +inf)
+__global__ __launch_bounds__(256) void vq_enorm_max(const float* __restrict__ enorm, int K, float* __restrict__ out) {
+    __shared__ float sh[256];
+    float m = 0.0f;
+    for (int k = threadIdx.x; k < K; k += 256) m = __builtin_fmaxf(m, enorm[k]);
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] = __builtin_fmaxf(sh[threadIdx.x], sh[threadIdx.x + w]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
 // ------------------------------------------------------------------------------------
 // fused distance + argmin
 //
@@ -143,6 +182,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const VqGroup g) 
     const float* __restrict__ E4 = g.lv[lvl].E4;
     const float* __restrict__ enorm = g.lv[lvl].enorm;
     unsigned long long* __restrict__ keys = g.lv[lvl].keys;
+    if (g.lv[lvl].gate && *g.lv[lvl].gate <= g.lv[lvl].gate_cap) return;       // the bf16 filter's overflow fallback: not needed (the usual case)
     const long N = g.lv[lvl].N;
     const int C = g.lv[lvl].C, Cp = g.lv[lvl].C, Kp = g.lv[lvl].Kp;
     constexpr int CODES = 32 * T;                // codes per workgroup
@@ -400,6 +440,453 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const VqGroup g) 
         o[15] = (unsigned long long)row_tile;
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------
+// bf16 candidate filter (r4): the distance + argmin of BF16 pixel rows at bf16-MFMA speed with the exact kernel's result.
+//
+// The rows are exact bf16 values (autocast activations); the fp32 codebook is split e = e_hi + e_lo + rho (bf16 each,
+// |rho| <= 2^-18 |e|).  Stage 1 (this kernel) computes approximate scores
+//       s~_k = |e_k|^2 - 2 (x . e_hi_k + x . e_lo_k)        on v_mfma_f32_32x32x16_bf16 (fp32 accumulation)
+// for a 128-row x 256-code tile per workgroup and leaves, per row and 128-code sub-chunk, the minimum score, its code and the number
+// of codes within the row's BAND of that minimum; every further code inside the band goes to a list of candidate pairs.  Stage 2
+// (vq_resolve_kernel) takes the minimum over the sub-chunks: a row with exactly ONE code inside the band of the global minimum is
+// decided (that code wins under the exact arithmetic too); for every other row the surviving sub-chunks' best codes join the pair
+// list.  Stage 3 (vq_rescore_kernel) evaluates the EXACT kernel's fmaf chains for the listed (row, code) pairs on the vector ALU --
+// one lane per pair -- and merges them with the exact kernel's own key rule: index AND distance bits are those of the exact chain.
+// Whatever share of the rows is open (4 % on well separated codebooks, half of them on the 2048-channel level of an untrained
+// network), only their few candidates are re-scored, not their K codes.  A pair list that overflows (degenerate codebooks: more
+// than four candidates per row on average) switches the level to the exact kernel on every row (gated launch).
+//
+// The band.  Let D_k be the exact kernel's squared distance (fl(fl(|x|^2 - 2 dot_chain_k) + |e_k|^2)) and S = sum_i |x_i| |e_ki|
+// <= sqrt(|x|^2 max_k |e_k|^2) =: S_max.  Errors against the real value |x|^2 + |e_k|^2 - 2 x.e_k:
+//     exact chain of C fmaf's               |dot_chain - x.e| <= C 2^-24 S
+//     split residual                         |x.rho|           <= 2^-18 S
+//     C / 8 bf16 MFMAs, products exact, each sum of 17 addends aligned to the largest one and truncated below 2^-24 of it
+//     (tools/micro/mfma_bf16_rounding.hip: errors up to 2^-23.3 of the magnitude sum on crafted rows, never more than
+//      17 * 2^-24 of the largest addend)     |dot~ - x.(e_hi + e_lo)| <= (C / 8) 17 2^-24 S
+//     the final roundings of both paths      <= 2^-22 (|x|^2 + |e|^2 + 2 S)
+// so |(|x|^2 + s~_k) - D_k| <= eps := 2 (C 2^-24 + 2^-18 + (C / 8) 17 2^-24) S_max + 2^-22 (|x|^2 + E + 2 S_max), E = max |e|^2.
+// The reference argmins over sqrt(D): codes whose D differ by less than 2^-20 relative can collapse into one float, the lower index
+// wins.  Hence: if D_a <= D_b (1 + 2^-20) then s~_a <= s~_b + 2 eps + 2^-20 (|x|^2 + E + 2 S_max) =: BAND (x 1.25 for margin).
+// Any code that can win or tie under the exact arithmetic lies within BAND of the approximate minimum.
+//
+// Roles are swapped against the exact kernel: codes are the MFMA's M dimension (LDS, staged by LDS-DMA), pixels the N dimension
+// (registers, straight from global in fragment shape), so that a lane owns ONE pixel per fragment and the minimum / band count over
+// its codes needs no cross-lane traffic (the two half-waves meet in one shuffle).
+// Workgroup: 4 waves = 2 (64 pixels) x 2 (128 codes); wave tile = 2 pixel fragments x 4 code tiles = 8 accumulators.
+// ------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int F_ROWS = 128, F_CODES = 256, F_SUB = 128;      // workgroup tile; codes per summary
+constexpr int F_BK = 32;                                    // channels per LDS stage (two MFMA K steps)
+constexpr int F_STAGE_BYTES = 2 * (F_BK / 8) * F_CODES * 16; // [hi | lo][4 slabs of 8 channels][256 codes][8 bf16] = 32 KiB
+
+__device__ __forceinline__ void glds16b(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base,
+                                     16, 0, 0);
+}
+
+// exclusive prefix sum of v over the 64 lanes; total = the wave's sum
+__device__ __forceinline__ int wave_excl_scan(int v, int& total) {
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if ((int)(threadIdx.x & 63) >= d) inc += o;
+    }
+    total = __shfl(inc, 63);
+    return inc - v;
+}
+
+struct FilterConsts {
+    float c_s, c_r;             // BAND = c_s * sqrt(|x|^2 * E) + c_r * (|x|^2 + E)   (per level: depends on C)
+};
+
+__global__ __launch_bounds__(256, 2) void vq_filter_bf16_kernel(const VqFilterGroup g, const FilterConsts fc0, const FilterConsts fc1,
+                                                                const FilterConsts fc2, const FilterConsts fc3) {
+    int lvl = 0;
+    while (lvl + 1 < g.n && blockIdx.x >= g.lv[lvl].wg_end) ++lvl;
+    const unsigned bid = blockIdx.x - (lvl ? g.lv[lvl - 1].wg_end : 0u);
+    const FilterConsts fc = lvl == 0 ? fc0 : (lvl == 1 ? fc1 : (lvl == 2 ? fc2 : fc3));
+    const unsigned short* __restrict__ x = static_cast<const unsigned short*>(g.lv[lvl].x);
+    const unsigned short* __restrict__ Eb = g.lv[lvl].Eb;
+    const long N = g.lv[lvl].N;
+    const int C = g.lv[lvl].C, Kp = g.lv[lvl].Kp;
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    char* Bs = fsm;                                             // [2 buffers][F_STAGE_BYTES]
+    float* en_s = reinterpret_cast<float*>(fsm + 2 * F_STAGE_BYTES);   // [F_CODES]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave & 1, wc = wave >> 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_stage = C / F_BK;
+    // workgroup id -> (row tile, code chunk): the chunks of a row tile sit 8 ids apart = same XCD, about the same time (see the exact kernel)
+    const int chunks = Kp / F_CODES;
+    const unsigned within = bid % (8u * chunks);
+    const long row_tile = (long)(bid / (8u * chunks)) * 8 + (within & 7u);
+    if (row_tile * F_ROWS >= N) return;
+    const int chunk = (int)(within >> 3);
+    const int code0 = chunk * F_CODES;
+
+    en_s[tid] = g.lv[lvl].enorm[code0 + tid];                   // 256 threads, 256 codes
+
+    const unsigned short* xrow[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        long row = row_tile * F_ROWS + wp * 64 + p * 32 + r;
+        if (row > N - 1) row = N - 1;
+        xrow[p] = x + row * (long)C + 8 * h;
+    }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[p][t][i] = 0.0f;
+    float xn_part[2] = {0.0f, 0.0f};
+
+    // stage fill: 32 wave-instructions of 1 KiB (64 codes x 16 B of one (hi|lo, slab)), 8 per wave
+    auto fill = [&](int stage, int buf) {
+        char* dst = Bs + buf * F_STAGE_BYTES;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int piece = wave * 8 + q;
+            const int hlslab = piece >> 2, quarter = piece & 3;
+            const int hl = hlslab >> 2, slab = hlslab & 3;
+            const unsigned short* src = Eb + (((size_t)hl * (C / 8) + (size_t)stage * 4 + slab) * Kp + code0 + quarter * 64 + lane) * 8;
+            glds16b(src, dst + (hlslab * F_CODES + quarter * 64) * 16);
+        }
+    };
+    auto load_x = [&](int stage, u32x4 (&xf)[2][2]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) xf[p][q] = *reinterpret_cast<const u32x4*>(xrow[p] + stage * F_BK + q * 16);
+    };
+
+    u32x4 xcur[2][2], xnxt[2][2];
+    fill(0, 0);
+    if (n_stage > 1) fill(1, 1);
+    load_x(0, xcur);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) xnxt[p][q] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    const char* a_lane = Bs + ((h * F_CODES) + wc * 128 + r) * 16;     // + buf * STAGE + ((hl * 4 + 2 q) * F_CODES + 32 t) * 16
+    for (int s = 0; s < n_stage; ++s) {
+        const char* abase = a_lane + (s & 1) * F_STAGE_BYTES;
+        if (s + 1 < n_stage) load_x(s + 1, xnxt);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bf16x8 ah[4], al[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                ah[t] = *reinterpret_cast<const bf16x8*>(abase + ((0 * 4 + 2 * q) * F_CODES + 32 * t) * 16);
+                al[t] = *reinterpret_cast<const bf16x8*>(abase + ((1 * 4 + 2 * q) * F_CODES + 32 * t) * 16);
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const bf16x8 xb = __builtin_bit_cast(bf16x8, xcur[p][q]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                     // |x|^2 of this lane's 8 channels (fp32; only the band needs it)
+                    const float lo = __builtin_bit_cast(float, xcur[p][q][e] << 16), hi = __builtin_bit_cast(float, xcur[p][q][e] & 0xFFFF0000u);
+                    xn_part[p] = __builtin_fmaf(lo, lo, xn_part[p]);
+                    xn_part[p] = __builtin_fmaf(hi, hi, xn_part[p]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], xb, acc[p][t], 0, 0, 0);
+                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], xb, acc[p][t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                        // stage s + 1 landed (issued a whole stage ago); buffer s & 1 is free
+        if (s + 2 < n_stage) fill(s + 2, s & 1);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) xcur[p][q] = xnxt[p][q];
+    }
+
+    // ---- epilogue: scores of this lane's 64 codes per pixel fragment, minimum, band count
+    const float en_max = *g.lv[lvl].en_max;
+    const int sub = chunk * 2 + wc, n_sub = Kp / F_SUB;
+    const float* en_l = en_s + wc * 128 + 4 * h;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        float m = __builtin_inff();
+        int bi = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 en4 = *reinterpret_cast<const f32x4*>(en_l + 32 * t + 8 * gq);    // codes 32 t + 8 gq + 4 h + (0..3): same address in a half-wave
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sc = __builtin_fmaf(-2.0f, acc[p][t][4 * gq + e], en4[e]);
+                    acc[p][t][4 * gq + e] = sc;
+                    const bool better = sc < m;                   // codes arrive in increasing index order: the first minimum is kept
+                    bi = better ? 32 * t + 8 * gq + e : bi;
+                    m = better ? sc : m;
+                }
+            }
+        bi += 4 * h;
+        {   // the other half-wave holds the other 64 codes of this pixel
+            const float mo = __shfl_xor(m, 32);
+            const int bo = __shfl_xor(bi, 32);
+            const bool take = mo < m || (mo == m && bo < bi);
+            m = take ? mo : m;
+            bi = take ? bo : bi;
+        }
+        const float xn = xn_part[p] + __shfl_xor(xn_part[p], 32);
+        const float band = __builtin_fmaf(fc.c_s, __builtin_sqrtf(xn * en_max), fc.c_r * (xn + en_max));
+        const float thr = m + band;
+        // which of this half-wave's 64 codes lie inside the band: bit 16 t + i of (lo, hi) <-> acc[p][t][i]
+        unsigned lo = 0u, hi = 0u;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lo |= acc[p][t][i] <= thr ? (1u << (16 * t + i)) : 0u;
+#pragma unroll
+        for (int t = 2; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hi |= acc[p][t][i] <= thr ? (1u << (16 * (t - 2) + i)) : 0u;
+        const int mine = __popc(lo) + __popc(hi);
+        const int cnt = mine + __shfl_xor(mine, 32);
+        const long row = row_tile * F_ROWS + wp * 64 + p * 32 + r;
+        const bool live = row < N;
+        if (h == 0 && live) {
+            const unsigned hiw = (unsigned)(code0 + wc * 128 + bi) | ((unsigned)(cnt > 0xffff ? 0xffff : cnt) << 16);
+            g.lv[lvl].summary[row * n_sub + sub] = ((unsigned long long)hiw << 32) | __float_as_uint(m);
+            if (sub == 0) g.lv[lvl].brow[row] = band;
+        }
+        // candidates beyond the best code -> the pair list (one reservation per wave; only lanes that have any walk their bits)
+        if ((bi & 4) == 4 * h) {                                  // the best code sits in this half-wave: clear its bit
+            const int bb = 16 * (bi >> 5) + 4 * ((bi >> 3) & 3) + (bi & 3);
+            if (bb < 32) lo &= ~(1u << bb);
+            else hi &= ~(1u << (bb - 32));
+        }
+        const int extra = live ? __popc(lo) + __popc(hi) : 0;
+        if (__any(extra > 0)) {                                   // wave-uniform
+            int total;
+            const int before = wave_excl_scan(extra, total);
+            const int list = blockIdx.x & (F_LISTS - 1), cap = g.lv[lvl].pair_cap;
+            int base = 0;
+            if (lane == 0) {
+                base = atomicAdd(g.lv[lvl].pair_count + list, total);
+                if (base + total > cap) g.lv[lvl].pair_count[F_LISTS] = 1;       // overflow: the gated exact launch serves the level
+            }
+            base = __shfl(base, 0);
+            if (extra > 0) {
+                int slot = base + before;
+                unsigned long long* out = g.lv[lvl].pair_rc + (size_t)list * cap;
+                unsigned long long bits = ((unsigned long long)hi << 32) | lo;
+                while (bits) {
+                    const int b = __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    const int cl = 32 * (b >> 4) + 8 * ((b >> 2) & 3) + 4 * h + (b & 3);
+                    if (slot < cap) out[slot] = ((unsigned long long)row << 32) | (unsigned)(code0 + wc * 128 + cl);
+                    ++slot;
+                }
+            }
+        }
+    }
+}
+
+// Stage 2 (all levels of the launch): per row the minimum over its sub-chunk summaries; exactly one code inside the band -> decided
+// (key written directly, the row's threshold word set to -inf: its listed candidates are skipped); otherwise the best code of every
+// surviving sub-chunk joins the pair list and brow keeps +inf-free "open" (the threshold itself).
+constexpr int F_MAX_SUB = 16;                               // sub-chunk summaries a row can have in registers (K <= 2048); more: re-read
+__global__ __launch_bounds__(256) void vq_resolve_kernel(const VqFilterGroup g, int force_all) {
+    int lvl = 0;
+    while (lvl + 1 < g.n && blockIdx.x >= g.lv[lvl].rblk_end) ++lvl;
+    const VqFilterLevel& L = g.lv[lvl];
+    const long N = L.N;
+    const int n_sub = L.Kp / F_SUB;
+    long row = (long)(blockIdx.x - (lvl ? g.lv[lvl - 1].rblk_end : 0u)) * 256 + threadIdx.x;
+    const bool valid = row < N;
+    if (!valid) row = N - 1;                                   // keep the wave whole for the scan below
+    const unsigned long long* sm = L.summary + row * n_sub;
+    unsigned long long v[F_MAX_SUB];
+#pragma unroll
+    for (int j = 0; j < F_MAX_SUB; j += 2)
+        if (j < n_sub) {                                        // n_sub is even (K % 256 == 0): 16-byte loads
+            const u32x4 w = *reinterpret_cast<const u32x4*>(sm + j);
+            v[j] = ((unsigned long long)w[1] << 32) | w[0];
+            v[j + 1] = ((unsigned long long)w[3] << 32) | w[2];
+        }
+    float m = __builtin_inff();
+    unsigned best = 0;
+#pragma unroll
+    for (int j = 0; j < F_MAX_SUB; ++j)
+        if (j < n_sub) {
+            const float mj = __uint_as_float((unsigned)(v[j] & 0xffffffffull));
+            const unsigned cj = (unsigned)(v[j] >> 32) & 0xffffu;
+            if (mj < m || (mj == m && cj < best)) m = mj, best = cj;
+        }
+    for (int j = F_MAX_SUB; j < n_sub; ++j) {                   // K > 2048
+        const float mj = __uint_as_float((unsigned)(sm[j] & 0xffffffffull));
+        const unsigned cj = (unsigned)(sm[j] >> 32) & 0xffffu;
+        if (mj < m || (mj == m && cj < best)) m = mj, best = cj;
+    }
+    const float thr = m + L.brow[row];
+    unsigned cnt = 0;
+    int alive = 0;
+#pragma unroll
+    for (int j = 0; j < F_MAX_SUB; ++j)
+        if (j < n_sub && __uint_as_float((unsigned)(v[j] & 0xffffffffull)) <= thr) cnt += (unsigned)(v[j] >> 48), ++alive;
+    for (int j = F_MAX_SUB; j < n_sub; ++j)
+        if (__uint_as_float((unsigned)(sm[j] & 0xffffffffull)) <= thr) cnt += (unsigned)(sm[j] >> 48), ++alive;
+    const bool open = valid && !(cnt == 1 && !force_all);
+    if (valid) {
+        if (!open) L.keys[row] = (unsigned long long)best;    // distance word 0: decided rows carry no exact distance (see vq_exact_dist_kernel)
+        L.brow[row] = open ? thr : -__builtin_inff();
+    }
+    if (!__any(open)) return;
+    int total;
+    const int before = wave_excl_scan(open ? alive : 0, total);
+    const int list = blockIdx.x & (F_LISTS - 1), cap = L.pair_cap;
+    int base = 0;
+    if ((threadIdx.x & 63) == 0) {
+        base = atomicAdd(L.pair_count + list, total);
+        if (base + total > cap) L.pair_count[F_LISTS] = 1;
+    }
+    base = __shfl(base, 0);
+    if (open) {
+        int slot = base + before;
+        unsigned long long* out = L.pair_rc + (size_t)list * cap;
+        for (int j = 0; j < n_sub; ++j) {
+            const unsigned long long vj = sm[j];
+            if (__uint_as_float((unsigned)(vj & 0xffffffffull)) <= thr) {
+                if (slot < cap) out[slot] = ((unsigned long long)row << 32) | ((unsigned)(vj >> 32) & 0xffffu);
+                ++slot;
+            }
+        }
+    }
+}
+
+// Stage 3 (all levels): the exact kernel's arithmetic for the listed (row, code) pairs of OPEN rows, one lane per pair: dot = the
+// "mfma8" fmaf chain, |x|^2 its two half chains, |e|^2 from the prepared blob, d = sqrt(max(fmaf(-2, dot, |x|^2) + |e|^2, 0)),
+// key = (bits(d) << 32) | code merged by atomicMin like the exact kernel's code groups (the lowest code wins a tie).
+struct RescoreTrip {                                        // 32 channels of one (row, code) pair
+    u32x4 xw[4];
+    f32x4 e0[4], e1[4];
+};
+
+template <bool ROWMAJOR>
+__device__ __forceinline__ void rescore_load(RescoreTrip& t, const unsigned short* xr, const float* er, int c, int Kp) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        t.xw[u] = *reinterpret_cast<const u32x4*>(xr + c + 8 * u);
+        if (ROWMAJOR) {
+            t.e0[u] = *reinterpret_cast<const f32x4*>(er + c + 8 * u);
+            t.e1[u] = *reinterpret_cast<const f32x4*>(er + c + 8 * u + 4);
+        } else {                                                // prepared image: 4-channel groups Kp * 16 bytes apart
+            t.e0[u] = *reinterpret_cast<const f32x4*>(er + (size_t)((c + 8 * u) / 4) * Kp * 4);
+            t.e1[u] = *reinterpret_cast<const f32x4*>(er + (size_t)((c + 8 * u) / 4 + 1) * Kp * 4);
+        }
+    }
+}
+
+__device__ __forceinline__ void rescore_fma(const RescoreTrip& t, float& dot, float& xa, float& xb) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float xv[8] = {__builtin_bit_cast(float, t.xw[u][0] << 16), __builtin_bit_cast(float, t.xw[u][0] & 0xFFFF0000u),
+                             __builtin_bit_cast(float, t.xw[u][1] << 16), __builtin_bit_cast(float, t.xw[u][1] & 0xFFFF0000u),
+                             __builtin_bit_cast(float, t.xw[u][2] << 16), __builtin_bit_cast(float, t.xw[u][2] & 0xFFFF0000u),
+                             __builtin_bit_cast(float, t.xw[u][3] << 16), __builtin_bit_cast(float, t.xw[u][3] & 0xFFFF0000u)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dot = __builtin_fmaf(xv[e], t.e0[u][e], dot);
+            dot = __builtin_fmaf(xv[4 + e], t.e1[u][e], dot);
+            xa = __builtin_fmaf(xv[e], xv[e], xa);
+            xb = __builtin_fmaf(xv[4 + e], xv[4 + e], xb);
+        }
+    }
+}
+
+// one sub-list of one level: lane i takes pairs i, i + nthreads, ...; a chain is serial (C dependent fmaf's), so its loads run two
+// 32-channel trips ahead of the arithmetic
+template <bool ROWMAJOR>
+__device__ __forceinline__ void rescore_pairs(const VqFilterLevel& L, int list, int tid, int nthreads) {
+    int n = L.pair_count[list];
+    if (n > L.pair_cap) n = L.pair_cap;                        // overflow: the gated exact launch serves the level anyway
+    const int C = L.C, Kp = L.Kp;
+    const unsigned short* __restrict__ x = static_cast<const unsigned short*>(L.x);
+    const unsigned long long* pairs = L.pair_rc + (size_t)list * L.pair_cap;
+    for (int i = tid; i < n; i += nthreads) {
+        const unsigned long long rc = pairs[i];
+        const long row = (long)(rc >> 32);
+        const unsigned k = (unsigned)(rc & 0xffffffffull);
+        if (L.brow[row] == -__builtin_inff()) continue;         // a decided row
+        const unsigned short* xr = x + row * (long)C;
+        const float* er = ROWMAJOR ? L.W + (size_t)k * C : L.E4 + (size_t)k * 4;
+        float dot = 0.0f, xa = 0.0f, xb = 0.0f;
+        RescoreTrip t0, t1, t2;                                  // C % 32 == 0 on this path
+        rescore_load<ROWMAJOR>(t0, xr, er, 0, Kp);
+        if (C > 32) rescore_load<ROWMAJOR>(t1, xr, er, 32, Kp);
+        int c = 0;
+        for (; c + 96 <= C; c += 96) {
+            if (c + 64 < C) rescore_load<ROWMAJOR>(t2, xr, er, c + 64, Kp);
+            rescore_fma(t0, dot, xa, xb);
+            if (c + 96 < C) rescore_load<ROWMAJOR>(t0, xr, er, c + 96, Kp);
+            rescore_fma(t1, dot, xa, xb);
+            if (c + 128 < C) rescore_load<ROWMAJOR>(t1, xr, er, c + 128, Kp);
+            rescore_fma(t2, dot, xa, xb);
+        }
+        if (c < C) {                                            // one or two trips left (already loaded into t0 / t1)
+            rescore_fma(t0, dot, xa, xb);
+            if (c + 32 < C) rescore_fma(t1, dot, xa, xb);
+        }
+        float d2 = __builtin_fmaf(-2.0f, dot, xa + xb) + L.enorm[k];
+        d2 = __builtin_fmaxf(d2, 0.0f);
+        atomicMin(L.keys + row, ((unsigned long long)__float_as_uint(__builtin_sqrtf(d2)) << 32) | k);
+    }
+}
+
+// Stage 3 launch: every level gets its own workgroups (a multiple of F_LISTS), workgroup b of a level serves sub-list b % F_LISTS
+__global__ __launch_bounds__(256) void vq_rescore_kernel(const VqFilterGroup g) {
+    int lvl = 0;
+    while (lvl + 1 < g.n && blockIdx.x >= g.lv[lvl].sblk_end) ++lvl;
+    const unsigned first = lvl ? g.lv[lvl - 1].sblk_end : 0u;
+    const unsigned b = blockIdx.x - first, per_list = (g.lv[lvl].sblk_end - first) / F_LISTS;
+    const int list = (int)(b % F_LISTS), tid = (int)(b / F_LISTS) * 256 + threadIdx.x, nthreads = (int)per_list * 256;
+    if (g.lv[lvl].W) rescore_pairs<true>(g.lv[lvl], list, tid, nthreads);
+    else rescore_pairs<false>(g.lv[lvl], list, tid, nthreads);
+}
+
+// The exact kernel's distance of ONE given code per row on the vector ALU (tests ask for the winning distance; rows the filter
+// decided never went through the exact kernel): the same fmaf chains in the same order (file header, "mfma8").
+__global__ __launch_bounds__(256) void vq_exact_dist_kernel(const unsigned short* __restrict__ x, const float* __restrict__ E4, int Kp,
+                                                            const float* __restrict__ enorm, const long long* __restrict__ idx, long N, int C,
+                                                            float* __restrict__ dmin) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= N) return;
+    const unsigned short* xr = x + row * (long)C;
+    const long long k = idx[row];
+    float dot = 0.0f, xa = 0.0f, xb = 0.0f;
+    for (int c = 0; c + 8 <= C; c += 8) {
+        float xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = __builtin_bit_cast(float, (unsigned)xr[c + e] << 16);
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(E4 + ((size_t)(c / 4) * Kp + k) * 4);          // channels c .. c + 3 of code k
+        const f32x4 e1 = *reinterpret_cast<const f32x4*>(E4 + ((size_t)(c / 4 + 1) * Kp + k) * 4);      // channels c + 4 .. c + 7
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dot = __builtin_fmaf(xv[e], e0[e], dot);
+            dot = __builtin_fmaf(xv[4 + e], e1[e], dot);
+            xa = __builtin_fmaf(xv[e], xv[e], xa);
+            xb = __builtin_fmaf(xv[4 + e], xv[4 + e], xb);
+        }
+    }
+    float d2 = __builtin_fmaf(-2.0f, dot, xa + xb) + enorm[k];
+    d2 = __builtin_fmaxf(d2, 0.0f);
+    dmin[row] = __builtin_sqrtf(d2);
 }
 
 // keys -> int64 code indices (+ the winning distance), and the code histogram of the dead-code statistic (vq_img.py:173-175):
@@ -774,16 +1261,47 @@ __global__ __launch_bounds__(256) void ema_embed_kernel(float* __restrict__ embe
 // ------------------------------------------------------------------------------------
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-size_t prepared_bytes(int C, int K) {
+static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// the candidate filter serves bf16 rows of layers with whole 256-code chunks and 32-channel stages
+static bool filter_shape_ok(int C, int K) { return K % 256 == 0 && C % 32 == 0 && K <= 65536; }
+
+PreparedLayout prepared_layout(int C, int K) {
     const int Kp = round_up(K, 32);
-    return (((size_t)C * Kp + Kp) * sizeof(float) + 255) & ~(size_t)255;
+    PreparedLayout l;
+    l.off_e4 = 0;
+    l.off_enorm = (size_t)C * Kp * sizeof(float);               // (kept adjacent to E4: the exact kernel's blob of rounds 1-3)
+    l.off_enmax = up256(l.off_enorm + (size_t)Kp * sizeof(float));
+    l.off_eb = l.off_enmax + 256;
+    l.bytes = filter_shape_ok(C, K) ? up256(l.off_eb + (size_t)2 * C * Kp * sizeof(unsigned short)) : l.off_eb;
+    return l;
 }
 
+size_t prepared_bytes(int C, int K) { return prepared_layout(C, K).bytes; }
+
 static int g_vq_max_tiles = 8;                              // cap on T (option "vq_max_tiles_per_wave": 8, 4, 2 or 1)
+static int g_vq_bf16_filter = 1;                            // bf16 rows: candidate filter + exact re-score (0: the exact kernel on every row)
+static int g_vq_filter_force_all = 0;                       // tests: 1 = every row is re-scored by the exact kernel (the filter decides nothing)
+static int g_vq_filter_launches = 0;                        // launches that took the filter path (tests read and reset it)
 int vq_set_option(const char* key, int value) {
     if (key && !strcmp(key, "vq_max_tiles_per_wave") && (value == 8 || value == 4 || value == 2 || value == 1)) {
         const int prev = g_vq_max_tiles;
         g_vq_max_tiles = value;
+        return prev;
+    }
+    if (key && !strcmp(key, "vq_bf16_filter")) {
+        const int prev = g_vq_bf16_filter;
+        g_vq_bf16_filter = value ? 1 : 0;
+        return prev;
+    }
+    if (key && !strcmp(key, "vq_filter_force_all")) {
+        const int prev = g_vq_filter_force_all;
+        g_vq_filter_force_all = value ? 1 : 0;
+        return prev;
+    }
+    if (key && !strcmp(key, "vq_filter_launches")) {
+        const int prev = g_vq_filter_launches;
+        g_vq_filter_launches = value;
         return prev;
     }
     return -1;
@@ -802,6 +1320,22 @@ VqPlan vq_plan(int64_t N, int C, int K) {
     off += ((size_t)p.Kp * sizeof(int) + 255) & ~(size_t)255;
     p.off_partial = off;
     off += (size_t)GATHER_BLOCKS_MAX * sizeof(float);
+    off = up256(off);
+    p.off_summary = p.off_brow = p.off_amb = p.off_pair_rc = off;
+    p.pair_cap = 0;
+    if (filter_shape_ok(C, K)) {
+        p.off_summary = off;
+        off += up256((size_t)N * (p.Kp / F_SUB) * sizeof(unsigned long long));
+        p.off_brow = off;
+        off += up256((size_t)N * sizeof(float));
+        p.off_amb = off;                                        // the pair sub-lists' counters [F_LISTS] + the overflow flag
+        off += 512;
+        const long total_cap = 4 * N < (1L << 30) ? 4 * N : (1L << 30);
+        p.pair_cap = (int)((total_cap + F_LISTS - 1) / F_LISTS);     // per sub-list: four candidates per row on average
+        if (p.pair_cap < 1024) p.pair_cap = 1024;
+        p.off_pair_rc = off;
+        off += up256((size_t)p.pair_cap * F_LISTS * sizeof(unsigned long long));
+    }
     p.bytes = (off + 255) & ~(size_t)255;
     long blocks = (N + GATHER_ROWS_PER_BLOCK - 1) / GATHER_ROWS_PER_BLOCK;
     p.gather_blocks = (int)(blocks < GATHER_BLOCKS_MAX ? (blocks > 0 ? blocks : 1) : GATHER_BLOCKS_MAX);
@@ -822,13 +1356,22 @@ VqPlan vq_plan(int64_t N, int C, int K) {
 
 hipError_t launch_prepare(const float* W, int K, int C, void* prepared, hipStream_t st) {
     const int Kp = round_up(K, 32);
-    float* E4 = reinterpret_cast<float*>(prepared);
-    float* en = E4 + (size_t)C * Kp;
+    const PreparedLayout pl = prepared_layout(C, K);
+    char* base = reinterpret_cast<char*>(prepared);
+    float* E4 = reinterpret_cast<float*>(base + pl.off_e4);
+    float* en = reinterpret_cast<float*>(base + pl.off_enorm);
     long total = (long)(C / 4) * Kp;
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(vq_pack_codebook, dim3((unsigned)blocks), dim3(256), 0, st, W, K, C, E4, Kp, C);
     hipLaunchKernelGGL(vq_code_norms, dim3((Kp + 63) / 64), dim3(64), 0, st, W, K, C, Kp, en);
+    if (filter_shape_ok(C, K)) {                              // the candidate filter's image of the same codebook
+        long b2 = ((long)(C / 8) * Kp + 255) / 256;
+        if (b2 > 4096) b2 = 4096;
+        hipLaunchKernelGGL(vq_pack_codebook_bf16, dim3((unsigned)b2), dim3(256), 0, st, W, K, C, Kp,
+                           reinterpret_cast<unsigned short*>(base + pl.off_eb));
+        hipLaunchKernelGGL(vq_enorm_max, dim3(1), dim3(256), 0, st, en, K, reinterpret_cast<float*>(base + pl.off_enmax));
+    }
     return hipGetLastError();
 }
 
@@ -856,7 +1399,7 @@ void profile_release() {
     g_prof.capacity = 0;
 }
 
-int profile_collect(int max_records, int64_t* n, int* c, int* k, float* ms) {
+int profile_collect(int max_records, int64_t* n, int* c, int* k, float* ms, int* kind) {
     g_prof.enabled = false;
     const int cnt = (int)g_prof.shape.size();
     int out = 0;
@@ -871,6 +1414,7 @@ int profile_collect(int max_records, int64_t* n, int* c, int* k, float* ms) {
         c[out] = sh.c;
         k[out] = sh.k;
         ms[out] = (float)(t * (all > 0 ? mine / all : 1.0));
+        if (kind) kind[out] = sh.kind;
         ++out;
     }
     profile_release();
@@ -913,34 +1457,81 @@ int vq_group_tiles(int n, const int64_t* N, const int* K) {
 // the distance + argmin pass of n <= VQ_MAX_LEVELS levels in ONE launch (keys pre-set, unpack per level afterwards)
 hipError_t launch_assign_group(int n, const void* const* x, int x_bf16, const int64_t* N, const int* C, const int* K,
                                const void* const* prepared, const VqPlan* plans, char* const* ws, int64_t* const* idx,
-                               float* const* dmin, int T, hipStream_t st) {
+                               float* const* dmin, int T, hipStream_t st, const float* const* codebooks) {
     if (n < 1 || n > VQ_MAX_LEVELS) return hipErrorInvalidValue;
     int order[VQ_MAX_LEVELS];
     for (int i = 0; i < n; ++i) order[i] = i;
     for (int i = 0; i < n; ++i)                                  // longest workgroups (most channels) first
         for (int j = i + 1; j < n; ++j)
             if (C[order[j]] > C[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    // bf16 rows of layers with whole 256-code chunks take the candidate filter: bf16 MFMA scores -> per-row decision -> the exact
+    // kernel (indirect mode) on the rows the filter left open.  Same keys as the exact kernel on every row.
+    bool filter = x_bf16 && g_vq_bf16_filter;
+    for (int i = 0; i < n; ++i) filter = filter && filter_shape_ok(C[i], K[i]);
     VqGroup g;
-    g.n = n;
+    VqFilterGroup fg;
+    FilterConsts fc[VQ_MAX_LEVELS] = {};
+    g.n = fg.n = n;
 #if VQ_TIMELINE
     g.tl = g_timeline;
 #endif
-    unsigned end = 0;
+    unsigned end = 0, fend = 0, rend = 0, send = 0;
     for (int q = 0; q < n; ++q) {
         const int i = order[q];
-        const float* E4 = reinterpret_cast<const float*>(prepared[i]);
+        const PreparedLayout pl = prepared_layout(C[i], K[i]);
+        const char* pb = reinterpret_cast<const char*>(prepared[i]);
+        const float* E4 = reinterpret_cast<const float*>(pb + pl.off_e4);
+        const float* enorm = reinterpret_cast<const float*>(pb + pl.off_enorm);
         unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws[i] + plans[i].off_keys);
         hipError_t e = hipMemsetAsync(keys, 0xff, (size_t)N[i] * sizeof(unsigned long long), st);
         if (e != hipSuccess) return e;
         end += assign_workgroups(N[i], plans[i].Kp, T);
-        g.lv[q] = VqLevel{x[i], E4, E4 + (size_t)C[i] * plans[i].Kp, keys, (long)N[i], C[i], plans[i].Kp, end};
+        g.lv[q] = VqLevel{x[i], E4, enorm, keys, (long)N[i], C[i], plans[i].Kp, end};
+        if (filter) {
+            int* amb = reinterpret_cast<int*>(ws[i] + plans[i].off_amb);
+            e = hipMemsetAsync(amb, 0, 512, st);                  // the sub-lists' counters and the overflow flag
+            if (e != hipSuccess) return e;
+            // a pair list that overflows (more than four candidates per row on average: degenerate codebooks) switches the level to the
+            // exact kernel on every row -- the gated launch below
+            g.lv[q].gate = amb + F_LISTS;                         // the overflow flag
+            g.lv[q].gate_cap = 0;
+            const long row_tiles = (N[i] + F_ROWS - 1) / F_ROWS;
+            fend += (unsigned)((row_tiles + 7) / 8 * 8 * (plans[i].Kp / F_CODES));
+            rend += (unsigned)((N[i] + 255) / 256);
+            {   // stage 3: a thread per expected pair (about one per row at most), whole multiples of F_LISTS workgroups, 4 .. 16 per sub-list
+                long per = (N[i] / 256 + F_LISTS - 1) / F_LISTS;
+                if (per < 4) per = 4;
+                if (per > 16) per = 16;
+                send += (unsigned)(per * F_LISTS);
+            }
+            fg.lv[q] = VqFilterLevel{x[i], reinterpret_cast<const unsigned short*>(pb + pl.off_eb), enorm,
+                                     reinterpret_cast<const float*>(pb + pl.off_enmax),
+                                     reinterpret_cast<unsigned long long*>(ws[i] + plans[i].off_summary),
+                                     reinterpret_cast<float*>(ws[i] + plans[i].off_brow),
+                                     reinterpret_cast<unsigned long long*>(ws[i] + plans[i].off_pair_rc), amb, plans[i].pair_cap, keys,
+                                     codebooks ? codebooks[i] : nullptr, E4, (long)N[i], C[i], plans[i].Kp, fend, rend, send};
+            // BAND = 1.25 * [ 2 eps + 2^-20 (|x|^2 + E + 2 S) ],  eps = 2 (C 2^-24 + 2^-18 + (C / 8) 17 2^-24) S + 2^-22 (|x|^2 + E + 2 S),
+            // S = sqrt(|x|^2 E)   (derivation at vq_filter_bf16_kernel)
+            const double u = ldexp(1.0, -24), cc = (double)C[i];
+            const double per_s = 2.0 * (cc * u + ldexp(1.0, -18) + (cc / 8.0) * 17.0 * u);
+            const double tail = 2.0 * ldexp(1.0, -22) + ldexp(1.0, -20);
+            fc[q].c_s = (float)(1.25 * (2.0 * per_s + 2.0 * tail));
+            fc[q].c_r = (float)(1.25 * tail);
+        }
     }
     const bool rec = g_prof.enabled && (int)g_prof.shape.size() + n <= g_prof.capacity;
     const size_t slot = g_prof.shape.size();
     if (rec) {
         // one event pair for the launch; its time is apportioned to the levels by their flops (2 N K C) when collected
-        for (int i = 0; i < n; ++i) g_prof.shape.push_back({N[i], C[i], K[i], (int)slot, n});
+        for (int i = 0; i < n; ++i) g_prof.shape.push_back({N[i], C[i], K[i], (int)slot, n, filter ? 2 : (x_bf16 ? 1 : 0)});
         (void)hipEventRecord(g_prof.ev[2 * slot], st);
+    }
+    if (filter) {
+        ++g_vq_filter_launches;
+        hipLaunchKernelGGL(vq_filter_bf16_kernel, dim3(fend), dim3(256), (size_t)(2 * F_STAGE_BYTES + F_CODES * sizeof(float)), st, fg, fc[0],
+                           fc[1], fc[2], fc[3]);
+        hipLaunchKernelGGL(vq_resolve_kernel, dim3(rend), dim3(256), 0, st, fg, g_vq_filter_force_all);
+        hipLaunchKernelGGL(vq_rescore_kernel, dim3(send), dim3(256), 0, st, fg);
     }
 #define VQ_ASSIGN(T_)                                                 \
     if (x_bf16) launch_assign_t<T_, __bf16>(g, st);                   \
@@ -967,13 +1558,21 @@ hipError_t launch_assign_group(int n, const void* const* x, int x_bf16, const in
         hipLaunchKernelGGL(vq_unpack_keys, dim3((unsigned)blocks), dim3(256), lds_hist ? (size_t)K[i] * sizeof(int) : 0, st,
                            reinterpret_cast<unsigned long long*>(ws[i] + plans[i].off_keys), (long)N[i],
                            reinterpret_cast<long long*>(idx[i]), dmin ? dmin[i] : nullptr, hist, K[i], lds_hist);
+        if (filter && dmin && dmin[i]) {
+            // rows the filter decided carry no exact distance: recompute the winner's on the vector ALU, in the exact kernel's order
+            const PreparedLayout pl = prepared_layout(C[i], K[i]);
+            const char* pb = reinterpret_cast<const char*>(prepared[i]);
+            hipLaunchKernelGGL(vq_exact_dist_kernel, dim3((unsigned)((N[i] + 255) / 256)), dim3(256), 0, st, static_cast<const unsigned short*>(x[i]),
+                               reinterpret_cast<const float*>(pb + pl.off_e4), plans[i].Kp, reinterpret_cast<const float*>(pb + pl.off_enorm),
+                               reinterpret_cast<const long long*>(idx[i]), (long)N[i], C[i], dmin[i]);
+        }
     }
     return hipGetLastError();
 }
 
 hipError_t launch_assign(const void* x, int x_bf16, int64_t N, int C, int K, const void* prepared, const VqPlan& p, char* ws,
-                         int64_t* idx, float* dmin, hipStream_t st) {
-    return launch_assign_group(1, &x, x_bf16, &N, &C, &K, &prepared, &p, &ws, &idx, &dmin, p.T, st);
+                         int64_t* idx, float* dmin, hipStream_t st, const float* codebook) {
+    return launch_assign_group(1, &x, x_bf16, &N, &C, &K, &prepared, &p, &ws, &idx, &dmin, p.T, st, codebook ? &codebook : nullptr);
 }
 
 hipError_t launch_gather(const void* x, int bf16, const float* W, const int64_t* idx, int64_t N, int C, int K, int training,

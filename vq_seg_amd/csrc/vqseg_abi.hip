@@ -59,15 +59,21 @@ int vqseg_profile_begin(int capacity) {
     return 0;
 }
 
-int vqseg_profile_collect(int max_records, int64_t* n_rows_host, int* channels_host, int* n_codes_host, float* ms_host) {
+int vqseg_profile_collect(int max_records, int64_t* n_rows_host, int* channels_host, int* n_codes_host, float* ms_host, int* kind_host) {
     if (max_records <= 0 || !n_rows_host || !channels_host || !n_codes_host || !ms_host)
         return fail(VQSEG_EINVAL, "bad argument");
-    return vqseg::profile_collect(max_records, n_rows_host, channels_host, n_codes_host, ms_host);
+    return vqseg::profile_collect(max_records, n_rows_host, channels_host, n_codes_host, ms_host, kind_host);
 }
 
 size_t vqseg_vq_workspace_bytes(int64_t n, int c, int k) {
     if (n <= 0 || c <= 0 || k <= 0) return 0;
     return vqseg::vq_plan(n, c, k).bytes;
+}
+
+size_t vqseg_vq_filter_counter_offset(int64_t n, int c, int k) {
+    if (n <= 0 || c <= 0 || k <= 0) return 0;
+    const vqseg::VqPlan p = vqseg::vq_plan(n, c, k);
+    return p.off_amb == p.off_summary ? 0 : p.off_amb;          // 0: the shape does not take the candidate filter
 }
 
 size_t vqseg_vq_prepared_bytes(int c, int k) {
@@ -101,7 +107,7 @@ static int vq_assign_any(const void* x, int x_bf16, const float* codebook, const
         if (e != hipSuccess) return hip_fail(e, "vq codebook prepare");
         prepared = w + p.off_prepared;
     }
-    hipError_t e = vqseg::launch_assign(x, x_bf16, n, c, k, prepared, p, w, idx, dmin, st);
+    hipError_t e = vqseg::launch_assign(x, x_bf16, n, c, k, prepared, p, w, idx, dmin, st, codebook);
     if (e != hipSuccess) return hip_fail(e, "vq_assign_f32_kernel");
     return 0;
 }
@@ -171,7 +177,7 @@ int vqseg_vq_forward_group(int n_levels, int bf16, const void* const* x, const f
         }
     }
     const int T = vqseg::vq_group_tiles(n_levels, n, k);
-    hipError_t e = vqseg::launch_assign_group(n_levels, x, bf16, n, c, k, prep, plans, wsp, idx, nullptr, T, st);
+    hipError_t e = vqseg::launch_assign_group(n_levels, x, bf16, n, c, k, prep, plans, wsp, idx, nullptr, T, st, codebook);
     if (e != hipSuccess) return hip_fail(e, "vq_assign_f32_kernel (grouped)");
     for (int i = 0; i < n_levels; ++i) {
         e = vqseg::launch_gather(x[i], bf16, codebook[i], idx[i], n[i], c[i], k[i], training, cw[i], plans[i], wsp[i], quant[i], loss[i],
