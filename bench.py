@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: train images/sec @512x512 vqreptunet1x1 K=512 (BASELINE.json `metric`).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload cfg2|cfg3|cfg4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -41,17 +41,31 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
-SIZE, K_CODES = 512, 512
+SIZE, K_CODES = 512, 512           # the metric's configuration (BASELINE.json `metric`; configs[2], "cfg3")
+
+# BASELINE.json `configs` that fit one GPU.  The driver's default run is cfg3 (the configuration the metric is quoted on); cfg2 / cfg4
+# are run by hand (profiles/r04_bench_cfg{2,4}.json).  "bs = 64 / GPU" of configs[4] is taken as 64 input images per GPU and step =
+# 32 labelled + 32 unlabelled (the reference's `batch_size` is per loader, config/vqreptunet1x1.json:34, i.e. 64 would mean 64 + 64:
+# `--batch 64` runs that reading).
+WORKLOADS = {
+    "cfg2": dict(model="vqreptunet1x1", recipe="v1", size=512, k=256, batch=32, margin=0.0, scale=1.0,
+                 what="BASELINE configs[1]: vqreptunet1x1 CWFID 512x512, codebook K = 256, bf16"),
+    "cfg3": dict(model="vqreptunet1x1", recipe="v1", size=512, k=512, batch=32, margin=0.0, scale=1.0,
+                 what="BASELINE configs[2] (the metric's configuration): vqreptunet1x1 512x512, K = 512"),
+    "cfg4": dict(model="vqreptunet1x1v2", recipe="v2", size=1024, k=1024, batch=8, margin=0.5, scale=30.0,
+                 what="BASELINE configs[3]: vqreptunet1x1v2 rice_s_n_w 1024x1024, K = 1024, bf16 (v2 recipe: score-mask CPS, CE + Dice)"),
+}
 
 
-def model_cfg():
-    return {"name": "vqreptunet1x1", "params": {
+def model_cfg(workload: str = "cfg3"):
+    w = WORKLOADS[workload]
+    return {"name": w["model"], "params": {
         "encoder_name": "resnet50", "num_classes": 3, "depth": 5,
-        "vq_cfg": {"num_embeddings": [0, 0, K_CODES, K_CODES, K_CODES], "distance": "euclidean", "kmeans_init": True},
-        "margin": 0.0, "scale": 1.0, "use_feature": False, "encoder_weights": None}}
+        "vq_cfg": {"num_embeddings": [0, 0, w["k"], w["k"], w["k"]], "distance": "euclidean", "kmeans_init": True},
+        "margin": w["margin"], "scale": w["scale"], "use_feature": False, "encoder_weights": None}}
 
 
-def cpu_baseline():
+def cpu_baseline(size: int = SIZE, k_codes: int = K_CODES):
     """The CPU oracle's CPS iteration itself (oracle/cps_ref.py::CPSReference.step: 2 eval forwards, 4 training forwards, one backward
     through both networks, 2 Adam steps, the loss / pseudo-label block -- the reference trainer's loop body restated on torch CPU ops,
     pinned to the reference by tests/golden/cps_iter_v1.npz) on a BOUNDED sample of the same workload: 1 labelled + 1 unlabelled
@@ -63,10 +77,10 @@ def cpu_baseline():
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
     lay = golden_io.layout("vqreptunet1x1")
-    ref = cps_ref.CPSReference([synth.synth_state_dict(lay, 77), synth.synth_state_dict(lay, 78)], num_embeddings=(0, 0, K_CODES, K_CODES, K_CODES))
+    ref = cps_ref.CPSReference([synth.synth_state_dict(lay, 77), synth.synth_state_dict(lay, 78)], num_embeddings=(0, 0, k_codes, k_codes, k_codes))
     NB, REPS = 1, 3
-    l_in, l_tg = synth.blob_images(1, NB, SIZE, cell=32)
-    ul_in, _ = synth.blob_images(2, NB, SIZE, cell=32)
+    l_in, l_tg = synth.blob_images(1, NB, size, cell=32)
+    ul_in, _ = synth.blob_images(2, NB, size, cell=32)
     ref.step(l_in, l_tg, ul_in)                         # warm-up (thread pool, primitive caches)
     times = []
     for _ in range(REPS):
@@ -76,8 +90,8 @@ def cpu_baseline():
         print(f"[bench] cpu baseline: CPS iteration on {NB}+{NB} images {times[-1]:.2f}s (loss {out['loss']:.4f})", file=sys.stderr, flush=True)
     dt = sum(times) / len(times)
     return {"value": round(2.0 * NB / dt, 5), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle/cps_ref.py::CPSReference.step (the whole CPS iteration, v1 recipe, K = {K_CODES}) on {NB} labelled + {NB} unlabelled "
-                      f"image of {SIZE}x{SIZE}, fp32, {cores} threads: mean of {REPS} iterations after a warm-up = {dt:.2f}s per {2 * NB} images"}
+            "sample": f"oracle/cps_ref.py::CPSReference.step (the whole CPS iteration, v1 recipe, K = {k_codes}) on {NB} labelled + {NB} unlabelled "
+                      f"image of {size}x{size}, fp32, {cores} threads: mean of {REPS} iterations after a warm-up = {dt:.2f}s per {2 * NB} images"}
 
 
 def bn_roofline(device):
@@ -98,7 +112,9 @@ def bn_roofline(device):
         outs = [torch.empty_like(t) for t in ys]
         mean, inv, gamma = torch.zeros(C, device=device), torch.ones(C, device=device), torch.ones(C, device=device)
         ws = torch.empty(L.vqseg_bn_backward_workspace_floats(M, C), device=device)
-        sync = torch.zeros(L.vqseg_bn_sync_ints(C), dtype=torch.int32, device=device)
+        # the step's default is the two-launch backward (sync = NULL); the one-launch form only when VQSEG_OPTS=py_bn_fused=1 selects it
+        from vq_seg_amd import nnf as _nnf
+        sync = torch.zeros(L.vqseg_bn_sync_ints(C), dtype=torch.int32, device=device) if _nnf.py_opt("py_bn_fused", 0) else None
         dg, gy = torch.empty(2, C, device=device), torch.empty_like(ys[0])
         gres = torch.empty_like(ys[0]) if res else None
 
@@ -111,7 +127,7 @@ def bn_roofline(device):
             k = i % sets
             rc = L.vqseg_bn_backward_f(1, gs[k].data_ptr(), outs[k].data_ptr() if res else None, ys[k].data_ptr(), mean.data_ptr(), inv.data_ptr(),
                                        gamma.data_ptr(), sc.data_ptr(), sh.data_ptr(), M, C, 1, 1, 0, ws.data_ptr(), dg[0].data_ptr(), dg[1].data_ptr(),
-                                       gy.data_ptr(), gres.data_ptr() if res else None, sync.data_ptr(), st)
+                                       gy.data_ptr(), gres.data_ptr() if res else None, sync.data_ptr() if sync is not None else None, st)
             assert rc == 0, L.vqseg_last_error()
         for name, fn, nbytes in (("apply", apply, M * C * 2 * (3 if res else 2)), ("backward", bwd, M * C * 2 * (8 if res else 5))):
             fn(0)
@@ -183,6 +199,41 @@ def vq_per_level(device, group, bf16_rows=True, reps=10):
     return out
 
 
+def measured_vq_clock(device, group):
+    """The shader clock INSIDE the distance + argmin kernel, measured in this run: one grouped launch of the
+    timeline build of the same kernel (libvqseg_hip_tl.so: -DVQ_TIMELINE=1, s_memtime / s_memrealtime stamps of wave 0 of every
+    workgroup) on fp32 rows of the step's shapes, right after the timed region.  -> dict or None (library not built)."""
+    import ctypes
+    import numpy as np
+    from vq_seg_amd import _hip
+    path = os.path.join(ROOT, "vq_seg_amd", "libvqseg_hip_tl.so")
+    if not os.path.exists(path) or not group:
+        return None
+    H = _hip.bind(path)
+    H.vqseg_debug_timeline.argtypes = [ctypes.c_void_p]
+    rows = [torch.relu(torch.randn(n, c, device=device)) for n, c, k in group]
+    books = [torch.relu(torch.randn(k, c, device=device)) for n, c, k in group]
+    preps = [_hip.vq_prepare(w) for w in books]
+    n_wg = sum(((n + 127) // 128 + 7) // 8 * 8 * ((k + 31) // 32) for n, c, k in group)       # upper bound (one 32-code tile per workgroup)
+    for _ in range(2):
+        _hip.vq_forward_group(rows, books, preps, False, [1.0] * len(group), handle=H)
+    torch.cuda.synchronize()
+    tl = torch.zeros(n_wg, 16, dtype=torch.int64, device=device)
+    H.vqseg_debug_timeline(tl.data_ptr())
+    _hip.vq_forward_group(rows, books, preps, False, [1.0] * len(group), handle=H)
+    torch.cuda.synchronize()
+    H.vqseg_debug_timeline(None)
+    t = tl.cpu().numpy().astype(np.int64)
+    t = t[t[:, 0] != 0]
+    if len(t) == 0:
+        return None
+    us = (t[:, 10] - t[:, 0]).astype(np.float64) * 0.01                  # s_memrealtime: 100 MHz
+    ck = (t[:, 11] - t[:, 1]).astype(np.float64)
+    mhz = ck[us > 0] / us[us > 0]
+    return {"clock_mhz": round(float(np.median(mhz)), 1), "p5": round(float(np.percentile(mhz, 5)), 1), "p95": round(float(np.percentile(mhz, 95)), 1),
+            "workgroups": int(len(mhz))}
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: become the launcher.  Starts N fresh children of this same
     script, one per GPU, with the rendezvous variables torch.distributed.run would set; rank 0's stdout (the one JSON line) is this
@@ -193,12 +244,20 @@ def launch_ranks(n: int) -> int:
     import subprocess
     rehearsal = os.environ.get("VQSEG_DIST_REHEARSAL") == "1"
     if not rehearsal:
-        have = torch.cuda.device_count()                       # device_count() does not create a HIP context
+        # the launcher never asks the HIP runtime anything: the GPUs are counted from the KFD topology (sysfs); a node that shows
+        # fewer is reported here, anything else by the ranks themselves
+        have = 0
+        try:
+            for node in os.listdir("/sys/class/kfd/kfd/topology/nodes"):
+                with open(f"/sys/class/kfd/kfd/topology/nodes/{node}/properties") as f:
+                    have += any(line.startswith("simd_count") and int(line.split()[1]) > 0 for line in f)
+        except OSError:
+            have = n                                           # no sysfs view: let the ranks find out
         if have < n:
             print(f"bench.py: --gpus {n} but this node shows {have} GPU(s); set VQSEG_DIST_REHEARSAL=1 for the one-GPU gloo rehearsal "
                   f"of the N > 1 path", file=sys.stderr)
             return 2
-    with socket.socket() as s:
+    with socket.socket() as s:                                 # (a port another process grabs in between makes rank 0 fail loudly at bind)
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
@@ -228,7 +287,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="labelled images per GPU per step (+ as many unlabelled)")
+    ap.add_argument("--batch", type=int, default=0, help="labelled images per GPU per step (+ as many unlabelled); 0 = the workload's default "
+                                                         "(32 at 512x512, 8 at 1024x1024)")
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS), help="BASELINE.json configs[1] / [2] / [3]; cfg3 = the metric's configuration")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -237,6 +298,10 @@ def main():
                     help="run the two no-grad pseudo-label forwards under autocast too (all-bf16 step; NOT the reference's "
                          "precision: its trainers run them in fp32, outside autocast)")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    if args.batch <= 0:
+        args.batch = wl["batch"]
+    size, k_codes = wl["size"], wl["k"]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
@@ -266,10 +331,10 @@ def main():
     from vq_seg_amd.trainer import CPSConfig, CPSTrainer, SyntheticCropWeed
 
     t_start = time.perf_counter()
-    cfg = CPSConfig(model=model_cfg(), recipe="v1", total_iters=args.steps + args.warmup + 1,
+    cfg = CPSConfig(model=model_cfg(args.workload), recipe=wl["recipe"], total_iters=args.steps + args.warmup + 1,
                     amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None, eval_amp=args.eval_amp)
     trainer = CPSTrainer(cfg, device)
-    data = SyntheticCropWeed(SIZE, args.batch, device, seed=42)
+    data = SyntheticCropWeed(size, args.batch, device, seed=42)
     batches = [(data.labelled(), data.unlabelled()) for _ in range(2)]      # resident in HBM before timing
     torch.cuda.synchronize()
 
@@ -303,25 +368,40 @@ def main():
     elapsed = float(t.item())
     loss = float(out["loss"])
     note(f"{args.steps} timed steps done in {elapsed:.2f}s")
-    if world > 1 and rehearsal:
-        # data-parallel invariant: after the same averaged updates every rank holds bit-identical parameters
-        chk = torch.stack([p.detach().double().sum() for m in trainer.models for p in m.parameters()]).cpu()
-        gathered = [torch.zeros_like(chk) for _ in range(world)]
+    dp_check = None
+    if multi:
+        # Self-validation of the N > 1 path in EVERY multi-rank run (RCCL on real GPUs as well as the gloo rehearsal):
+        # after the same averaged updates every rank must hold bit-identical parameters -- checksums are all-gathered and compared --
+        # and the gradient buckets must have been reduced from inside backward, in the same order on every rank.
+        dev_c = device if not rehearsal else torch.device("cpu")
+        chk = torch.stack([p.detach().double().sum() for m in trainer.models for p in m.parameters()]).to(dev_c)
+        gathered = [torch.zeros_like(chk) for _ in range(dist.get_world_size())]
         dist.all_gather(gathered, chk)
-        if not all(torch.equal(g, gathered[0]) for g in gathered):
+        identical = all(torch.equal(g, gathered[0]) for g in gathered)
+        seq = torch.tensor([bi for b in trainer.buckets for bi in b.launch_sequence[:64]] + [-1] * 128, device=dev_c)[:128]
+        seqs = [torch.zeros_like(seq) for _ in range(dist.get_world_size())]
+        dist.all_gather(seqs, seq)
+        same_seq = all(torch.equal(q, seqs[0]) for q in seqs)
+        dp_check = {"world_size_seen": dist.get_world_size(), "ranks_identical": bool(identical), "same_bucket_sequence_on_all_ranks": bool(same_seq),
+                    "buckets_reduced_in_backward": [int(sum(b.launched_in_backward)) for b in trainer.buckets],
+                    "buckets": [len(b.buckets) for b in trainer.buckets], "backend": dist.get_backend()}
+        if not identical:
             names = [f"model{i}.{k}" for i, m in enumerate(trainer.models) for k, _ in m.named_parameters()]
             bad = [names[j] for j in range(len(names)) if any(g[j] != gathered[0][j] for g in gathered)]
             raise AssertionError(f"ranks diverged in {len(bad)} of {len(names)} parameters, e.g. {bad[:6]} ... {bad[-3:]}")
-        trainer.sync_buffers()                                # BatchNorm statistics are per-rank by design; after the sync they agree too
-        chk = torch.stack([b.detach().double().sum() for m in trainer.models for b in m.buffers()]).cpu()
-        gathered = [torch.zeros_like(chk) for _ in range(world)]
-        dist.all_gather(gathered, chk)
-        assert all(torch.equal(g, gathered[0]) for g in gathered), "buffers differ after sync_buffers()"
-        in_bwd = [sum(b.launched_in_backward) for b in trainer.buckets]
-        note(f"rank {rank}: parameter and (synced) buffer checksums identical on all {world} ranks; buckets reduced inside backward: "
-             f"{in_bwd} of {[len(b.buckets) for b in trainer.buckets]}")
+        assert same_seq, "the ranks issued their bucket all-reduces in different orders"
+        if rehearsal and world > 1:
+            trainer.sync_buffers()                            # BatchNorm statistics are per-rank by design; after the sync they agree too
+            chk = torch.stack([b.detach().double().sum() for m in trainer.models for b in m.buffers()]).cpu()
+            gathered = [torch.zeros_like(chk) for _ in range(world)]
+            dist.all_gather(gathered, chk)
+            assert all(torch.equal(g, gathered[0]) for g in gathered), "buffers differ after sync_buffers()"
+        note(f"rank {rank}: parameter checksums identical on all {dist.get_world_size()} ranks; buckets reduced inside backward: "
+             f"{dp_check['buckets_reduced_in_backward']} of {dp_check['buckets']}")
 
-    recs = _hip.profile_collect(64 * args.steps) if rank == 0 else []
+    recs_all = _hip.profile_collect(64 * args.steps, with_kind=True) if rank == 0 else []
+    recs = [r[:4] for r in recs_all if r[4] != 2]              # the exact fp32-MFMA kernel (fp32 rows; bf16 rows without the filter)
+    recs_f = [r[:4] for r in recs_all if r[4] == 2]            # the bf16 candidate filter + exact re-score (bf16 rows)
     # next to the CPS figure, plain forward + backward + Adam of ONE network on the B labelled images
     # (ordinary supervised training throughput) -- measured after, and outside of, the timed region
     (l_in, l_tg), _ul = batches[0]
@@ -386,64 +466,117 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        flops = sum(2.0 * n * c * k for n, c, k, _ in recs)
-        ms = sum(r[3] for r in recs)
-        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        group = []                                               # the levels of one (grouped) launch: records until a shape repeats
-        for n, c, k, _ in recs:
-            if (n, c, k) in group:
-                break
-            group.append((n, c, k))
-        n_launch = len(recs) // max(len(group), 1)
-        # Bytes the TIMED kernel moves, per launch and row type: the pixel rows in (C * s) + one 8-byte key per row out (the quantised
-        # rows are written by the gather kernel, not by this one) -- the figure `traffic` (PMC bytes of the same kernel) compares with.
-        # Per step the kernel runs 4 x on bf16 rows (training forwards) and 2 x on fp32 rows (pseudo-label forwards; all bf16 with --eval-amp).
-        n_bf16, n_f32 = ((6, 0) if args.eval_amp else (4, 2)) if args.dtype == "bf16" else (0, 6)
-        alg = {"bf16": round(sum(n * (c * 2.0 + 8) for n, c, k in group)), "f32": round(sum(n * (c * 4.0 + 8) for n, c, k in group))}
-        alg_avg = (n_bf16 * alg["bf16"] + n_f32 * alg["f32"]) / 6.0
-        hbm_gbs = alg_avg * n_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        tr, traffic_src = pmc_traffic(group)
-        traffic = round((n_bf16 * tr["bf16"] + n_f32 * tr["f32"]) / 6.0) if ("bf16" in tr and "f32" in tr) else (tr.get("bf16") if n_f32 == 0 else None)
-        per_shape = vq_per_level(device, group, bf16_rows=args.dtype == "bf16") if not args.no_extras else {}
+        def level_group(rs):                                     # the levels of one (grouped) launch: records until a shape repeats
+            grp = []
+            for n, c, k, _ in rs:
+                if (n, c, k) in grp:
+                    break
+                grp.append((n, c, k))
+            return grp
+
+        group = level_group(recs) or level_group(recs_f)
         images = 2 * args.batch * world * args.steps
+        # ---- the exact fp32-MFMA kernel (the pseudo-label forwards' fp32 rows; every launch when the bf16 filter is off)
+        roof = None
+        if recs:
+            flops = sum(2.0 * n * c * k for n, c, k, _ in recs)
+            ms = sum(r[3] for r in recs)
+            achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            n_launch = len(recs) // max(len(group), 1)
+            per_step = n_launch / max(args.steps, 1)
+            # Bytes the TIMED kernel moves, per launch and row type: the pixel rows in (C * s) + one 8-byte key per row out (the quantised
+            # rows are written by the gather kernel, not by this one) -- the figure `traffic` (PMC bytes of the same kernel) compares with.
+            n_f32 = 0 if (args.eval_amp and args.dtype == "bf16") else (2 if args.dtype == "bf16" else 6)
+            n_bf16 = round(per_step) - n_f32                         # bf16 rows reach this kernel only with the candidate filter off
+            alg = {"bf16": round(sum(n * (c * 2.0 + 8) for n, c, k in group)), "f32": round(sum(n * (c * 4.0 + 8) for n, c, k in group))}
+            alg_avg = (n_bf16 * alg["bf16"] + n_f32 * alg["f32"]) / max(n_bf16 + n_f32, 1)
+            hbm_gbs = alg_avg * n_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            tr, traffic_src = pmc_traffic(group)
+            traffic = None
+            if (n_bf16 == 0 or "bf16" in tr) and (n_f32 == 0 or "f32" in tr):
+                traffic = round((n_bf16 * tr.get("bf16", 0) + n_f32 * tr.get("f32", 0)) / max(n_bf16 + n_f32, 1))
+            per_shape = vq_per_level(device, group, bf16_rows=False) if not args.no_extras else {}
+            clk = measured_vq_clock(device, group) if not args.no_extras else None
+            roof = {"kernel": "vq_assign_f32_kernel", "bound": "mfma", "achieved": round(achieved, 2),
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic_by_row_type": tr, "algorithmic_bytes_per_launch": round(alg_avg), "algorithmic_bytes_by_row_type": alg,
+                    "launch_mix_per_step": {"bf16 rows": n_bf16, "f32 rows": n_f32},
+                    "other_roof": {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
+                                   "note": "algorithmic bytes of this kernel (rows in + one 8-byte key per row) over the same launch "
+                                           "times: the fp32 distance contraction sits far on the MFMA side of the ridge"},
+                    "launches": n_launch, "levels_per_launch": len(group), "avg_launch_us": round(ms / max(n_launch, 1) * 1e3, 2),
+                    "per_shape": per_shape,
+                    "note": "algorithmic flops 2*N*K*C per launch / HIP-event time on the launch stream, all launches of this kernel inside "
+                            "the timed region (the pseudo-label forwards' fp32 rows; bf16 rows go through the candidate filter: "
+                            "roofline_vq_bf16); peak = fp32 MFMA (MI355X_MICROARCH.md); the three levels of a forward share ONE launch "
+                            "(longest workgroups first); per_shape = each level ALONE in its own launch, after the timed region"}
+            if clk is not None:
+                held = FP32_MFMA_PEAK_TFLOPS * clk["clock_mhz"] / 2400.0
+                roof["at_held_clock"] = dict(clk, peak=round(held, 1), frac=round(achieved / held, 4),
+                                             source="MEASURED in this run: s_memtime / s_memrealtime of every workgroup of one stamped grouped launch of "
+                                                    "the timeline build (libvqseg_hip_tl.so) right after the timed region; the 157.3 TF/s peak is quoted "
+                                                    "at 2.4 GHz; `frac` above stays against the nominal peak")
+        # ---- the bf16 candidate filter + exact re-score (the training forwards' bf16 rows)
+        roof_f = None
+        if recs_f:
+            grp_f = level_group(recs_f)
+            ms_f = sum(r[3] for r in recs_f)
+            nl_f = len(recs_f) // max(len(grp_f), 1)
+            alg_fl = sum(2.0 * n * c * k for n, c, k, _ in recs_f)
+            exe_fl = 2.0 * alg_fl                                  # hi + lo parts of the codebook: twice the algorithmic contraction (re-score: < 1 %)
+            alg_b = sum(n * (c * 2.0 + 8) for n, c, k in grp_f)
+            tf_alg, tf_exe = alg_fl / (ms_f * 1e-3) / 1e12, exe_fl / (ms_f * 1e-3) / 1e12
+            gbs = alg_b * nl_f / (ms_f * 1e-3) / 1e9
+            roof_f = {"kernel": "vq_filter_bf16_kernel + vq_resolve_kernel + vq_rescore_kernel (bf16 rows: bf16-MFMA candidate filter, exact "
+                                "fmaf-chain re-score of the candidates; indices and distances identical to vq_assign_f32_kernel)",
+                      "bound": "mfma", "achieved": round(tf_exe, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": round(tf_exe / BF16_MFMA_PEAK_TFLOPS, 4),
+                      "algorithmic_tflops": round(tf_alg, 1), "executed_over_algorithmic_flops": 2.0,
+                      "vs_fp32_mfma_peak": round(tf_alg / FP32_MFMA_PEAK_TFLOPS, 3),
+                      "other_roof": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                     "algorithmic_bytes_per_launch": round(alg_b)},
+                      "traffic": None, "launches": nl_f, "levels_per_launch": len(grp_f), "avg_launch_us": round(ms_f / max(nl_f, 1) * 1e3, 2),
+                      "note": "HIP-event time from the filter kernel's launch to the end of the re-score (three kernels), all launches inside the "
+                              "timed region; achieved = EXECUTED bf16 flops (2 x 2*N*K*C: the codebook's hi and lo parts) against the dense bf16 "
+                              "MFMA peak, algorithmic_tflops = 2*N*K*C / time (what the exact kernel is measured by: SURVEY 8d's per-row figure); "
+                              "with bf16 operands and K = 512 the path sits near the HBM / MFMA ridge (SURVEY 8d): both fractions are given"}
+            if recs:
+                roof_f["speedup_over_exact_kernel_per_launch"] = round((sum(r[3] for r in recs) / max(len(recs), 1)) / (ms_f / max(len(recs_f), 1)), 2)
+        if roof is None:                                          # every launch took the filter (--eval-amp): it IS the dominant VQ kernel
+            roof, roof_f = roof_f, None
+        model_name = wl["model"]
         line = {
-            "metric": "train images/sec @512x512 vqreptunet1x1 K=512",
+            "metric": f"train images/sec @{size}x{size} {model_name} K={k_codes}",
             "value": round(images / elapsed, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "CPS training iteration (2 x vqreptunet1x1, ResNet-50 encoder, K=[0,0,512,512,512], "
-                                   "v1 recipe: 6 forwards + 4 backwards + 2 Adam steps) on 512x512x3 images",
+            "config": {"workload": f"CPS training iteration (2 x {model_name}, ResNet-50 encoder, K=[0,0,{k_codes},{k_codes},{k_codes}], "
+                                   f"{wl['recipe']} recipe: 6 forwards + 4 backwards + 2 Adam steps) on {size}x{size}x3 images -- {wl['what']}",
+                       "baseline_config": args.workload,
                        "images_per_step_per_gpu": 2 * args.batch, "labelled_per_gpu": args.batch,
-                       "unlabelled_per_gpu": args.batch, "parallelism": f"dp{world}",
+                       "unlabelled_per_gpu": args.batch,
+                       "batch_reading": "BASELINE's 'bs=64/GPU' is taken as 64 input images per GPU and step = 32 labelled + 32 unlabelled; "
+                                        "`--batch 64` runs the other reading (64 + 64: the reference's batch_size is per loader)",
+                       "parallelism": f"dp{world}",
                        "collectives": ("none (one process)" if not multi else "gloo rehearsal, every rank on cuda:0 (timings meaningless)" if rehearsal
                                        else "RCCL" + (" (one-rank drive of the N > 1 code path, VQSEG_DIST_SINGLE)" if world == 1 else "")),
-                       "vq_dtype": "f32 (exact fp32 MFMA, bit-exact argmin)", "conv_dtype": args.dtype,
+                       "vq_dtype": "f32 arithmetic, bit-exact argmin (fp32 rows: exact fp32 MFMA; bf16 rows: bf16-MFMA candidate filter + exact re-score)",
+                       "conv_dtype": args.dtype,
                        "precision_per_forward": {
                            "4 training forwards + 4 backwards": args.dtype + (" (under autocast, like the reference's AMP region; its fp16 -> bf16)" if args.dtype == "bf16" else ""),
                            "2 no-grad pseudo-label forwards": ("bf16 (--eval-amp: NOT the reference's precision)" if (args.eval_amp and args.dtype == "bf16")
                                                                else "fp32 (outside autocast, train_vqreptunet1x1v2.py:143-149)")},
                        "final_loss": round(loss, 5)},
-            "roofline": {"kernel": "vq_assign_f32_kernel", "bound": "mfma", "achieved": round(achieved, 2),
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_by_row_type": tr, "algorithmic_bytes_per_launch": round(alg_avg), "algorithmic_bytes_by_row_type": alg,
-                         "launch_mix_per_step": {"bf16 rows": n_bf16, "f32 rows": n_f32},
-                         "other_roof": {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
-                                        "note": "algorithmic bytes of this kernel (rows in + one 8-byte key per row) over the same launch "
-                                                "times: the fp32 distance contraction sits far on the MFMA side of the ridge"},
-                         "launches": n_launch, "levels_per_launch": len(group), "avg_launch_us": round(ms / max(n_launch, 1) * 1e3, 2),
-                         "at_held_clock": {"clock_mhz": 2142, "peak": round(FP32_MFMA_PEAK_TFLOPS * 2142 / 2400, 1),
-                                           "frac": round(achieved / (FP32_MFMA_PEAK_TFLOPS * 2142 / 2400), 4),
-                                           "source": "profiles/r03_vq_wg_timeline.md: s_memtime / s_memrealtime inside this kernel = 2.14 GHz "
-                                                     "(the 157.3 TF/s peak is quoted at 2.4 GHz); `frac` above stays against the nominal peak"},
-                         "per_shape": per_shape,
-                         "note": "algorithmic flops 2*N*K*C per launch / HIP-event time on the launch stream, all launches inside the "
-                                 "timed region; peak = fp32 MFMA (MI355X_MICROARCH.md); the three levels of a forward share ONE launch "
-                                 "(longest workgroups first); per_shape = each level ALONE in its own launch, after the timed region"},
+            "roofline": roof,
         }
+        if roof_f is not None:
+            line["roofline_vq_bf16"] = roof_f
+        if dp_check is not None:
+            line["dp_check"] = dp_check
         if sup_s is not None:
             line["supervised_step"] = {"images_per_sec": round(args.batch * world / sup_s, 2), "ms_per_step": round(sup_s * 1e3, 2),
                                        "what": "forward + backward + Adam of ONE network on the labelled half of the batch "
@@ -460,7 +593,7 @@ def main():
                 "kernel": "conv3x3_patch_kernel / conv_igemm_glds_kernel (every 3x3 bf16 launch: forward + data gradient)",
                 "bound": "mfma", "achieved": k3["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(k3["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "traffic_source": "profiles/r02_conv_patch_pmc.md (per-layer PMC passes of the patch kernel: HBM-side bytes 1.2-4.0x algorithmic, Infinity-Cache hits included; no single per-launch figure exists for an aggregate over 260 launches of 40 shapes)",
+                "traffic_source": "per-layer PMC passes (tools/pmc_conv.sh -> profiles/r04_conv_layers_pmc.md when present, else r02_conv_patch_pmc.md): HBM-side bytes 1.2-4.0x algorithmic, Infinity-Cache hits included; no single per-launch figure exists for an aggregate over 260 launches of 40 shapes",
                 "by_kind": {"3x3 bf16": k3, "1x1 bf16": rate(lambda kd: kd == 100), "3x3 split-3 (fp32-precision eval)": rate(lambda kd: kd == 302),
                             "1x1 split-3": rate(lambda kd: kd == 102), "precise (fp32 activations)": rate(lambda kd: kd % 100 == 1),
                             "3x3 weight gradient bf16": rate(lambda kd: kd == 350), "1x1 weight gradient bf16": rate(lambda kd: kd == 150),
@@ -477,8 +610,8 @@ def main():
             line["all_bf16_step"] = {"images_per_sec": round(images / all_bf16_s, 3), "ms_per_step": round(all_bf16_s / args.steps * 1e3, 3),
                                      "what": "the same step with the two pseudo-label forwards under bf16 autocast too (CPSConfig.eval_amp=True); "
                                              "narrower than the reference's trainer there, so it is NOT the headline"}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_cpu_baseline and wl["recipe"] == "v1":      # (the oracle's CPS iteration restates the v1 loop body)
+            line["cpu_baseline"] = cpu_baseline(size, k_codes)
         print(json.dumps(line), flush=True)
     if multi:
         dist.destroy_process_group()

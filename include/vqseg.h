@@ -5,8 +5,10 @@
  * The reference has no FFI layer; its boundary for this path is the Python nn.Module
  * surface.  These entry points are what that surface binds: each one cites
  * the reference function (file:line, relative to the reference root) whose arithmetic
- * it replaces.  Plain pointers and sizes only -- no torch types, no C++ exceptions, no
- * global mutable state except the thread-local last-error string.
+ * it replaces.  Plain pointers and sizes only -- no torch types, no C++ exceptions.  Process-global
+ * state: the thread-local last-error string, the dispatch options of vqseg_set_option and the two
+ * measurement recorders (vqseg_profile_*, vqseg_conv_profile_*) -- none of them thread safe; launches
+ * themselves keep no state between calls.
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in _host;

@@ -59,6 +59,13 @@ def _grad_job(rank, world):
     # (finish() of step 1) every bucket is reduced from inside backward
     assert not all(in_bwd[0]) and all(in_bwd[1]) and all(in_bwd[2]), in_bwd
     assert buckets._silent == {id(frozen)}
+    # r4: every bucket all-reduce carries its place in the issue order; all ranks must issue the same sequence (a rank that reduced
+    # its buckets in another order would pair different buffers in the collectives) -- bench.py asserts the same in every N > 1 run
+    seq = torch.tensor(buckets.launch_sequence)
+    assert sorted(seq.tolist()) == list(range(len(buckets.buckets)))
+    seqs = [torch.zeros_like(seq) for _ in range(world)]
+    dist.all_gather(seqs, seq)
+    assert all(torch.equal(q, seqs[0]) for q in seqs), seqs
     return [p.grad.clone() for p in params]
 
 
@@ -122,3 +129,44 @@ def test_synthetic_data_is_sharded_by_rank():
     img, lab = a.labelled()
     assert img.shape == (2, 3, 32, 32) and lab.shape == (2, 32, 32) and img.min() >= 0 and img.max() <= 1
     assert set(lab.unique().tolist()) <= {0, 1, 2}
+
+
+def _flat_broadcast_and_resume_job(rank, world):
+    """CPSTrainer's rank-0 -> all broadcast of the initial state (one flat buffer per dtype) and the per-rank BatchNorm statistics of
+    a data-parallel checkpoint, on the host logic alone (the models here are plain torch modules: no kernel runs)."""
+    import tempfile
+    from vq_seg_amd import trainer as T
+    from vq_seg_amd.utils.ckpoints import load_training_state
+    torch.manual_seed(100 + rank)                            # different initial state per rank
+    nets = [nn.Sequential(nn.Conv2d(3, 4, 3), nn.BatchNorm2d(4)) for _ in range(2)]
+    tr = T.CPSTrainer.__new__(T.CPSTrainer)                  # the two methods under test need only these attributes
+    tr.models, tr.device, tr.iter = nets, torch.device("cpu"), 7
+    tr.opts = [torch.optim.Adam(m.parameters(), lr=1e-3) for m in nets]
+    for m in tr.models:                                      # what the constructor does under data parallelism
+        T.broadcast_module_state(m)
+    state = torch.cat([t.detach().double().reshape(-1) for m in nets for t in list(m.parameters()) + list(m.buffers())])
+    # -- per-rank statistics, then a checkpoint written by rank 0 that keeps every rank's own
+    for m in nets:
+        m[1].running_mean.fill_(float(rank + 1))
+        m[1].num_batches_tracked.fill_(10 * (rank + 1))
+    path = os.path.join(tempfile.gettempdir(), f"vqseg_dp_ckpt_{os.environ['MASTER_PORT']}.pt")
+    tr.save_checkpoint(path)
+    dist.barrier()
+    for m in nets:
+        m[1].running_mean.zero_()
+        m[1].num_batches_tracked.zero_()
+    tr.iter = 0
+    tr.load_checkpoint(path)
+    ok = all(float(m[1].running_mean[0]) == float(rank + 1) and int(m[1].num_batches_tracked) == 10 * (rank + 1) for m in nets) and tr.iter == 7
+    dist.barrier()
+    if rank == 0:
+        keys = set(load_training_state(path))
+        os.remove(path)
+        assert {"model_1", "model_2", "epoch", "batch_idx", "optimizer_1", "optimizer_2"} <= keys      # the reference's layout is intact
+    return state, ok
+
+
+def test_initial_broadcast_is_flat_and_dp_resume_keeps_per_rank_bn_statistics():
+    out = spawn(_flat_broadcast_and_resume_job)
+    assert torch.equal(out[0][0], out[1][0])                 # every rank starts from rank 0's parameters and buffers
+    assert out[0][1] and out[1][1]                           # ADVICE r3: ranks > 0 get THEIR OWN running statistics back on resume

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
+import time
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 from typing import Optional, Tuple
 
@@ -198,7 +200,31 @@ def _tptr_report(t, name, dtype, numel, at_least):
     return t.data_ptr()
 
 
-_NOT_ON_GPU: list = []
+class _Pending(threading.local):
+    """Deferred 'tensor is not on the GPU' messages of the wrapper call in progress -- per thread (autograd runs backward wrappers
+    on its own threads), and short-lived: a message is raised by the SAME wrapper call microseconds later (_stream / _check); one
+    that is still here after two seconds was orphaned by an unrelated exception between a tptr() and its launch and must not
+    fail a later, valid call."""
+
+    def __init__(self):
+        self.msgs = []
+
+    def append(self, m):
+        self.msgs.append((time.monotonic(), m))
+
+    def clear(self):
+        self.msgs.clear()
+
+    def __bool__(self):
+        now = time.monotonic()
+        self.msgs = [e for e in self.msgs if now - e[0] < 2.0]
+        return bool(self.msgs)
+
+    def __getitem__(self, i):
+        return self.msgs[i][1]
+
+
+_NOT_ON_GPU = _Pending()
 
 
 def _raise_if_not_on_gpu() -> None:
@@ -271,11 +297,21 @@ def vq_forward(rows: torch.Tensor, codebook: torch.Tensor, training: bool, commi
     return out + (dmin,) if want_dmin else out
 
 
-def vq_forward_group(rows_list, codebooks, prepared_list, training: bool, commitment_weights):
+def bind(path: str) -> ctypes.CDLL:
+    """another build of the same ABI (the per-workgroup timeline build) as a SECOND handle next to lib(): measurement code only"""
+    handle = ctypes.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(handle, name)
+        fn.restype, fn.argtypes = res, args
+    return handle
+
+
+def vq_forward_group(rows_list, codebooks, prepared_list, training: bool, commitment_weights, handle=None):
     """vq_forward for several independent layers with ONE distance + argmin launch (vqseg_vq_forward_group).
-    -> list of (quant, idx, loss (1,), dead_pct ()) per level; bit-identical to per-level vq_forward calls."""
+    -> list of (quant, idx, loss (1,), dead_pct ()) per level; bit-identical to per-level vq_forward calls.
+    `handle`: another build of the library (bind()), for measurement code."""
     import numpy as np
-    L = lib()
+    L = handle or lib()
     nl = len(rows_list)
     bf16 = rows_list[0].dtype == torch.bfloat16
     dev = rows_list[0].device

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import nnf
 from .measurement import Measurement, confusion_matrix_device
 
 
@@ -33,7 +34,10 @@ def test_loop(model: torch.nn.Module, batches: Iterable[Tuple[torch.Tensor, torc
         else:
             pred = model(img)
         pred = pred[0] if isinstance(pred, tuple) else pred
-        pred = F.interpolate(pred.float(), target.shape[-2:], mode="bilinear")
+        pred = pred.float()
+        # F.interpolate(pred, size, mode="bilinear") of test_detailviz.py:118 (align_corners=False): the HIP resize kernel on the device
+        pred = nnf.upsample_bilinear(pred, size=tuple(target.shape[-2:]), align_corners=False) if pred.is_cuda else \
+            F.interpolate(pred, target.shape[-2:], mode="bilinear")
         conf = confusion_matrix_device(pred, target, num_classes)                  # (N, C, C), rows = ground truth
         hits = (pred.argmax(dim=1) == target).flatten(1).double().mean(dim=1)       # Measurement.accuracy per image
         conf_np = conf.cpu().numpy()

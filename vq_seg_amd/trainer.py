@@ -73,6 +73,8 @@ class GradBuckets:
         self._silent = None
         self._names = {}
         self.launched_in_backward = []                     # per step: which buckets were reduced from inside backward (tests)
+        self.launch_sequence: List[int] = []               # the order this step's bucket all-reduces were issued in (must be the same on
+                                                           # every rank: bench.py / tests compare it across ranks)
         # RCCL has an averaging reduction; gloo (CPU tests, rehearsal) does not: sum, then scale
         self._avg = dist.ReduceOp.AVG if (self.on and dist.get_backend() == "nccl") else None
         self.producer_streams = []          # set by CPSTrainer: the side stream(s) the gradient kernels of these params run on
@@ -95,9 +97,11 @@ class GradBuckets:
         self._launched = [False] * len(self.buckets)
         self._handles = []
         self._reported = set()
+        self.launch_sequence = []
 
     def _launch(self, bi):
         self._launched[bi] = True
+        self.launch_sequence.append(bi)
         # The collective orders itself after the CURRENT stream only.  The last gradient of a bucket may report from an
         # autograd hook running on another stream than the one the HIP weight-gradient kernels wrote the rest of the bucket
         # on, so order the current stream after everything those streams hold so far (all of this bucket's gradients).
@@ -206,6 +210,21 @@ class CPSConfig:
     extra: dict = field(default_factory=dict)
 
 
+def broadcast_module_state(m: nn.Module, src: int = 0) -> None:
+    """rank `src`'s parameters and buffers to every rank: ONE broadcast per dtype over a flat copy (r3 issued ~750 per-tensor
+    broadcasts per network)."""
+    by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
+    for t in list(m.parameters()) + list(m.buffers()):
+        by_dtype.setdefault(t.dtype, []).append(t.data)
+    for ts in by_dtype.values():
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in ts:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
+
 def regularized_pseudo_label(raw: torch.Tensor, percent: float) -> torch.Tensor:
     """make_regularized_pseudo_label (deprecated/train_with_test_pt_pseudo_entropy_reg.py:30-39) with
     the percentile taken on the device (np.percentile's linear interpolation between two order statistics)."""
@@ -245,8 +264,7 @@ class CPSTrainer:
                             cfg.bn_momentum, mode="fan_in", nonlinearity="relu")
         if vdist.collectives_on():
             for m in self.models:
-                for t in list(m.parameters()) + list(m.buffers()):
-                    dist.broadcast(t.data, src=0)
+                broadcast_module_state(m)
                 nnf.invalidate_weight_caches(m)          # `.data` writes do not bump the version counter (_wcache)
         for m in self.models:
             m.async_code_usage = True                     # no host sync inside forward (usage is read after the step)
@@ -489,9 +507,22 @@ class CPSTrainer:
         the iteration counter that positions the cosine schedule.  Rank 0 writes ITS state (parameters, codebooks and optimiser
         moments are identical on all ranks; the BatchNorm running statistics in the file are rank 0's); no collective, no rank's
         state is touched -- writing a checkpoint cannot alter the run."""
+        extra = {"iter": self.iter}
+        if vdist.collectives_on() and vdist.world_size() > 1:
+            # BatchNorm running statistics are per-rank: COPIES of every rank's buffers are gathered to rank 0 (no rank's state is
+            # touched) and stored beside the reference's keys, so that a data-parallel resume restores each rank's own statistics
+            for i, m in enumerate(self.models):
+                names = [k for k, _ in m.named_buffers()]
+                flat = torch.cat([b.detach().double().reshape(-1) for _, b in m.named_buffers()]) if names else torch.zeros(0, dtype=torch.float64, device=self.device)
+                if dist.get_backend() == "gloo":
+                    flat = flat.cpu()
+                gathered = [torch.zeros_like(flat) for _ in range(vdist.world_size())]
+                dist.all_gather(gathered, flat)
+                extra[f"bn_buffers_model_{i + 1}"] = {"names": names, "shapes": [tuple(b.shape) for _, b in m.named_buffers()],
+                                                       "per_rank": [g.cpu() for g in gathered]}
         if vdist.rank() == 0:
             m1, m2, o1, o2 = self.state_dicts()
-            save_ckpoints(m1, m2, epoch, batch_idx, o1, o2, filepath, models=self.models, extra={"iter": self.iter})
+            save_ckpoints(m1, m2, epoch, batch_idx, o1, o2, filepath, models=self.models, extra=extra)
 
     def load_checkpoint(self, filepath):
         """Resume from save_checkpoint's file (or a reference-written one: then the flags and the counter stay as they are).
@@ -503,6 +534,19 @@ class CPSTrainer:
             nnf.invalidate_weight_caches(m)
         for m, flags in zip(self.models, state.get("initted") or (None, None)):
             restore_initted(m, flags)
+        for i, m in enumerate(self.models):                # data-parallel resume: this rank's own BatchNorm statistics (see save_checkpoint)
+            rec = state.get(f"bn_buffers_model_{i + 1}")
+            if rec and vdist.rank() < len(rec["per_rank"]):
+                flat, off = rec["per_rank"][vdist.rank()], 0
+                bufs = dict(m.named_buffers())
+                with torch.no_grad():
+                    for name, shape in zip(rec["names"], rec["shapes"]):
+                        n = 1
+                        for d in shape:
+                            n *= d
+                        if name in bufs:
+                            bufs[name].copy_(flat[off:off + n].view(shape).to(bufs[name].dtype))
+                        off += n
         self.iter = int(state.get("iter", self.iter))
         return state.get("epoch", 0), state.get("batch_idx", 0)
 
