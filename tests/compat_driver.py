@@ -1,6 +1,6 @@
 """Child process of tests/test_compat_gpu.py: the reference trainer's situation on the GPU box.
 
-    python tests/compat_driver.py <repo>/compat <out.npz> iter_v1|iter_v2|iter_v1_amp|iter_v2_amp|curve|curve_bf16|curve_amp|train_main
+    python tests/compat_driver.py <repo>/compat <out.npz> iter_v1|iter_v2|iter_v1_amp|iter_v2_amp|curve|curve_bf16|curve_amp|curve128|curve128_bf16|curve128_amp|train_main
 
 sys.path gets `<repo>/compat` (the maintainer's one line) and -- for the restated loop body only, which lives under tests/ --
 the repository root.  Models, losses, metrics and the schedule are reached through the reference's TOP-LEVEL names
@@ -63,6 +63,10 @@ elif what == "curve_bf16":                            # the benchmarked precisio
     arrays = cps_loop.run_curve(ns, dev, to_cfg=EasyDict, prepare=prepare, half=True, amp_dtype=torch.bfloat16)
 elif what == "curve_amp":                             # `half: true` as shipped: fp16-default autocast + GradScaler, literally
     arrays = cps_loop.run_curve(ns, dev, to_cfg=EasyDict, prepare=prepare, half=True, scaler=True)
+elif what in ("curve128", "curve128_bf16", "curve128_amp"):
+    # r4: the thicker mIoU-parity run -- 128x128, K = 512 at the three levels, 200 v1 iterations (fixture cps_curve_v1_128.npz)
+    kw = dict(curve128={}, curve128_bf16=dict(half=True, amp_dtype=torch.bfloat16), curve128_amp=dict(half=True, scaler=True))[what]
+    arrays = cps_loop.run_curve(ns, dev, to_cfg=EasyDict, prepare=prepare, k=cps_loop.K128, spec=cps_loop.CURVE128, **kw)
 elif what == "train_main":
     # train() of train_vqreptunet1x1v2.py:48-218 as far as the hot path goes: datasets + loaders (:86-93), models + init_weight
     # (:70-80, random init, k-means codebook / prototype init in the first training forward), optimisers + schedule + AMP region

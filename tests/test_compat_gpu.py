@@ -119,7 +119,8 @@ def test_miou_parity_run(tmp_path):
     # ~ lr * sign(g) (lr = 1e-3 here), so a last-bit difference of ANY forward kernel (r3: the bilinear kernels' spelled-out fma order)
     # moves iteration 2 by ~1e-3 -- the CPU oracle against itself under a 1e-5 input perturbation moves more
     # (tests/diagnostics/cps_mask_sensitivity.py); the end of the curve above carries the bar that matters
-    for i, tol in enumerate((1e-4, 1e-3, 5e-3)):
+    # (r4: bars at <= 2x the measured deltas -- 1e-6 / 3e-4 / 1.1e-3 on the r3 build)
+    for i, tol in enumerate((1e-4, 1e-3, 2.5e-3)):
         assert abs(got["sup_loss_1"][i] - fx["sup_loss_1"].numpy()[i]) <= tol * abs(fx["sup_loss_1"].numpy()[i]), (i, got["sup_loss_1"][:3], fx["sup_loss_1"][:3])
 
 
@@ -209,3 +210,23 @@ def test_miou_parity_run_literal_amp(tmp_path):
     assert abs(a[0] - b[0]) <= 1e-4
     assert abs(a[-1] - b[-1]) <= 0.002, (a, b)
     assert np.abs(a - b).max() <= 0.05, (a, b)
+
+
+@pytest.mark.parametrize("what", ["curve128", "curve128_bf16", "curve128_amp"])
+def test_miou_parity_run_128_k512_200_steps(tmp_path, what):
+    """the thicker mIoU-parity run.  200 v1 iterations at 128x128 with the shipped codebook size K = 512 at the
+    three levels (the 64x64 run uses K = 64), test mIoU every 25 steps; reference modules on the CPU (fixture cps_curve_v1_128.npz,
+    oracle/make_golden.py curve128: 0.219 -> 0.929 -> 0.984 -> ... -> 0.998) against this repository through the flat names on the
+    MI355X in fp32, under bf16 autocast (the benchmarked precision) and under the trainer's literal AMP region.  North_star:
+    the end point within 0.2 mIoU points."""
+    got, fx = drive(tmp_path, what), golden_io.load("cps_curve_v1_128")
+    a, b = got["test_miou"], fx["test_miou"].numpy()
+    print(f"test mIoU  GPU {what}:", np.round(a, 5), " reference CPU fp32:", np.round(b, 5))
+    assert a.shape == b.shape == (9,)
+    assert abs(a[0] - b[0]) <= 1e-4                                  # same start (fp32 evaluation before any training)
+    assert abs(a[-1] - b[-1]) <= 0.002, (a, b)                       # 0.2 mIoU points at the end
+    assert np.abs(a[2:] - b[2:]).max() <= 0.01, (a, b)               # from step 50 on the curves stay within one point
+    assert np.abs(a - b).max() <= (0.03 if what == "curve128" else 0.06), (a, b)     # steep phase (step 25)
+    assert b[-1] > 0.99 and a[-1] > 0.99
+    if what == "curve128_amp":
+        assert (got["scale"] == 65536.0).all(), got["scale"]
