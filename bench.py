@@ -209,8 +209,12 @@ def measured_vq_clock(device, group):
     path = os.path.join(ROOT, "vq_seg_amd", "libvqseg_hip_tl.so")
     if not os.path.exists(path) or not group:
         return None
-    H = _hip.bind(path)
-    H.vqseg_debug_timeline.argtypes = [ctypes.c_void_p]
+    try:
+        H = _hip.bind(path)                                     # a stale build (other ABI) must not take the bench down: no clock then
+        H.vqseg_debug_timeline.argtypes = [ctypes.c_void_p]
+    except (OSError, AttributeError) as exc:
+        print(f"[bench] timeline build not usable ({exc}); run __graft_entry__.build()", file=sys.stderr)
+        return None
     rows = [torch.relu(torch.randn(n, c, device=device)) for n, c, k in group]
     books = [torch.relu(torch.randn(k, c, device=device)) for n, c, k in group]
     preps = [_hip.vq_prepare(w) for w in books]

@@ -327,6 +327,12 @@ int vqseg_maxpool3x3s2_backward_add_f(int bf16, const void* g, const unsigned ch
 int vqseg_im2col_f(int out_bf16, const float* x, int n, int h, int w, int cin, int kh, int kw, int stride,
                    int pad, int reflect, int ho, int wo, int kp, void* out, void* stream);
 int vqseg_reflect_fold_f(int bf16, const void* gp, int n, int h, int w, int c, void* gx, void* stream);
+/* The data gradient of a 3x3 / stride 1 / REFLECT-pad-1 convolution (resnet.py:134-148: every Bottleneck conv2) without the padded
+ * gradient tensor (r4): gx [n][h][w][cgx] must already hold the ZERO-padded data gradient of gy (vqseg_conv2d_f with the transposed
+ * image and pad 1: the padded gradient's interior, on the fast patch kernel); this call evaluates the full correlation only on the
+ * border ring of the (h + 2) x (w + 2) grid -- ring [n][2 (w + 2) + 2 h][cgx], scratch -- and folds the ring onto rows 1 / h-2 and
+ * columns 1 / w-2 of gx in place.  bf16 activations; cgy % 64 == 0 (gy's channels), cgx % 8 == 0; h, w >= 4. */
+int vqseg_reflect_ring_f(const void* gy, const void* t_hi, void* ring, void* gx, int n, int h, int w, int cgy, int cgx, void* stream);
 
 /* ----------------------------------------------------------------------------------
  * "Split-3" activations: the fp32-precision NO-GRAD EVAL forward (the trainers' pseudo-label passes, outside autocast:

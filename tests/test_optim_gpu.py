@@ -333,3 +333,39 @@ def test_trainer_step_with_fanin_fusion_matches_the_unfused_step(amp):
         for k in ("loss", "sup_loss_1", "cps_loss", "commitment_loss", "prototype_loss"):
             assert abs(a[k] - b[k]) <= tol * abs(b[k]) + 1e-6, (k, a[k], b[k])
     assert rel(outs[0][1], outs[1][1]) < (5e-2 if amp is not None else 1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ reflect-padding data gradient by ring
+@pytest.mark.parametrize("shape", [(2, 64, 64, 16, 16), (1, 128, 64, 12, 20), (3, 64, 128, 8, 8), (2, 256, 256, 4, 4), (1, 64, 64, 17, 13)])
+def test_reflect_data_gradient_by_border_ring_matches_the_padded_gradient_path(shape):
+    """3x3 / stride 1 / reflect-pad-1 convolution (every Bottleneck conv2, resnet.py:134-148): the data gradient as zero-padded
+    gradient + border ring (vqseg_reflect_ring_f) against the padded-gradient + fold path it replaces and against autograd of
+    F.conv2d on the reflect-padded input in float64 (same bf16 values)."""
+    from vq_seg_amd import _hip, nnf
+    n, cin, cout, h, w = shape
+    torch.manual_seed(0)
+    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=False, padding_mode="reflect").to(dev())
+    bn = nn.BatchNorm2d(cout).to(dev())
+    bn.eval()                                                    # fixed affine: the comparison is about the convolution's data gradient
+    x = synth.uniform(40, (n, cin, h, w), -1, 1).to(dev()).contiguous(memory_format=torch.channels_last).bfloat16()
+    g = synth.uniform(41, (n, cout, h, w), -1, 1).to(dev()).contiguous(memory_format=torch.channels_last).bfloat16()
+    outs = []
+    for ring in (1, 0):
+        _hip.PY_OPTS["py_reflect_ring"] = ring
+        try:
+            xi = x.clone().requires_grad_(True)
+            y = nnf.conv_bn_act(xi, conv, bn, relu=False)
+            (gx,) = torch.autograd.grad(y, xi, g)
+        finally:
+            _hip.PY_OPTS.pop("py_reflect_ring", None)
+        outs.append(gx.float())
+    xd = x.double().cpu().requires_grad_(True)
+    wq = conv.weight.detach().bfloat16().double().cpu()
+    scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().double().cpu()
+    yd = F.conv2d(F.pad(xd, (1, 1, 1, 1), mode="reflect"), wq) * scale[None, :, None, None]
+    (ref,) = torch.autograd.grad(yd, xd, g.double().cpu())
+    assert rel(outs[0], ref) < 2 ** -7 and rel(outs[1], ref) < 2 ** -7          # bf16 outputs of bf16 operands
+    assert rel(outs[0], outs[1]) < 2 ** -7                                        # border pixels: two bf16 roundings in either path
+    if h > 4 and w > 4:
+        inner = (slice(None), slice(None), slice(2, h - 2), slice(2, w - 2))      # interior: the same zero-padded correlation
+        assert rel(outs[0][inner], outs[1][inner]) < 2 ** -8

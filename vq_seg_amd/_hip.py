@@ -95,6 +95,7 @@ SYMBOLS = {
     "vqseg_order_stats_f": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
     "vqseg_im2col_f": (c_int, [c_int, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p]),
     "vqseg_reflect_fold_f": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vqseg_reflect_ring_f": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vqseg_cast_f": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "vqseg_conv_pack_all_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqseg_conv_packed_s2_elems": (c_size_t, [c_int, c_int, c_int]),

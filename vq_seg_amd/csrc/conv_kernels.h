@@ -31,6 +31,11 @@ struct ConvArgs {
     // strided output placement: GEMM row (n, oh, ow) -> pixel (n, 2 oh + omap_ph, 2 ow + omap_pw) of an omap_h x omap_w grid
     int omap = 0, omap_h = 0, omap_w = 0, omap_ph = 0, omap_pw = 0;
     int prof_k = 0;             // kernel size the launch is filed under by the convolution profile (0: KH)
+    // ring mode (r4; generic LDS-DMA kernel only): the GEMM rows are the border ring of a ring_h x ring_w output grid (top row,
+    // bottom row, left column, right column -- 2 ring_w + 2 (ring_h - 2) pixels per image; set Ho = 1, Wo = that length), written
+    // densely as [N][ring length][Cout].  The data gradient of a REFLECT-padded 3x3 layer needs the full correlation only there:
+    // its interior is the zero-padded data gradient (the fast patch kernel), see launch_reflect_ring / reflect_ring_fold
+    int ring = 0, ring_h = 0, ring_w = 0;
     int ep_res_out = 0;         // 1: ep_res is indexed like the OUTPUT (through omap) instead of by GEMM row -- in-place accumulation
                                 // into a tensor of the output's geometry (launch_dgrad_s2 with `accumulate`)
 };
@@ -70,6 +75,7 @@ hipError_t launch_pack_all(const float* w, int Cout, int Cin, int K, int C1, uns
 hipError_t launch_pack_weights_s2(const float* w, int Cout, int Cin, int K, unsigned short* hi, unsigned short* lo, hipStream_t st);
 hipError_t launch_dgrad_s2(const void* gy, const unsigned short* w_hi, const unsigned short* w_lo, void* gx, int N, int Ho, int Wo,
                            int Cout, int Cin, int K, int OH, int OW, int precise, int accumulate, hipStream_t st);
+hipError_t launch_reflect_ring(const void* gy, const unsigned short* t_hi, void* ring, int N, int H, int W, int Cgy, int Cgx, hipStream_t st);
 hipError_t launch_pack_weights_s3(const float* w, int Cout, int Cin, int C1, int KH, int KW, unsigned short* out, hipStream_t st);
 
 }  // namespace vqseg

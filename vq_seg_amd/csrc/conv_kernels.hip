@@ -639,6 +639,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
             a_n[i] = n;
             a_oh[i] = rem / p.Wo;
             a_ow[i] = rem - a_oh[i] * p.Wo;
+            if (p.ring) {                                    // rem = position on the border ring of a ring_h x ring_w grid
+                const int q = rem, wp = p.ring_w, hp = p.ring_h;
+                if (q < wp) a_oh[i] = 0, a_ow[i] = q;
+                else if (q < 2 * wp) a_oh[i] = hp - 1, a_ow[i] = q - wp;
+                else if (q < 2 * wp + hp - 2) a_oh[i] = 1 + (q - 2 * wp), a_ow[i] = 0;
+                else a_oh[i] = 1 + (q - 2 * wp - (hp - 2)), a_ow[i] = wp - 1;
+            }
         }
     }
     // ---- this lane's B rows (weights): wave w covers tile rows [w * BN/NW, (w+1) * BN/NW)
@@ -1438,6 +1445,13 @@ hipError_t launch_conv(const ConvArgs& a_in, int precise, hipStream_t st) {
 static hipError_t launch_conv_impl(const ConvArgs& a, int precise, hipStream_t st) {
     const int bn = a.Cout >= 128 ? 128 : (a.Cout >= 64 ? 64 : 32);
     const bool k64 = !precise && a.Cin % 64 == 0 && (a.C1 == a.Cin || a.C1 % 64 == 0);
+    if (a.ring) {                                            // border ring of a full correlation: few rows, generic LDS-DMA kernel
+        if (!k64) return hipErrorInvalidValue;
+        if (bn == 128) launch_glds_t<128, 128, 4, 2>(a, st);
+        else if (bn == 64) launch_glds_t<128, 64, 4, 3>(a, st);
+        else launch_glds_t<128, 32, 4, 3>(a, st);
+        return hipGetLastError();
+    }
     if (precise) {
         if (bn == 128) launch_t<128, true, 32>(a, st);
         else if (bn == 64) launch_t<64, true, 32>(a, st);
@@ -1632,6 +1646,23 @@ hipError_t launch_dgrad_s2(const void* gy, const unsigned short* w_hi, const uns
         off += (size_t)Cin * nh * nw * Cp;
     }
     return hipGetLastError();
+}
+
+// ring [N][2 (W + 2) + 2 H][Cgx] = the full 3x3 correlation of gy [N][H][W][Cgy] with the tap-flipped transposed weights, evaluated
+// on the border ring of the (H + 2) x (W + 2) grid only (bf16; Cgy % 64 == 0)
+hipError_t launch_reflect_ring(const void* gy, const unsigned short* t_hi, void* ring, int N, int H, int W, int Cgy, int Cgx, hipStream_t st) {
+    ConvArgs a;
+    a.x = gy; a.x2 = nullptr; a.C1 = Cgy;
+    a.w_hi = t_hi; a.w_lo = nullptr;
+    a.y = ring; a.stat_partial = nullptr;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cgy; a.Cout = Cgx; a.KH = 3; a.KW = 3;
+    a.ring = 1; a.ring_h = H + 2; a.ring_w = W + 2;
+    a.Ho = 1; a.Wo = 2 * (W + 2) + 2 * H;
+    a.stride = 1; a.pad = 2; a.pad_w = 2; a.reflect = 0; a.up = 1;
+    a.ep_scale = nullptr; a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_relu = 0;
+    a.prof_k = 3;
+    if ((long)a.N * a.Wo >= (1L << 31)) return hipErrorInvalidValue;
+    return launch_conv(a, 0, st);
 }
 
 hipError_t launch_pack_weights_s3(const float* w, int Cout, int Cin, int C1, int KH, int KW, unsigned short* out, hipStream_t st) {

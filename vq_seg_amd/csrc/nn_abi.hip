@@ -309,6 +309,17 @@ int vqseg_conv2d_dgrad_s2_f(const void* gy, const void* w_hi, const void* w_lo, 
     return e == hipSuccess ? 0 : hipfail(e, "conv2d_dgrad_s2");
 }
 
+int vqseg_reflect_ring_f(const void* gy, const void* t_hi, void* ring, void* gx, int n, int h, int w, int cgy, int cgx, void* stream) {
+    if (!gy || !t_hi || !ring || !gx) return bad("reflect_ring: null pointer");
+    if (n <= 0 || h < 4 || w < 4 || cgy <= 0 || cgx <= 0 || cgy % 64 || cgx % 8) return bad("reflect_ring: needs H, W >= 4, Cgy % 64 == 0, Cgx % 8 == 0");
+    if (!a16(gy) || !a16(t_hi) || !a16(ring) || !a16(gx)) return bad("reflect_ring: pointers must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = vqseg::launch_reflect_ring(gy, static_cast<const unsigned short*>(t_hi), ring, n, h, w, cgy, cgx, st);
+    if (e != hipSuccess) return hipfail(e, "reflect ring convolution");
+    e = vqseg::launch_reflect_ring_fold(1, ring, n, h, w, cgx, gx, st);
+    return e == hipSuccess ? 0 : hipfail(e, "reflect_ring_fold");
+}
+
 int vqseg_conv_pack_weights_s3_f32(const float* w, int cout, int cin, int c1, int kh, int kw, void* out, void* stream) {
     if (!w || !out || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || c1 <= 0 || c1 > cin || cin % 32 || c1 % 32)
         return bad("conv_pack_weights_s3: bad argument (Cin and the concat split must be multiples of 32)");

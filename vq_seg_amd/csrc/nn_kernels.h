@@ -36,6 +36,7 @@ hipError_t launch_s3_merge(const void* x, long rows, int C, float* y, hipStream_
 hipError_t launch_s3_maxpool(const void* x, int N, int H, int W, int C, void* y, hipStream_t st);
 hipError_t launch_s3_bilinear(const void* x, int N, int H, int W, int C, int Ho, int Wo, int align, void* y, hipStream_t st);
 hipError_t launch_reflect_fold(int bf16, const void* gp, int N, int H, int W, int C, void* gx, hipStream_t st);
+hipError_t launch_reflect_ring_fold(int bf16, const void* ring, int N, int H, int W, int C, void* gx, hipStream_t st);
 hipError_t launch_cast(int to_bf16, const void* x, long n, void* y, hipStream_t st);
 
 }  // namespace vqseg

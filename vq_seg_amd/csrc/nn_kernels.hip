@@ -1446,6 +1446,53 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const T* __restrict__
     }
 }
 
+// gradient of reflect padding (pad 1) when only the border RING of the padded gradient was computed (conv ring mode): gx [N, H, W, C]
+// already holds the padded gradient's interior (= the zero-padded data gradient); the pixels of rows 1 / H-2 and columns 1 / W-2
+// gather the ring positions that reflect onto them.  ring [N][2 (W + 2) + 2 H][C]: top row, bottom row, left column, right column.
+template <typename T, int VC>
+__global__ __launch_bounds__(256) void reflect_ring_fold_kernel(const T* __restrict__ ring, int N, int H, int W, int C, T* __restrict__ gx) {
+    constexpr int V = VecN<T>::N;
+    const int cv = C / VC;
+    const int Hp = H + 2, Wp = W + 2, rl = 2 * Wp + 2 * H, nb = 2 * W + 2 * (H - 2);      // border pixels of gx that receive something
+    const long total = (long)N * nb * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv) * VC;
+        long t = i / cv;
+        const int b = (int)(t % nb);
+        const int n = (int)(t / nb);
+        int h, w;
+        if (b < W) h = 1, w = b;
+        else if (b < 2 * W) h = H - 2, w = b - W;
+        else {                                              // columns 1 and W-2 of the rows other than 1 and H-2
+            const int q = b - 2 * W, half = H - 2;
+            int r = q < half ? q : q - half;                // index among the rows {0, 2, 3, ..., H-3, H-1}
+            h = r == 0 ? 0 : (r == half - 1 ? H - 1 : r + 1);
+            w = q < half ? 1 : W - 2;
+        }
+        int hs[3], ws[3], nh = 0, nw = 0;
+        hs[nh++] = h + 1;
+        if (h == 1) hs[nh++] = 0;
+        if (h == H - 2) hs[nh++] = Hp - 1;
+        ws[nw++] = w + 1;
+        if (w == 1) ws[nw++] = 0;
+        if (w == W - 2) ws[nw++] = Wp - 1;
+        float acc[V];
+        const long o = (((long)n * H + h) * W + w) * C + c;
+        ldc<T, VC>(gx, o, acc);
+        for (int a = 0; a < nh; ++a)
+            for (int bb = 0; bb < nw; ++bb) {
+                if (a == 0 && bb == 0) continue;           // the interior position itself: already in gx
+                const int pa = hs[a], pb = ws[bb];
+                const int q = pa == 0 ? pb : (pa == Hp - 1 ? Wp + pb : (pb == 0 ? 2 * Wp + pa - 1 : 2 * Wp + (Hp - 2) + pa - 1));
+                float v[V];
+                ldc<T, VC>(ring, ((long)n * rl + q) * C + c, v);
+#pragma unroll
+                for (int e = 0; e < VC; ++e) acc[e] += v[e];
+            }
+        stc<T, VC>(gx, o, acc);
+    }
+}
+
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, long n, TO* __restrict__ y) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = (TO)(float)x[i];
@@ -1738,6 +1785,18 @@ hipError_t launch_reflect_fold(int bf16, const void* gp, int N, int H, int W, in
     } else {
         if (C % 4 == 0) reflect_fold_t<float, 4>(gp, N, H, W, C, gx, st_);
         else reflect_fold_t<float, 1>(gp, N, H, W, C, gx, st_);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_reflect_ring_fold(int bf16, const void* ring, int N, int H, int W, int C, void* gx, hipStream_t st_) {
+    const long work = (long)N * (2 * W + 2 * (H - 2));
+    if (bf16) {
+        if (C % 8 == 0) hipLaunchKernelGGL((reflect_ring_fold_kernel<__bf16, 8>), dim3(grid_for(work * (C / 8))), dim3(256), 0, st_, (const __bf16*)ring, N, H, W, C, (__bf16*)gx);
+        else hipLaunchKernelGGL((reflect_ring_fold_kernel<__bf16, 1>), dim3(grid_for(work * C)), dim3(256), 0, st_, (const __bf16*)ring, N, H, W, C, (__bf16*)gx);
+    } else {
+        if (C % 4 == 0) hipLaunchKernelGGL((reflect_ring_fold_kernel<float, 4>), dim3(grid_for(work * (C / 4))), dim3(256), 0, st_, (const float*)ring, N, H, W, C, (float*)gx);
+        else hipLaunchKernelGGL((reflect_ring_fold_kernel<float, 1>), dim3(grid_for(work * C)), dim3(256), 0, st_, (const float*)ring, N, H, W, C, (float*)gx);
     }
     return hipGetLastError();
 }

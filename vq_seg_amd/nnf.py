@@ -681,6 +681,33 @@ class _ConvBNAct(torch.autograd.Function):
 
             def dgrad(c_lo, c_cnt):
                 nonlocal extra
+                # reflect padding, 3x3 / stride 1 (every Bottleneck conv2): the padded gradient's INTERIOR is the zero-padded data
+                # gradient (fast patch kernel, unpadded grid); only its border ring is evaluated as a full correlation and folded
+                # onto rows 1 / H-2 and columns 1 / W-2 (vqseg_reflect_ring_f) -- no (H+2) x (W+2) tensor, no fold pass over it
+                ring = (reflect and stride == 1 and kh == 3 and kw == 3 and pad == 1 and bf and x2r is None and cout % 64 == 0
+                        and c_cnt % 8 == 0 and h >= 4 and w >= 4 and py_opt("py_reflect_ring", 1) == 1)
+                if ring:
+                    gp = None
+                    if extra is not None and extra.shape == (n, h, w, c_cnt):
+                        one, zero = _unit_affine(dev, c_cnt)
+                        gp = torch.empty((n, h, w, c_cnt), dtype=g_y.dtype, device=dev)
+                        with _hip.on_device(dev):
+                            tneed = c_cnt * 9 * ((cout + 31) // 32 * 32)
+                            _check(L.vqseg_conv2d_affine_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), None, cout,
+                                                           _w16(t_hi, "transposed image", tneed), None, _f32(one, "unit scale", c_cnt),
+                                                           _f32(zero, "zero shift", c_cnt), _T(extra, "shortcut gradient", bf=bf, numel=n * h * w * c_cnt), 0,
+                                                           _T(gp, "input gradient", bf=bf, numel=n * h * w * c_cnt), n, ho, wo, cout, c_cnt,
+                                                           3, 3, 1, 1, 0, h, w, 0, _stream()), "vqseg_conv2d_affine_f")
+                        extra = None
+                    else:
+                        gp = _conv_raw(g_y, None, cout, t_hi, t_lo, (n, h, w, c_cnt), None, n, ho, wo, cout, c_cnt, 3, 3, 1, 1, False, 1, h, w)
+                    rbuf = torch.empty((n, 2 * (w + 2) + 2 * h, c_cnt), dtype=g_y.dtype, device=dev)
+                    with _hip.on_device(dev):
+                        _check(L.vqseg_reflect_ring_f(_T(g_y, "conv output gradient", bf=1, numel=m * cout),
+                                                      _w16(t_hi, "transposed image", c_cnt * 9 * ((cout + 31) // 32 * 32)),
+                                                      _T(rbuf, "gradient ring", bf=1, numel=rbuf.numel()), _T(gp, "input gradient", bf=1, numel=n * h * w * c_cnt),
+                                                      n, h, w, cout, c_cnt, _stream()), "vqseg_reflect_ring_f")
+                    return gp
                 if extra is not None and not reflect and stride == 1 and x2r is None and extra.shape == (n, hp, wp, c_cnt):
                     # the data gradient and the residual-branch gradient meet in the convolution's epilogue (one add pass less)
                     one, zero = _unit_affine(dev, c_cnt)
