@@ -175,6 +175,26 @@ def pmc_traffic(shapes):
     return {}, None
 
 
+def pmc_traffic_filter(shapes):
+    """HBM bytes per grouped launch of the bf16 candidate filter's three kernels from the same committed summary (its "bf16_filter"
+    table, keyed by kernel and grid) -> (bytes or None, {kernel: bytes}, source)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_vq_assign_pmc.json")))
+    if not files:
+        return None, {}, None
+    table = json.load(open(files[-1])).get("bf16_filter", {})
+    fend = sum(((n + 127) // 128 + 7) // 8 * 8 * (k // 256) for n, _c, k in shapes)
+    rend = sum((n + 255) // 256 for n, _c, k in shapes)
+    send = sum(min(max((n // 256 + 63) // 64, 4), 16) * 64 for n, _c, k in shapes)
+    parts = {}
+    for kern, wgs in (("vq_filter_bf16_kernel", fend), ("vq_resolve_kernel", rend), ("vq_rescore_kernel", send)):
+        e = table.get(f"{kern}_WG{wgs}")
+        if e is None:
+            return None, {}, None
+        parts[kern] = round(e["hbm_bytes"])
+    return sum(parts.values()), parts, os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
+
+
 def vq_per_level(device, group, bf16_rows=True, reps=10):
     """Each level of the grouped launch ALONE (its own launch of the same kernel, in-stream events, outside the timed region): the
     grouped launch's time cannot be split by level, so the per-shape rates are measured, not apportioned."""
@@ -533,6 +553,7 @@ def main():
             alg_b = sum(n * (c * 2.0 + 8) for n, c, k in grp_f)
             tf_alg, tf_exe = alg_fl / (ms_f * 1e-3) / 1e12, exe_fl / (ms_f * 1e-3) / 1e12
             gbs = alg_b * nl_f / (ms_f * 1e-3) / 1e9
+            tr_f, tr_parts, tr_src = pmc_traffic_filter(grp_f)
             roof_f = {"kernel": "vq_filter_bf16_kernel + vq_resolve_kernel + vq_rescore_kernel (bf16 rows: bf16-MFMA candidate filter, exact "
                                 "fmaf-chain re-score of the candidates; indices and distances identical to vq_assign_f32_kernel)",
                       "bound": "mfma", "achieved": round(tf_exe, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -541,7 +562,8 @@ def main():
                       "vs_fp32_mfma_peak": round(tf_alg / FP32_MFMA_PEAK_TFLOPS, 3),
                       "other_roof": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                      "algorithmic_bytes_per_launch": round(alg_b)},
-                      "traffic": None, "launches": nl_f, "levels_per_launch": len(grp_f), "avg_launch_us": round(ms_f / max(nl_f, 1) * 1e3, 2),
+                      "traffic": tr_f, "traffic_by_kernel": tr_parts, "traffic_source": tr_src,
+                      "launches": nl_f, "levels_per_launch": len(grp_f), "avg_launch_us": round(ms_f / max(nl_f, 1) * 1e3, 2),
                       "note": "HIP-event time from the filter kernel's launch to the end of the re-score (three kernels), all launches inside the "
                               "timed region; achieved = EXECUTED bf16 flops (2 x 2*N*K*C: the codebook's hi and lo parts) against the dense bf16 "
                               "MFMA peak, algorithmic_tflops = 2*N*K*C / time (what the exact kernel is measured by: SURVEY 8d's per-row figure); "
