@@ -270,13 +270,13 @@ def launch_ranks(n: int) -> int:
     if not rehearsal:
         # the launcher never asks the HIP runtime anything: the GPUs are counted from the KFD topology (sysfs); a node that shows
         # fewer is reported here, anything else by the ranks themselves
-        have = 0
-        try:
-            for node in os.listdir("/sys/class/kfd/kfd/topology/nodes"):
-                with open(f"/sys/class/kfd/kfd/topology/nodes/{node}/properties") as f:
+        have, topo = 0, "/sys/class/kfd/kfd/topology/nodes"
+        for node in (os.listdir(topo) if os.path.isdir(topo) else []):      # no KFD topology = no amdgpu driver = no GPU
+            try:
+                with open(f"{topo}/{node}/properties") as f:
                     have += any(line.startswith("simd_count") and int(line.split()[1]) > 0 for line in f)
-        except OSError:
-            have = n                                           # no sysfs view: let the ranks find out
+            except (OSError, ValueError, IndexError):
+                have += 1                                      # an unreadable node: count it, the ranks will find out
         if have < n:
             print(f"bench.py: --gpus {n} but this node shows {have} GPU(s); set VQSEG_DIST_REHEARSAL=1 for the one-GPU gloo rehearsal "
                   f"of the N > 1 path", file=sys.stderr)
