@@ -142,6 +142,9 @@ constexpr int ROWS_PER_WG = ROWS_PER_WAVE * WAVES;
 #ifndef VQ_BIG_STAGE
 #define VQ_BIG_STAGE 0
 #endif
+#ifndef VQ_SHAPE16
+#define VQ_SHAPE16 0              // 1: timing-only experiment build (wrong results), see mfma_block
+#endif
 // floats per LDS stage = BK * 32T: 16 KiB, or (VQ_BIG_STAGE, wide workgroups) 32 KiB = half as many barriers
 constexpr int stage_floats(int T) { return (VQ_BIG_STAGE && T >= 4) ? 8192 : 4096; }
 
@@ -288,8 +291,21 @@ __global__ __launch_bounds__(256, 2) void vq_assign_f32_kernel(const VqGroup g) 
         for (int e = 0; e < 4; ++e) {
             const float a = a_cur[j][e];
             xn_part = __builtin_fmaf(a, a, xn_part);
+#if VQ_SHAPE16
+            // TIMING EXPERIMENT ONLY (results garbage; VERDICT r3 item 2 ii): the same flops as one 32x32x2 per (e, t) issued as TWO
+            // v_mfma_f32_16x16x4_f32 on quarters of the accumulator tile, inside the real kernel -- does the chip hold another clock?
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                f32x4 q0 = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]}, q1 = {acc[t][8], acc[t][9], acc[t][10], acc[t][11]};
+                q0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b_cur[t][e], q0, 0, 0, 0);
+                q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b_cur[t][e], q1, 0, 0, 0);
+                acc[t][0] = q0[0], acc[t][1] = q0[1], acc[t][2] = q0[2], acc[t][3] = q0[3];
+                acc[t][8] = q1[0], acc[t][9] = q1[1], acc[t][10] = q1[2], acc[t][11] = q1[3];
+            }
+#else
 #pragma unroll
             for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b_cur[t][e], acc[t], 0, 0, 0);
+#endif
         }
         // issue order: one LDS read per four MFMAs (the reads belong to the NEXT block and are never waited on here)
 #pragma unroll
