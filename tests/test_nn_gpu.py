@@ -328,6 +328,50 @@ def test_wgrad3x3_fused_taps(case):
     assert rel(gw, 2 * ref) < 2e-5
 
 
+WGRAD_S2_CASES = [
+    # n, cin, cout, h, w (input size; output h / 2, w / 2), reflect, second source (two-use launch)
+    (2, 128, 128, 32, 32, True, False), (3, 64, 128, 8, 64, False, False), (1, 96, 256, 12, 32, True, False),
+    (2, 256, 128, 4, 32, False, True), (3, 128, 256, 16, 32, True, True),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_S2_CASES)
+def test_wgrad3x3_stride2_fused_taps(case):
+    """Stride-2 3x3 layers (first conv2 of a Bottleneck stage, first conv1 of a BasicBlock stage) on the nine-tap kernel (r4: 2 x 16
+    output blocks, the 5 x 33 input patch de-interleaved into column-parity planes by the DMA): fp64 reference on the same bf16 values,
+    2e-5 of the tensor scale; and the r3 per-tap kernel (option off) agrees with the same reference."""
+    from vq_seg_amd import _hip
+    n, cin, cout, h, w, reflect, pair = case
+    ho, wo = h // 2, w // 2
+    L = _hip.lib()
+    seed = sum(case[:5]) + 11
+    x = synth.uniform(seed, (n, h, w, cin), -1, 1).bfloat16()
+    gy = synth.uniform(seed + 1, (n, ho, wo, cout), -1, 1).bfloat16()
+    xp = F.pad(x.double().permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect" if reflect else "constant")
+    ref = torch.nn.grad.conv2d_weight(xp, (cout, cin, 3, 3), gy.double().permute(0, 3, 1, 2), stride=2)
+    xd, gyd = x.to(dev()), gy.to(dev())
+    nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, 3, 3)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    st = torch.cuda.current_stream().cuda_stream
+    for opt in (1, 0):
+        prev = _hip.set_option("conv_wgrad3x3_stride2", opt)
+        try:
+            gw = torch.full((cout, cin, 3, 3), float("nan"), dtype=torch.float32, device=dev())
+            if pair:                                    # images [0, na) from the first source, the rest from the second
+                na = 1
+                rc = L.vqseg_conv2d_wgrad2_f(gyd[:na].data_ptr(), xd[:na].data_ptr(), None, na, gyd[na:].data_ptr(), xd[na:].data_ptr(), None,
+                                             n - na, cin, h, w, cin, ho, wo, cout, 3, 3, 2, 1, int(reflect), 0, cin, 0, 0,
+                                             ws.data_ptr(), nbytes, gw.data_ptr(), st)
+            else:
+                rc = L.vqseg_conv2d_wgrad_f(gyd.data_ptr(), xd.data_ptr(), None, cin, n, h, w, cin, ho, wo, cout, 3, 3, 2, 1, int(reflect),
+                                            0, cin, 0, 0, ws.data_ptr(), nbytes, gw.data_ptr(), st)
+            assert rc == 0, L.vqseg_last_error()
+            torch.cuda.synchronize()
+            assert rel(gw, ref) < 2e-5, opt
+        finally:
+            _hip.set_option("conv_wgrad3x3_stride2", prev)
+
+
 WGRAD1_CASES = [
     # n, cin, cout, h, w, stride   (every tile config of the 1x1 weight-gradient kernel; ragged pixel counts; stride 2)
     (2, 128, 256, 16, 16, 1), (3, 64, 256, 9, 7, 1), (2, 128, 128, 8, 24, 1), (1, 64, 128, 20, 20, 1), (2, 256, 64, 12, 12, 1),

@@ -1116,11 +1116,17 @@ static int g_patch_tile512 = 2;                             // 512-pixel tiles f
 static int g_patch_tile512_min_wgs = 512;
 static int g_patch_tile512_launches = 0;                    // launches that took a 512-pixel tile (tests read it to see the dispatch)
 static int g_patch_unroll = 1;                              // 128-channel tile: tap loop unrolled
+static int g_wgrad3x3_s2 = 1;                               // stride-2 3x3 weight gradients on the nine-tap kernel (0: the per-tap kernel, r3)
 
 int conv_set_option(const char* key, int value) {
     if (key && !strcmp(key, "conv3x3_patch_min_workgroups")) {
         const int prev = g_patch_min_wgs;
         g_patch_min_wgs = value;
+        return prev;
+    }
+    if (key && !strcmp(key, "conv_wgrad3x3_stride2")) {
+        const int prev = g_wgrad3x3_s2;
+        g_wgrad3x3_s2 = value;
         return prev;
     }
     if (key && !strcmp(key, "conv_short_k_small_tile")) {
@@ -1974,19 +1980,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // Waves split (ci tile) x (co pair) x (tap range); a wave keeps its G fragments for all its taps.
 // Output: the same per-slab fp32 partials [z][Cout][9][Cin] as the per-tap kernel (fixed-order reduction).
 // =====================================================================================================
-template <int COT, int CIT>
+// S = 2 (r4): the stride-2 layers (first conv2 of a Bottleneck stage / first conv1 of a BasicBlock stage) ran on the per-tap kernel at
+// 6-8 % MFMA busy and 3-4 x the algorithmic bytes (r04_conv_weak_layers_pmc.md).  Same machinery with a 2 x 16 output block and its
+// 5 x 33 input patch; the DMA de-interleaves the patch columns into an even plane (17 pixels) and an odd plane (16) per patch row, so
+// a tap's 16 input pixels (columns 2 ow + kw - 1) are again CONSECUTIVE patch pixels: kw = 0 / 2 read the even plane at ow / ow + 1,
+// kw = 1 the odd plane at ow.
+template <int COT, int CIT, int S = 1>
 struct Wg3 {
+    static constexpr int BH = S == 1 ? 4 : 2;               // output rows of a block (16 columns): one MFMA K step per row
+    static constexpr int PR = S * BH + 3 - S, PC = S * 16 + 3 - S, NPATCH = PR * PC;   // patch rows / columns / pixels (halo included)
     static constexpr int PM = COT >= 2 ? 2 : 1;             // co tiles per wave
     static constexpr int WO = COT / PM, WC = CIT;            // wave groups over co pairs / ci tiles
     static constexpr int NW = (COT == 4 && CIT == 2) ? 8 : 4;
     static constexpr int WT = NW / (WO * WC);                // wave groups over taps
     static constexpr int NTM = (9 + WT - 1) / WT;            // taps per wave (upper bound)
     static constexpr int RBG = COT * 64, RBA = CIT * 64;     // row bytes of the GY tile / the patch
-    static constexpr int G_INSTR = 64 * RBG / 1024;          // 1 KB DMA wave-instructions for the GY tile
+    static constexpr int G_INSTR = BH * 16 * RBG / 1024;     // 1 KB DMA wave-instructions for the GY tile
     static constexpr int G_PER = G_INSTR / NW;
-    static constexpr int P_INSTR = (108 * RBA + 1023) / 1024;
+    static constexpr int P_INSTR = (NPATCH * RBA + 1023) / 1024;
     static constexpr int P_PER = (P_INSTR + NW - 1) / NW;    // every wave issues the same count (counted vmcnt)
-    static constexpr int G_BYTES = 64 * RBG, P_BYTES = P_PER * NW * 1024;
+    static constexpr int G_BYTES = BH * 16 * RBG, P_BYTES = P_PER * NW * 1024;
     static constexpr int STAGE = G_BYTES + P_BYTES;
     static constexpr int NBUF = 3;
     static_assert(G_INSTR % NW == 0, "GY tile must split evenly over the waves");
@@ -2012,9 +2025,9 @@ __device__ __forceinline__ bf16x8 tr_frag_swz(const char* tile, int pix0, int co
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int COT, int CIT>
-__global__ __launch_bounds__((Wg3<COT, CIT>::NW * 64)) void conv_wgrad3x3_kernel(const WgradArgs p, int blocks_per_slab) {
-    using C = Wg3<COT, CIT>;
+template <int COT, int CIT, int S = 1>
+__global__ __launch_bounds__((Wg3<COT, CIT, S>::NW * 64)) void conv_wgrad3x3_kernel(const WgradArgs p, int blocks_per_slab) {
+    using C = Wg3<COT, CIT, S>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2022,7 +2035,7 @@ __global__ __launch_bounds__((Wg3<COT, CIT>::NW * 64)) void conv_wgrad3x3_kernel
     const int t0 = (9 * wt + C::WT - 1) / C::WT, t1 = (9 * (wt + 1) + C::WT - 1) / C::WT;
 
     const int ci0 = blockIdx.x * (32 * CIT), co0 = blockIdx.y * (32 * COT);
-    const int bw = p.Wo >> 4, bh = p.Ho >> 2;
+    const int bw = p.Wo >> 4, bh = p.Ho / C::BH;
     const int n_blk = p.N * bh * bw;
     const int b_begin = blockIdx.z * blocks_per_slab;
     int b_end = b_begin + blocks_per_slab;
@@ -2043,7 +2056,7 @@ __global__ __launch_bounds__((Wg3<COT, CIT>::NW * 64)) void conv_wgrad3x3_kernel
 #pragma unroll
     for (int i = 0; i < C::G_PER; ++i) {
         const int j = wave + C::NW * i;
-        const int bp = j * (1024 / C::RBG) + (lane * 16) / C::RBG;          // block pixel 0..63
+        const int bp = j * (1024 / C::RBG) + (lane * 16) / C::RBG;          // block pixel 0..16 BH - 1
         const int slot = lane & (C::RBG / 16 - 1);
         const int chunk = slot ^ swz_chunk<C::RBG>(bp);
         g_rel[i] = ((bp >> 4) * p.Wo + (bp & 15)) * p.Cout + co0 + chunk * 8;
@@ -2052,12 +2065,14 @@ __global__ __launch_bounds__((Wg3<COT, CIT>::NW * 64)) void conv_wgrad3x3_kernel
 #pragma unroll
     for (int i = 0; i < C::P_PER; ++i) {
         const int j = wave + C::NW * i;
-        const int pp = j * (1024 / C::RBA) + (lane * 16) / C::RBA;          // patch pixel 0..107 (beyond: zero page)
+        const int pp = j * (1024 / C::RBA) + (lane * 16) / C::RBA;          // patch pixel 0..NPATCH - 1 (beyond: zero page)
         const int slot = lane & (C::RBA / 16 - 1);
         const int chunk = slot ^ swz_chunk<C::RBA>(pp);
-        const int pr = pp / 18;
-        p_dr[i] = pp < 108 ? pr - 1 : -(1 << 20);
-        p_dc[i] = pp - 18 * pr - 1;
+        const int pr = pp / C::PC;
+        const int q = pp - C::PC * pr;                                      // position inside the LDS patch row
+        const int pc = S == 1 ? q : (q < 17 ? 2 * q : 2 * (q - 17) + 1);   // S = 2: even plane first, then the odd plane
+        p_dr[i] = pp < C::NPATCH ? pr - 1 : -(1 << 20);
+        p_dc[i] = pc - 1;
         p_ch[i] = cbase + chunk * 8;
     }
 
@@ -2065,7 +2080,8 @@ __global__ __launch_bounds__((Wg3<COT, CIT>::NW * 64)) void conv_wgrad3x3_kernel
 #pragma unroll
     for (int t = 0; t < C::NTM; ++t) {
         const int tap = t0 + t < 9 ? t0 + t : 8;
-        toff[t] = (tap / 3) * 18 + tap % 3;
+        const int kw = tap % 3;
+        toff[t] = (tap / 3) * C::PC + (S == 1 ? kw : (kw == 1 ? 17 : kw >> 1));
     }
 
     f32x16 acc[C::PM][C::NTM];
@@ -2084,7 +2100,7 @@ __global__ __launch_bounds__((Wg3<COT, CIT>::NW * 64)) void conv_wgrad3x3_kernel
     auto stage = [&](int buf) {
         char* Gs = smem + buf * C::STAGE;
         char* Ps = Gs + C::G_BYTES;
-        const int oh0 = iby * 4, ow0 = ibx * 16;
+        const int oh0 = iby * C::BH, ow0 = ibx * 16;
         const bool sb = in_ >= p.Na;                        // wave-uniform: the block's image belongs to the second source
         const int img = sb ? in_ - p.Na : in_;
         const char* gsrc = sb ? gsrc_b : gsrc_a;
@@ -2094,7 +2110,7 @@ __global__ __launch_bounds__((Wg3<COT, CIT>::NW * 64)) void conv_wgrad3x3_kernel
         for (int i = 0; i < C::G_PER; ++i) glds16(gsrc + (gbase + g_rel[i]) * 2, Gs + (wave + C::NW * i) * 1024);
 #pragma unroll
         for (int i = 0; i < C::P_PER; ++i) {
-            int ih = oh0 + p_dr[i], iw = ow0 + p_dc[i];
+            int ih = S * oh0 + p_dr[i], iw = S * ow0 + p_dc[i];
             if (p.reflect) {
                 if (ih > -(1 << 19)) ih = reflect_idx(ih, p.H);
                 iw = reflect_idx(iw, p.W);
@@ -2116,14 +2132,14 @@ __global__ __launch_bounds__((Wg3<COT, CIT>::NW * 64)) void conv_wgrad3x3_kernel
         const char* Gs = smem + buf * C::STAGE;
         const char* Ps = Gs + C::G_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {                   // block row kk = 16 pixels = one MFMA K step
+        for (int kk = 0; kk < C::BH; ++kk) {               // block row kk = 16 pixels = one MFMA K step
             bf16x8 gf[C::PM];
 #pragma unroll
             for (int a = 0; a < C::PM; ++a) gf[a] = tr_frag_swz<C::RBG>(Gs, kk * 16, (wo * C::PM + a) * 32, lane);
 #pragma unroll
             for (int t = 0; t < C::NTM; ++t) {
                 if (t0 + t < t1) {                          // wave-uniform
-                    const bf16x8 af = tr_frag_swz<C::RBA>(Ps, kk * 18 + toff[t], wc * 32, lane);
+                    const bf16x8 af = tr_frag_swz<C::RBA>(Ps, kk * S * C::PC + toff[t], wc * 32, lane);
 #pragma unroll
                     for (int a = 0; a < C::PM; ++a)
                         acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[a], af, acc[a][t], 0, 0, 0);
@@ -2403,13 +2419,15 @@ static void wgrad1x1_launch_t(const WgradArgs& a, const Wg1Plan& pl, hipStream_t
 
 struct Wg3Plan {
     int cot, cit, slabs, blocks_per_slab;                  // cot == 0: not eligible
+    int stride;
 };
 
 static Wg3Plan wgrad3x3_plan(const WgradArgs& a, int precise, bool shape_only, int force_cit = 0) {
-    Wg3Plan pl{0, 0, 0, 0};
-    if (precise || a.per_tap_only || a.KH != 3 || a.KW != 3 || a.Ho != a.H || a.Wo != a.W || a.Ho % 4 || a.Wo % 16 || a.Cout % 32 || a.Cin % 32)
-        return pl;
-    if (!shape_only && (a.stride != 1 || a.pad != 1)) return pl;
+    Wg3Plan pl{0, 0, 0, 0, 1};
+    const bool s2 = g_wgrad3x3_s2 && a.H == 2 * a.Ho && a.W == 2 * a.Wo;       // stride 2 (pad 1): Cout % 128 only (COT = 4)
+    if (precise || a.per_tap_only || a.KH != 3 || a.KW != 3 || a.Cout % 32 || a.Cin % 32 || a.Wo % 16) return pl;
+    if (s2 ? (a.Ho % 2 || a.Cout % 128) : (a.Ho != a.H || a.Wo != a.W || a.Ho % 4)) return pl;
+    if (!shape_only && (a.stride != (s2 ? 2 : 1) || a.pad != 1)) return pl;
     int cit = (a.Cin % 64 == 0 && force_cit != 1) ? 2 : 1;
     if (!shape_only && a.C1 != a.Cin && a.C1 % (32 * cit)) {
         if (a.C1 % 32) return pl;
@@ -2417,18 +2435,19 @@ static Wg3Plan wgrad3x3_plan(const WgradArgs& a, int precise, bool shape_only, i
     }
     const int cot = a.Cout % 128 == 0 ? 4 : (a.Cout % 64 == 0 ? 2 : 1);
     const long tiles = (long)(a.Cin / (32 * cit)) * (a.Cout / (32 * cot));
-    const long n_blk = (long)a.N * (a.Ho / 4) * (a.Wo / 16);
+    const long n_blk = (long)a.N * (a.Ho / (s2 ? 2 : 4)) * (a.Wo / 16);
     if (n_blk > (1L << 30)) return pl;
     // every workgroup writes its whole (co x ci x 9) fp32 tile once, so the partial volume is (#workgroups x tile
     // bytes) whatever the layer: one resident round of workgroups is the cheapest split
     const long target = (cot == 4 && cit == 2) ? 256 : 512;
     long s = (target + tiles - 1) / tiles;
-    const long max_s = (n_blk + 7) / 8;                     // at least 8 blocks (512 pixels) per slab
+    const long max_s = s2 ? (n_blk + 15) / 16 : (n_blk + 7) / 8;   // at least 512 pixels per slab
     if (s > max_s) s = max_s;
     if (s > 256) s = 256;
     if (s < 1) s = 1;
     const long bps = (n_blk + s - 1) / s;
     s = (n_blk + bps - 1) / bps;                            // no empty slabs
+    pl.stride = s2 ? 2 : 1;
     pl.cot = cot;
     pl.cit = cit;
     pl.slabs = (int)s;
@@ -2436,11 +2455,11 @@ static Wg3Plan wgrad3x3_plan(const WgradArgs& a, int precise, bool shape_only, i
     return pl;
 }
 
-template <int COT, int CIT>
+template <int COT, int CIT, int S = 1>
 static void wgrad3x3_launch_t(const WgradArgs& a, const Wg3Plan& pl, hipStream_t st) {
-    using C = Wg3<COT, CIT>;
+    using C = Wg3<COT, CIT, S>;
     dim3 grid((unsigned)(a.Cin / (32 * CIT)), (unsigned)(a.Cout / (32 * COT)), (unsigned)pl.slabs);
-    hipLaunchKernelGGL((conv_wgrad3x3_kernel<COT, CIT>), grid, dim3(C::NW * 64), (size_t)C::NBUF * C::STAGE, st, a, pl.blocks_per_slab);
+    hipLaunchKernelGGL((conv_wgrad3x3_kernel<COT, CIT, S>), grid, dim3(C::NW * 64), (size_t)C::NBUF * C::STAGE, st, a, pl.blocks_per_slab);
 }
 
 template <int TM, int TN, bool PRECISE>
@@ -2511,6 +2530,11 @@ hipError_t launch_wgrad(const WgradArgs& a, int precise, int slabs, int* final_l
 static hipError_t launch_wgrad_impl(const WgradArgs& a, int precise, int slabs, int* final_layout, hipStream_t st) {
     const Wg3Plan pl = wgrad3x3_plan(a, precise, false);
     *final_layout = pl.cot ? 1 : 0;                          // 1: slabs already are [Cout][Cin][KH][KW]
+    if (pl.cot && pl.stride == 2) {
+        if (pl.cit == 2) wgrad3x3_launch_t<4, 2, 2>(a, pl, st);
+        else wgrad3x3_launch_t<4, 1, 2>(a, pl, st);
+        return hipGetLastError();
+    }
     if (pl.cot) {
 #define WG3_CASE(COT_, CIT_) \
     if (pl.cot == COT_ && pl.cit == CIT_) wgrad3x3_launch_t<COT_, CIT_>(a, pl, st);
