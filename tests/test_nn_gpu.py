@@ -376,6 +376,7 @@ WGRAD1_CASES = [
     # n, cin, cout, h, w, stride   (every tile config of the 1x1 weight-gradient kernel; ragged pixel counts; stride 2)
     (2, 128, 256, 16, 16, 1), (3, 64, 256, 9, 7, 1), (2, 128, 128, 8, 24, 1), (1, 64, 128, 20, 20, 1), (2, 256, 64, 12, 12, 1),
     (2, 256, 512, 16, 16, 2), (1, 128, 256, 15, 9, 2), (4, 1024, 256, 8, 8, 1),
+    (2, 64, 64, 16, 16, 1), (3, 64, 64, 9, 7, 1), (2, 192, 64, 12, 20, 1),      # r4: 64 output channels on four waves (<2, 2>)
 ]
 
 
@@ -401,6 +402,41 @@ def test_wgrad1x1(case):
         assert rc == 0, L.vqseg_last_error()
         torch.cuda.synchronize()
         assert rel(gw, (1 + acc) * ref) < 2e-5
+
+
+@pytest.mark.parametrize("pair", [False, True])
+def test_wgrad_stem_patch_matrix(pair):
+    """The stem's weight gradient = a 1x1 weight gradient over its im2col patch matrix ([rows][160 columns = (kh, kw, ci) padded]).
+    r4: all 160 columns in ONE ten-wave workgroup of the LDS-DMA kernel (<2, 5>, 320-byte rows) instead of five 32-column tiles of the
+    per-tap kernel; fp64 reference on the same bf16 values, 2e-5 of the scale; the per-tap kernel (option off) meets the same bar."""
+    from vq_seg_amd import _hip
+    n, ho, wo, cout, kp = 3, 10, 13, 64, 160                # ragged row count: 390 rows = 6 stages + 6 rows
+    L = _hip.lib()
+    pm = synth.uniform(31, (n, ho, wo, kp), -1, 1).bfloat16()
+    pm[..., 147:] = 0                                       # the padding columns of a real patch matrix
+    gy = synth.uniform(32, (n, ho, wo, cout), -1, 1).bfloat16()
+    full = gy.double().reshape(-1, cout).t() @ pm.double().reshape(-1, kp)           # [co][(kh, kw, ci)]
+    ref = full[:, :147].reshape(cout, 7, 7, 3).permute(0, 3, 1, 2).contiguous()
+    pmd, gyd = pm.to(dev()), gy.to(dev())
+    nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, ho, wo, kp, ho, wo, cout, 1, 1)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    st = torch.cuda.current_stream().cuda_stream
+    for opt in (1, 0):
+        prev = _hip.set_option("conv_wgrad1x1_narrow", opt)
+        try:
+            gw = torch.full((cout, 3, 7, 7), float("nan"), dtype=torch.float32, device=dev())
+            for acc in (0, 1):
+                if pair:
+                    rc = L.vqseg_conv2d_wgrad2_f(gyd[:2].data_ptr(), pmd[:2].data_ptr(), None, 2, gyd[2:].data_ptr(), pmd[2:].data_ptr(), None, 1,
+                                                 kp, ho, wo, kp, ho, wo, cout, 7, 7, 1, 0, 0, 0, 3, 1, acc, ws.data_ptr(), nbytes, gw.data_ptr(), st)
+                else:
+                    rc = L.vqseg_conv2d_wgrad_f(gyd.data_ptr(), pmd.data_ptr(), None, kp, n, ho, wo, kp, ho, wo, cout, 7, 7, 1, 0, 0, 0, 3, 1,
+                                                acc, ws.data_ptr(), nbytes, gw.data_ptr(), st)
+                assert rc == 0, L.vqseg_last_error()
+                torch.cuda.synchronize()
+                assert rel(gw, (1 + acc) * ref) < 2e-5, (opt, acc)
+        finally:
+            _hip.set_option("conv_wgrad1x1_narrow", prev)
 
 
 @pytest.mark.parametrize("mode", ["precise", "fast"])

@@ -12,6 +12,7 @@ dev = torch.device("cuda:0")
 LAYERS = {  # cin, c2 (concat), cout, k, stride, reflect, H
     "l1.conv2": (64, 0, 64, 3, 1, True, 128), "l2.0.conv2": (128, 0, 128, 3, 2, True, 128), "l3.0.conv2": (256, 0, 256, 3, 2, True, 64),
     "l4.0.conv2": (512, 0, 512, 3, 2, True, 32), "dec4.0": (128, 64, 32, 3, 1, False, 256), "dec4.1": (32, 0, 32, 3, 1, False, 256),
+    "stem": (3, 0, 64, 7, 2, True, 512), "l1.0.conv1": (64, 0, 64, 1, 1, True, 128),
 }
 name = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -24,9 +25,15 @@ for p in list(conv.parameters()) + list(bn.parameters()):
     p.grad = torch.zeros_like(p)
     p._vq_grad_sink = None
 x = torch.relu(torch.randn(B, cin, H, H, device=dev)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+if name == "stem":
+    x = torch.rand(B, 3, H, H, device=dev).contiguous(memory_format=torch.channels_last)
 x2 = torch.relu(torch.randn(B, c2, H, H, device=dev)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True) if c2 else None
 for i in range(reps + 1):
-    y = nnf.conv_bn_act(x, conv, bn, x2=x2)
+    if name == "stem":
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = nnf.stem_conv_bn_act(x, conv, bn)
+    else:
+        y = nnf.conv_bn_act(x, conv, bn, x2=x2)
     y.float().mean().backward()
     x.grad = None
     if x2 is not None:

@@ -1116,12 +1116,18 @@ static int g_patch_tile512 = 2;                             // 512-pixel tiles f
 static int g_patch_tile512_min_wgs = 512;
 static int g_patch_tile512_launches = 0;                    // launches that took a 512-pixel tile (tests read it to see the dispatch)
 static int g_patch_unroll = 1;                              // 128-channel tile: tap loop unrolled
+static int g_wgrad1x1_narrow = 1;                           // 64-output-channel 1x1 weight gradients (stem patch matrix, 64 -> 64) on the LDS-DMA kernel
 static int g_wgrad3x3_s2 = 1;                               // stride-2 3x3 weight gradients on the nine-tap kernel (0: the per-tap kernel, r3)
 
 int conv_set_option(const char* key, int value) {
     if (key && !strcmp(key, "conv3x3_patch_min_workgroups")) {
         const int prev = g_patch_min_wgs;
         g_patch_min_wgs = value;
+        return prev;
+    }
+    if (key && !strcmp(key, "conv_wgrad1x1_narrow")) {
+        const int prev = g_wgrad1x1_narrow;
+        g_wgrad1x1_narrow = value;
         return prev;
     }
     if (key && !strcmp(key, "conv_wgrad3x3_stride2")) {
@@ -2213,15 +2219,20 @@ __global__ __launch_bounds__((Wg3<COT, CIT, S>::NW * 64)) void conv_wgrad3x3_ker
 // =====================================================================================================
 template <int COT, int CIT>
 struct Wg1 {
-    static constexpr int NW = 8;
+    // 64-output-channel layers (r4): <2, 5> = the stem's patch matrix (160 columns: ALL of them in one workgroup, ten waves -- the
+    // per-tap kernel read GY once per 32-column tile, 2 GB for a 0.94 GB problem), <2, 2> = 64 -> 64 (four waves)
+    static constexpr int NW = (COT == 2 && CIT == 5) ? 10 : ((COT == 2 && CIT == 2) ? 4 : 8);
     static constexpr int WO = COT < 4 ? COT : 4, PM = COT / WO;   // wave groups over co, co tiles per wave
     static constexpr int WC = NW / WO, PN = CIT / WC;             // wave groups over ci, ci tiles per wave
     static constexpr int RBG = COT * 64, RBA = CIT * 64;         // row bytes
     static constexpr int G_BYTES = 64 * RBG, A_BYTES = 64 * RBA;
-    static constexpr int G_PER = G_BYTES / 1024 / NW, A_PER = (A_BYTES / 1024 + NW - 1) / NW;
-    static constexpr int STAGE = G_BYTES + A_PER * NW * 1024;
+    // every wave issues the same number of 1 KB DMA instructions (counted vmcnt); instructions beyond a tile read the zero page into
+    // the padding of its region
+    static constexpr int G_PER = (G_BYTES / 1024 + NW - 1) / NW, A_PER = (A_BYTES / 1024 + NW - 1) / NW;
+    static constexpr int G_REGION = G_PER * NW * 1024;
+    static constexpr int STAGE = G_REGION + A_PER * NW * 1024;
     static constexpr int NBUF = 3;
-    static_assert(WO * WC == NW && PN >= 1 && PM >= 1 && (G_BYTES / 1024) % NW == 0, "unsupported tile");
+    static_assert(WO * WC == NW && PN * WC == CIT && PM * WO == COT, "unsupported tile");
     static_assert(RBG <= 256 || RBG == 512, "GY rows: 64..256 B swizzle classes, or 512 B");
 };
 
@@ -2229,7 +2240,9 @@ struct Wg1 {
 // different 64-byte bank groups
 template <int RB>
 __device__ __forceinline__ int swz_chunk_w(int row) {
-    return RB >= 256 ? ((row & 3) << 2) : (RB == 128 ? (((row >> 1) & 1) << 2) : 0);
+    // 320-byte rows (the stem's 160 patch columns) need none: consecutive rows start 16 banks apart, the four 64-byte row segments
+    // of a half-wave's fragment read cover the 64 banks once
+    return RB == 320 ? 0 : (RB >= 256 ? ((row & 3) << 2) : (RB == 128 ? (((row >> 1) & 1) << 2) : 0));
 }
 template <int RB>
 __device__ __forceinline__ bf16x8 tr_frag_w(const char* tile, int pix0, int col0, int lane) {
@@ -2245,7 +2258,7 @@ __device__ __forceinline__ bf16x8 tr_frag_w(const char* tile, int pix0, int col0
 }
 
 template <int COT, int CIT>
-__global__ __launch_bounds__(512) void conv_wgrad1x1_kernel(const WgradArgs p, int stages_per_slab) {
+__global__ __launch_bounds__((Wg1<COT, CIT>::NW * 64)) void conv_wgrad1x1_kernel(const WgradArgs p, int stages_per_slab) {
     using C = Wg1<COT, CIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2270,7 +2283,7 @@ __global__ __launch_bounds__(512) void conv_wgrad1x1_kernel(const WgradArgs p, i
 #pragma unroll
     for (int i = 0; i < C::G_PER; ++i) {
         const int j = wave + C::NW * i;
-        g_row[i] = j * (1024 / C::RBG) + (lane * 16) / C::RBG;
+        g_row[i] = j * (1024 / C::RBG) + (lane * 16) / C::RBG;     // rows >= 64: instruction beyond the tile (zero page)
         const int slot = lane & (C::RBG / 16 - 1);
         g_col[i] = co0 + ((slot ^ swz_chunk_w<C::RBG>(g_row[i])) << 3);
     }
@@ -2279,8 +2292,9 @@ __global__ __launch_bounds__(512) void conv_wgrad1x1_kernel(const WgradArgs p, i
 #pragma unroll
     for (int i = 0; i < C::A_PER; ++i) {
         const int j = wave + C::NW * i;
-        a_row[i] = j * (1024 / C::RBA) + (lane * 16) / C::RBA;   // rows >= 64: instruction beyond the tile (zero page)
-        const int slot = lane & (C::RBA / 16 - 1);
+        const int byte = j * 1024 + lane * 16;                   // (rows need not divide 1 KB: 320-byte rows)
+        a_row[i] = byte / C::RBA;                                // rows >= 64: instruction beyond the tile (zero page)
+        const int slot = (byte - a_row[i] * C::RBA) >> 4;
         a_col[i] = ci0 + ((slot ^ swz_chunk_w<C::RBA>(a_row[i])) << 3);
         long m = s_begin * 64 + a_row[i];
         if (m >= M) m = M - 1;
@@ -2301,12 +2315,13 @@ __global__ __launch_bounds__(512) void conv_wgrad1x1_kernel(const WgradArgs p, i
     long issue_m0 = s_begin * 64;                          // first pixel row of the stage being issued
     auto stage = [&](int buf) {
         char* Gs = smem + buf * C::STAGE;
-        char* As = Gs + C::G_BYTES;
+        char* As = Gs + C::G_REGION;
 #pragma unroll
         for (int i = 0; i < C::G_PER; ++i) {
             const long m = issue_m0 + g_row[i];
             const bool sb = m >= Ma;
-            glds16(m < M ? (sb ? gsrc_b : gsrc_a) + ((sb ? m - Ma : m) * p.Cout + g_col[i]) * 2 : zero, Gs + (wave + C::NW * i) * 1024);
+            glds16(g_row[i] < 64 && m < M ? (sb ? gsrc_b : gsrc_a) + ((sb ? m - Ma : m) * p.Cout + g_col[i]) * 2 : zero,
+                   Gs + (wave + C::NW * i) * 1024);
         }
 #pragma unroll
         for (int i = 0; i < C::A_PER; ++i) {
@@ -2328,7 +2343,7 @@ __global__ __launch_bounds__(512) void conv_wgrad1x1_kernel(const WgradArgs p, i
     };
     auto compute = [&](int buf) {
         const char* Gs = smem + buf * C::STAGE;
-        const char* As = Gs + C::G_BYTES;
+        const char* As = Gs + C::G_REGION;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             bf16x8 gf[C::PM], af[C::PN];
@@ -2384,19 +2399,23 @@ struct Wg1Plan {
 
 static Wg1Plan wgrad1x1_plan(const WgradArgs& a, int precise, bool shape_only) {
     Wg1Plan pl{0, 0, 0, 0};
-    if (precise || a.per_tap_only || a.KH != 1 || a.KW != 1 || (!shape_only && a.C1 != a.Cin)) return pl;
+    if (precise || a.KH != 1 || a.KW != 1 || (!shape_only && a.C1 != a.Cin)) return pl;
     if (!shape_only && (a.pad != 0 || (a.stride != 1 && a.stride != 2))) return pl;
     int cot, cit;
-    if (a.Cout % 256 == 0 && a.Cin % 128 == 0) cot = 8, cit = 4;
+    if (a.per_tap_only) {                                   // the stem's patch matrix: 7 x 7 x 3 taps padded to 160 columns
+        if (!g_wgrad1x1_narrow || a.Cout % 64 || a.Cin != 160) return pl;
+        cot = 2, cit = 5;
+    } else if (a.Cout % 256 == 0 && a.Cin % 128 == 0) cot = 8, cit = 4;
     else if (a.Cout % 256 == 0 && a.Cin % 64 == 0) cot = 8, cit = 2;
     else if (a.Cout % 128 == 0 && a.Cin % 128 == 0) cot = 4, cit = 4;
     else if (a.Cout % 128 == 0 && a.Cin % 64 == 0) cot = 4, cit = 2;
     else if (a.Cout % 64 == 0 && a.Cin % 128 == 0) cot = 2, cit = 4;
+    else if (g_wgrad1x1_narrow && a.Cout % 64 == 0 && a.Cin % 64 == 0) cot = 2, cit = 2;
     else return pl;
     const long tiles = (long)(a.Cin / (32 * cit)) * (a.Cout / (32 * cot));
     const long n_stage = ((long)a.N * a.Ho * a.Wo + 63) / 64;
     if (n_stage > (1L << 30)) return pl;
-    long s = (256 + tiles - 1) / tiles;                     // one resident round of 8-wave workgroups
+    long s = ((cit == 2 && cot == 2 ? 768 : 256) + tiles - 1) / tiles;   // one resident round of workgroups (4-wave ones: three per CU)
     const long max_s = (n_stage + 3) / 4;                   // at least 4 stages (256 pixels) per slab
     if (s > max_s) s = max_s;
     if (s > 256) s = 256;
@@ -2414,7 +2433,7 @@ template <int COT, int CIT>
 static void wgrad1x1_launch_t(const WgradArgs& a, const Wg1Plan& pl, hipStream_t st) {
     using C = Wg1<COT, CIT>;
     dim3 grid((unsigned)(a.Cin / (32 * CIT)), (unsigned)(a.Cout / (32 * COT)), (unsigned)pl.slabs);
-    hipLaunchKernelGGL((conv_wgrad1x1_kernel<COT, CIT>), grid, dim3(512), (size_t)C::NBUF * C::STAGE, st, a, pl.stages_per_slab);
+    hipLaunchKernelGGL((conv_wgrad1x1_kernel<COT, CIT>), grid, dim3(C::NW * 64), (size_t)C::NBUF * C::STAGE, st, a, pl.stages_per_slab);
 }
 
 struct Wg3Plan {
@@ -2501,6 +2520,10 @@ int wgrad_slabs_max(const WgradArgs& a) {
     }
     const Wg1Plan p1 = wgrad1x1_plan(a, 0, true);
     if (p1.cot && p1.slabs > m) m = p1.slabs;
+    WgradArgs ap = a;                                       // the same shape as a patch matrix (the stem)
+    ap.per_tap_only = 1;
+    const Wg1Plan p2 = wgrad1x1_plan(ap, 0, true);
+    if (p2.cot && p2.slabs > m) m = p2.slabs;
     return m;
 }
 
@@ -2544,10 +2567,10 @@ static hipError_t launch_wgrad_impl(const WgradArgs& a, int precise, int slabs, 
     }
     const Wg1Plan p1 = wgrad1x1_plan(a, precise, false);
     if (p1.cot) {
-        *final_layout = 1;                                  // [Cout][Cin] == [Cout][Cin][1][1]
+        *final_layout = a.per_tap_only ? 0 : 1;             // [Cout][Cin] == [Cout][Cin][1][1]; a patch matrix: [Cout][1][columns], as the per-tap kernel
 #define WG1_CASE(COT_, CIT_) \
     if (p1.cot == COT_ && p1.cit == CIT_) wgrad1x1_launch_t<COT_, CIT_>(a, p1, st);
-        WG1_CASE(8, 4) WG1_CASE(8, 2) WG1_CASE(4, 4) WG1_CASE(4, 2) WG1_CASE(2, 4)
+        WG1_CASE(8, 4) WG1_CASE(8, 2) WG1_CASE(4, 4) WG1_CASE(4, 2) WG1_CASE(2, 4) WG1_CASE(2, 5) WG1_CASE(2, 2)
 #undef WG1_CASE
         return hipGetLastError();
     }
