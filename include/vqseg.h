@@ -64,6 +64,11 @@ const char* vqseg_kernel_name(const char* entry_point);
  *                                   measured equal; the kernel does not wait on HBM for its patches)
  *   "conv_short_k_small_tile", "conv_short_k_single_buffer"   K loops of up to that many 64-channel stages take the
  *                                   128x128 tile at 4 waves/SIMD, double- resp. single-buffered (defaults 1 and 8)
+ *   "conv_wgrad3x3_stride2"         1 (default): stride-2 3x3 weight gradients (Cout % 128 == 0, Wo % 16 == 0) on the nine-tap LDS-DMA
+ *                                   kernel (r4); 0: the per-tap kernel
+ *   "conv_wgrad1x1_narrow"          1 (default): 64-output-channel 1x1 weight gradients -- the stem's 160-column patch matrix, 64 -> 64
+ *                                   -- on the LDS-DMA kernel (r4); 0: the per-tap kernel
+ *   "im2col_strip"                  1 (default): the stem's patch matrix from LDS-staged strips (r4, bit-identical); 0: the gather kernel
  * The environment variable VQSEG_OPTS="key=value,..." applies options when the Python binding loads the library.
  * Returns the previous value, or VQSEG_EINVAL for an unknown key / negative value.  Not thread safe. */
 int vqseg_set_option(const char* key, int value);

@@ -404,6 +404,38 @@ def test_wgrad1x1(case):
         assert rel(gw, (1 + acc) * ref) < 2e-5
 
 
+@pytest.mark.parametrize("reflect", [True, False])
+@pytest.mark.parametrize("shape", [(2, 40, 36), (1, 8, 300), (3, 130, 128)])
+def test_stem_patch_matrix_strip_kernel_is_bit_identical_to_the_gather_kernel(shape, reflect):
+    """r4: the stem's im2col patch matrix from LDS-staged strips of 64 output pixels (7 input rows per strip, padding applied while
+    staging) -- every output type (fp32 / bf16 / split-3 rows), ragged last strips, both paddings: the same bits as the r3 gather
+    kernel (option off), and the fp32 form equals F.unfold on the padded image (reference: resnet.py:122-125's 7x7 / 2 / 3 conv)."""
+    from vq_seg_amd import _hip
+    n, h, w = shape
+    ho, wo, kp = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1, 160
+    L = _hip.lib()
+    x = synth.uniform(n + h + w, (n, h, w, 3), -1, 1)
+    xd = x.to(dev())
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for opt in (1, 0):
+        prev = _hip.set_option("im2col_strip", opt)
+        try:
+            for kind, dt, width in ((0, torch.float32, kp), (1, torch.bfloat16, kp), (2, torch.bfloat16, 2 * kp)):
+                out = torch.full((n * ho * wo, width), float("nan"), dtype=dt, device=dev())
+                rc = L.vqseg_im2col_f(kind, xd.data_ptr(), n, h, w, 3, 7, 7, 2, 3, int(reflect), ho, wo, kp, out.data_ptr(), st)
+                assert rc == 0, L.vqseg_last_error()
+                torch.cuda.synchronize()
+                outs[(opt, kind)] = out.cpu()
+        finally:
+            _hip.set_option("im2col_strip", prev)
+    for kind in (0, 1, 2):
+        assert torch.equal(outs[(1, kind)].view(torch.int16 if kind else torch.int32), outs[(0, kind)].view(torch.int16 if kind else torch.int32)), kind
+    xp = F.pad(x.permute(0, 3, 1, 2), (3, 3, 3, 3), mode="reflect" if reflect else "constant")
+    ref = F.unfold(xp, 7, stride=2).reshape(n, 3, 7, 7, ho * wo).permute(0, 4, 2, 3, 1).reshape(n * ho * wo, 147)   # columns (kh, kw, ci)
+    assert torch.equal(outs[(1, 0)][:, :147], ref) and not outs[(1, 0)][:, 147:].any()
+
+
 @pytest.mark.parametrize("pair", [False, True])
 def test_wgrad_stem_patch_matrix(pair):
     """The stem's weight gradient = a 1x1 weight gradient over its im2col patch matrix ([rows][160 columns = (kh, kw, ci) padded]).

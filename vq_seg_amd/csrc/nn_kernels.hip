@@ -1278,6 +1278,112 @@ __global__ __launch_bounds__(256) void im2col_stem7_kernel(const float* __restri
     }
 }
 
+// r4: the same patch rows from an LDS-staged strip.  The gather kernel above spends its time on address arithmetic and 8 scattered
+// 4-byte loads per 16-byte store (464 us for the bench's 671 MB bf16 patch matrix = 1.7 TB/s, and both networks of a CPS pair wait for
+// it).  Here a workgroup owns 64 consecutive output pixels of one output row: the 7 input rows x (2 * 63 + 7 = 133) input pixels x 3
+// channels they read (padding applied while staging: reflect or zero) go to LDS with coalesced loads -- 3.4 x fewer global loads --
+// and a patch column k = (kh, kw, ci) of pixel p is LDS word kh * ROW + 6 p + (k - 21 kh): for a fixed kh the 21 columns are
+// CONSECUTIVE input floats.  320 threads = 16 pixels x 20 column chunks: a thread keeps its chunk (its eight LDS offsets are computed
+// once) and walks TP / 16 pixels; ROW = 22 mod 32 puts the 20 chunks of a pixel in different banks.  Stride 2 / pad 3 / 160 columns
+// (the stem).  Values identical to the gather kernel's.  Measured at the bench's shape (tools/bench_im2col.py; gather kernel -> strips
+// of 64 -> of 128 pixels): bf16 rows 475 -> 236 -> 194 us (4.0 TB/s), split-3 rows 604 -> 311 -> 319, fp32 rows 583 -> 359 -> 381:
+// bf16 takes 128-pixel strips (one load round trip per 8 KB stored instead of per 4 KB), the 32-byte-per-element forms 64.
+#ifndef IM2COL_ABL
+#define IM2COL_ABL 0              // debug builds only (results wrong): 1 no global stores, 2 no global loads
+#endif
+template <typename TO, int TP>
+__global__ __launch_bounds__(320) void im2col_stem7_strip_kernel(const float* __restrict__ x, int N, int H, int W, int reflect, int Ho, int Wo,
+                                                                 TO* __restrict__ out) {
+    constexpr int NCOL = (2 * (TP - 1) + 7) * 3, KP = 160, CPR = KP / 8;   // NCOL floats of an input row feed the strip
+    constexpr int ROW = (NCOL + 31 - 22) / 32 * 32 + 22;    // >= NCOL, = 22 mod 32 (406 for 64-pixel strips)
+    constexpr int NH = (NCOL + 319) / 320;
+    __shared__ float strip[7 * ROW];
+    const int strips = (Wo + TP - 1) / TP;
+    const int sx = blockIdx.x % strips;
+    const int oh = (blockIdx.x / strips) % Ho, n = blockIdx.x / (strips * Ho);
+    const int ow0 = sx * TP, iw0 = 2 * ow0 - 3;
+    const int t = threadIdx.x;
+    // staging: a thread owns NH columns of the strip in all seven rows.  The loads are UNCONDITIONAL (clamped address, value selected
+    // afterwards) and all issued before the first LDS write: a load under a divergent branch is waited for right there -- fourteen
+    // serialised round trips per workgroup (measured: 190 us of a 300 us launch).  One strip per workgroup: a loop over strips with
+    // the next strip's loads in flight was SLOWER (285 vs 234 us) -- gfx950 counts loads and stores on one in-order counter, so waiting
+    // for the prefetch drains the stores issued after it.
+    const float* xn = x + (size_t)n * H * W * 3;
+    float r[NH][7];
+#pragma unroll
+    for (int half = 0; half < NH; ++half) {
+        const int c = t + 320 * half;
+        const int px = c / 3, ci = c - 3 * px;
+        int iw = iw0 + px;
+        if (reflect) {
+            if (iw < 0) iw = -iw;
+            if (iw >= W) iw = 2 * W - 2 - iw;
+        }
+        const bool cok = c < NCOL && iw >= 0 && iw < W;     // (beyond a ragged last strip: unused)
+        const int coff = cok ? iw * 3 + ci : 0;
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            int ih = 2 * oh - 3 + kh;                       // workgroup-uniform
+            if (reflect) {
+                if (ih < 0) ih = -ih;
+                if (ih >= H) ih = 2 * H - 2 - ih;
+            }
+            const bool ok = cok && ih >= 0 && ih < H;
+#if IM2COL_ABL == 2
+            const float v = (float)coff;
+#else
+            const float v = xn[(ok ? ih : 0) * W * 3 + coff];
+#endif
+            r[half][kh] = ok ? v : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int half = 0; half < NH; ++half)
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh)
+            if (t + 320 * half < NCOL) strip[kh * ROW + t + 320 * half] = r[half][kh];
+    __syncthreads();
+    const int ch = t % CPR, p0 = t / CPR;                   // this thread's column chunk; pixels p0, p0 + 16, ...
+    int off[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = ch * 8 + e;
+        const int kh = k / 21;
+        off[e] = k < 147 ? kh * ROW + (k - 21 * kh) : -1;
+    }
+    const int npx = Wo - ow0 < TP ? Wo - ow0 : TP;
+    const size_t row0 = ((size_t)n * Ho + oh) * Wo + ow0;
+#pragma unroll
+    for (int it = 0; it < TP / 16; ++it) {
+        const int p = p0 + 16 * it;
+        if (p < npx) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = off[e] >= 0 ? strip[off[e] + 6 * p] : 0.0f;
+#if IM2COL_ABL == 1
+            if (v[0] != 12345.678f) continue;
+#endif
+            if constexpr (__is_same(TO, S3Out)) {          // split-3 rows [2 * KP]: chunk ch of hi | lo
+                s3_store8(reinterpret_cast<unsigned short*>(out) + (row0 + p) * 2 * KP, KP, ch * 8, v);
+            } else {
+                TO* dst = out + (row0 + p) * KP + ch * 8;
+                if constexpr (sizeof(TO) == 2) {
+                    u32x4 q;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
+                        q[e] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+                    }
+                    *reinterpret_cast<u32x4*>(dst) = q;
+                } else {
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // "split-3" activations (the fp32-precision eval forward on the bf16 kernels): a logical fp32 tensor [rows][C] is stored as
 // [rows][2C] bf16 = [hi | lo], hi = bf16(v), lo = bf16(v - hi).  A bf16 convolution over the logical channels [hi | lo | hi]
@@ -1517,6 +1623,10 @@ int nn_set_option(const char* key, int value) {
         g_debug_skip_small = value;
         return prev;
     }
+    if (key && !strcmp(key, "im2col_strip")) {
+        extern int im2col_strip_option(int);
+        return im2col_strip_option(value);
+    }
     if (key && !strcmp(key, "bilinear_up2")) {
         extern int bilinear_up2_option(int);
         return bilinear_up2_option(value);
@@ -1746,8 +1856,25 @@ hipError_t launch_s3_bilinear(const void* x, int N, int H, int W, int C, int Ho,
     return hipGetLastError();
 }
 
+static int g_im2col_strip = 1;                              // the stem's patch matrix from LDS-staged strips (0: the gather kernel, r3)
+int im2col_strip_option(int value) {
+    const int prev = g_im2col_strip;
+    g_im2col_strip = value ? 1 : 0;
+    return prev;
+}
 hipError_t launch_im2col_stem(int out_bf16, const float* x, int N, int H, int W, int Cin, int KH, int KW, int stride, int pad,
                               int reflect, int Ho, int Wo, int Kp, void* out, hipStream_t st_) {
+    if (g_im2col_strip && KH == 7 && KW == 7 && Cin == 3 && stride == 2 && pad == 3 && Kp == 160 && (long)H * W * 3 < (1L << 31) &&
+        (long)N * Ho * ((Wo + 63) / 64) < (1L << 31)) {
+        const unsigned g64 = (unsigned)((long)N * Ho * ((Wo + 63) / 64)), g128 = (unsigned)((long)N * Ho * ((Wo + 127) / 128));
+        if (out_bf16 == 2)
+            hipLaunchKernelGGL((im2col_stem7_strip_kernel<S3Out, 64>), dim3(g64), dim3(320), 0, st_, x, N, H, W, reflect, Ho, Wo, (S3Out*)out);
+        else if (out_bf16)
+            hipLaunchKernelGGL((im2col_stem7_strip_kernel<__bf16, 128>), dim3(g128), dim3(320), 0, st_, x, N, H, W, reflect, Ho, Wo, (__bf16*)out);
+        else
+            hipLaunchKernelGGL((im2col_stem7_strip_kernel<float, 64>), dim3(g64), dim3(320), 0, st_, x, N, H, W, reflect, Ho, Wo, (float*)out);
+        return hipGetLastError();
+    }
     if (KH == 7 && KW == 7 && Cin == 3 && Kp % 8 == 0 && (long)N * Ho * Wo * (Kp / 8) < (1L << 31)) {
         const unsigned g8 = grid_for((long)N * Ho * Wo * (Kp / 8));
         if (out_bf16 == 2)
