@@ -68,6 +68,10 @@ const char* vqseg_kernel_name(const char* entry_point);
  *                                   kernel (r4); 0: the per-tap kernel
  *   "conv_wgrad1x1_narrow"          1 (default): 64-output-channel 1x1 weight gradients -- the stem's 160-column patch matrix, 64 -> 64
  *                                   -- on the LDS-DMA kernel (r4); 0: the per-tap kernel
+ *   "conv_dgrad_s2_merge"           1 (default): vqseg_conv2d_dgrad_s2_fold_f available (r4); 0: it returns VQSEG_EINVAL (callers take the
+ *                                   four-launch path with the padded grid)
+ *   "conv_wgrad3x3_fill"            1 (default): nine-tap weight gradients split into one FULL round of resident workgroups (r4);
+ *                                   0: r3's split
  *   "im2col_strip"                  1 (default): the stem's patch matrix from LDS-staged strips (r4, bit-identical); 0: the gather kernel
  * The environment variable VQSEG_OPTS="key=value,..." applies options when the Python binding loads the library.
  * Returns the previous value, or VQSEG_EINVAL for an unknown key / negative value.  Not thread safe. */
@@ -371,6 +375,16 @@ int vqseg_conv_pack_weights_s2_f32(const float* w, int cout, int cin, int k, voi
  * separate add pass (bit-identical to adding the two tensors). */
 int vqseg_conv2d_dgrad_s2_f(const void* gy, const void* w_hi, const void* w_lo, void* gx, int n, int ho, int wo, int cout, int cin,
                             int k, int oh, int ow, int precise, int accumulate, void* stream);
+/* r4: the 3x3 / stride 2 / pad 1 data gradient (bf16; the first conv2 of a Bottleneck stage, reflect-padded in the VQ-UNet's encoder:
+ * resnet.py:134-148; the first conv1 of a BasicBlock stage, zero-padded) written STRAIGHT into the unpadded gx [n][h][w][cin]
+ * (h = 2 ho, w = 2 wo): the four parity classes in ONE launch, no padded-grid tensor, no fold / crop pass over it.  gx must hold
+ * vqseg_conv2d_dgrad_s2_fold_rows(n, h, w, reflect) rows of cin elements: behind the n * h * w pixel rows, reflect padding keeps
+ * the gradients of the padded top row / left column (a ring of n * (w + 1 + h) rows, added onto x row 1 / column 1 by a second
+ * small launch) and one dump row.  w_hi: vqseg_conv_pack_weights_s2_f32's image (k = 3).  VQSEG_EINVAL for shapes outside the
+ * merged path (cout % 64, cin % 8, cin >= 64) or with option "conv_dgrad_s2_merge" = 0: use vqseg_conv2d_dgrad_s2_f then. */
+int64_t vqseg_conv2d_dgrad_s2_fold_rows(int n, int h, int w, int reflect);
+int vqseg_conv2d_dgrad_s2_fold_f(const void* gy, const void* w_hi, void* gx, int n, int ho, int wo, int cout, int cin, int h, int w,
+                                 int reflect, void* stream);
 int vqseg_s3_split_f(const float* x, int64_t rows, int channels, void* y, void* stream);
 int vqseg_s3_merge_f(const void* x, int64_t rows, int channels, float* y, void* stream);
 int vqseg_s3_maxpool3x3s2_f(const void* x, int n, int h, int w, int c, void* y, void* stream);

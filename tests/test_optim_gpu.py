@@ -369,3 +369,62 @@ def test_reflect_data_gradient_by_border_ring_matches_the_padded_gradient_path(s
     if h > 4 and w > 4:
         inner = (slice(None), slice(None), slice(2, h - 2), slice(2, w - 2))      # interior: the same zero-padded correlation
         assert rel(outs[0][inner], outs[1][inner]) < 2 ** -8
+
+
+# ------------------------------------------------------------------------------------------------ stride-2 3x3 data gradient, one launch
+@pytest.mark.parametrize("case", [
+    # n, channels of g_y (the layer's Cout), channels of g_x (its Cin), h, w, reflect
+    (2, 128, 128, 16, 24, True), (1, 64, 64, 8, 8, False), (3, 128, 256, 4, 36, True), (2, 256, 128, 12, 8, False), (2, 64, 72, 20, 20, True),
+])
+def test_stride2_data_gradient_in_one_launch_without_the_padded_grid(case):
+    """vqseg_conv2d_dgrad_s2_fold_f (r4): the four parity classes of a 3x3 / stride 2 / pad 1 data gradient in ONE launch, written
+    straight into the unpadded gradient; reflect padding: the padded top row / left column through a small ring onto x row 1 / column 1.
+    Against (a) the fp64 autograd gradient of F.conv2d on the padded input with the same bf16-rounded operands (2^-7 of the scale:
+    bf16 output) and (b) the four-launch path on the padded grid + fold / crop: bit-identical away from x row 1 / column 1 (same
+    accumulation order), one extra bf16 rounding there (reflect only)."""
+    from vq_seg_amd import _hip, nnf
+    L = _hip.lib()
+    d = dev()
+    st = torch.cuda.current_stream().cuda_stream
+    n, cgy, cgx, h, w, reflect = case
+    ho, wo = h // 2, w // 2
+    wt = nn.Parameter(synth.uniform(sum(case[:5]), (cgy, cgx, 3, 3), -0.3, 0.3).to(d))
+    s_hi, s_lo = nnf._s2_weights(wt, False)
+    gy = synth.uniform(9, (n, ho, wo, cgy), -1, 1).bfloat16()
+    # (a) fp64 reference on the bf16-rounded weights
+    x = torch.zeros(n, cgx, h, w, dtype=torch.float64, requires_grad=True)
+    xp = F.pad(x, (1, 1, 1, 1), mode="reflect" if reflect else "constant")
+    F.conv2d(xp, wt.detach().cpu().bfloat16().double(), stride=2).backward(gy.double().permute(0, 3, 1, 2))
+    ref = x.grad.permute(0, 2, 3, 1)
+    gyd = gy.to(d)
+    rows = int(L.vqseg_conv2d_dgrad_s2_fold_rows(n, h, w, int(reflect)))
+    assert rows == n * h * w + (n * (w + 1 + h) if reflect else 0) + 1
+    buf = torch.full((rows, cgx), float("nan"), dtype=torch.bfloat16, device=d)
+    rc = L.vqseg_conv2d_dgrad_s2_fold_f(gyd.data_ptr(), s_hi.data_ptr(), buf.data_ptr(), n, ho, wo, cgy, cgx, h, w, int(reflect), st)
+    assert rc == 0, L.vqseg_last_error()
+    torch.cuda.synchronize()
+    got = buf[:n * h * w].view(n, h, w, cgx).float().cpu()
+    assert torch.isfinite(got).all()
+    assert rel(got, ref) < 2 ** -7
+    # (b) the four-launch path
+    gp = torch.empty((n, h + 2, w + 2, cgx), dtype=torch.bfloat16, device=d)
+    assert L.vqseg_conv2d_dgrad_s2_f(gyd.data_ptr(), s_hi.data_ptr(), None, gp.data_ptr(), n, ho, wo, cgy, cgx, 3, h + 2, w + 2, 0, 0, st) == 0, L.vqseg_last_error()
+    if reflect:
+        old = torch.empty((n, h, w, cgx), dtype=torch.bfloat16, device=d)
+        assert L.vqseg_reflect_fold_f(1, gp.data_ptr(), n, h, w, cgx, old.data_ptr(), st) == 0, L.vqseg_last_error()
+    else:
+        old = gp[:, 1:h + 1, 1:w + 1, :].contiguous()
+    torch.cuda.synchronize()
+    old = old.float().cpu()
+    keep = torch.ones(h, w, dtype=torch.bool)
+    if reflect:
+        keep[1, :] = False
+        keep[:, 1] = False
+    assert torch.equal(got[:, keep], old[:, keep])
+    assert (got - old).abs().max() <= 2 ** -7 * old.abs().max()
+    # the option switches the entry point off (callers then take the four-launch path)
+    prev = _hip.set_option("conv_dgrad_s2_merge", 0)
+    try:
+        assert L.vqseg_conv2d_dgrad_s2_fold_f(gyd.data_ptr(), s_hi.data_ptr(), buf.data_ptr(), n, ho, wo, cgy, cgx, h, w, int(reflect), st) != 0
+    finally:
+        _hip.set_option("conv_dgrad_s2_merge", prev)

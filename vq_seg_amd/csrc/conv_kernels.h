@@ -38,6 +38,21 @@ struct ConvArgs {
     int ring = 0, ring_h = 0, ring_w = 0;
     int ep_res_out = 0;         // 1: ep_res is indexed like the OUTPUT (through omap) instead of by GEMM row -- in-place accumulation
                                 // into a tensor of the output's geometry (launch_dgrad_s2 with `accumulate`)
+    // r4: the four parity classes of a stride-2 3x3 data gradient in ONE launch (conv_igemm_glds_kernel<..., CLS = true>): a workgroup
+    // picks its class from its tile index and takes that class's taps / padding / extent / weight image; and the rows land
+    // straight in the UNPADDED input gradient (omap_fold; omap_h x omap_w is then the input's own H x W):
+    //   1 (reflect padding): padded pixel (i, j), i, j >= 1 -> x pixel (i - 1, j - 1); the padded top row / left column (whose
+    //     gradients reflect onto x row 1 / column 1) -> a ring region behind the N * H * W rows ([N][W + 1 + H]), added by
+    //     reflect_s2_ring_add; pixels beyond (i > H or j > W: no gradient reaches them) -> one dump row behind the ring
+    //   2 (zero padding): the border of the padded grid is dropped (dump row behind the N * H * W rows)
+    struct Cls {
+        int KH, KW, pad, pad_w, Ho, Wo, ph, pw;
+        unsigned w_off;         // element offset of the class's weight image
+        unsigned tile_end;      // exclusive end of the class's M tiles in blockIdx.x
+    };
+    int n_cls = 0;
+    Cls cls[4];
+    int omap_fold = 0;
 };
 
 struct WgradArgs {
@@ -58,6 +73,12 @@ struct WgradArgs {
 };
 
 hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st);
+// rows the input-gradient buffer of launch_dgrad_s2_fold must have (N * H * W, + the ring region for reflect padding, + a dump row)
+long dgrad_s2_fold_rows(int N, int H, int W, int reflect);
+// 3x3 / stride 2 / pad 1 data gradient (bf16) written straight into the unpadded gx [N][H][W][Cin] (H = 2 Ho, W = 2 Wo), one launch
+// for the four parity classes (+ the ring add for reflect padding).  hipErrorInvalidValue: shape outside the merged path.
+hipError_t launch_dgrad_s2_fold(const void* gy, const unsigned short* w_hi, void* gx, int N, int Ho, int Wo, int Cout, int Cin, int H, int W,
+                                int reflect, hipStream_t st);
 hipError_t conv_profile_begin(int capacity);
 void conv_profile_release();
 int conv_profile_collect(int max_records, double* flops, int* kind, float* ms, int* shape);

@@ -40,6 +40,13 @@ __device__ __forceinline__ unsigned int pack2(float a, float b) {
     const __bf16 x = (__bf16)a, y = (__bf16)b;
     return (unsigned int)__builtin_bit_cast(unsigned short, x) | ((unsigned int)__builtin_bit_cast(unsigned short, y) << 16);
 }
+__device__ __forceinline__ void unpack8(const u32x4 a, float (&v)[8]) {      // 8 bf16 -> fp32
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[2 * e] = __builtin_bit_cast(float, a[e] << 16);
+        v[2 * e + 1] = __builtin_bit_cast(float, a[e] & 0xFFFF0000u);
+    }
+}
 __device__ __forceinline__ float bf16_round(float a) { return (float)((__bf16)a); }
 
 // pixel row m -> (image n, offset inside the image): 32-bit division whenever the row count allows (a 64-bit
@@ -89,6 +96,18 @@ __device__ __forceinline__ long out_row(const ConvArgs& p, long m) {
     const unsigned hw = (unsigned)(p.Ho * p.Wo), um = (unsigned)m;
     const unsigned n = um / hw, rem = um - n * hw;
     const unsigned oh = rem / (unsigned)p.Wo, ow = rem - oh * (unsigned)p.Wo;
+    if (p.omap_fold) {                                       // (i, j) on the padded grid -> the unpadded gradient / ring / dump row
+        const int i = 2 * (int)oh + p.omap_ph, j = 2 * (int)ow + p.omap_pw, H = p.omap_h, W = p.omap_w;
+        const long body = (long)p.N * H * W;
+        if (i >= 1 && j >= 1 && i <= H && j <= W) return ((long)n * H + i - 1) * W + j - 1;
+        if (p.omap_fold == 1) {
+            const int rl = W + 1 + H;
+            if (i == 0 && j <= W) return body + (long)n * rl + j;
+            if (j == 0 && i <= H) return body + (long)n * rl + W + i;          // i >= 1 here
+            return body + (long)p.N * rl;
+        }
+        return body;
+    }
     return ((long)n * p.omap_h + 2 * oh + p.omap_ph) * p.omap_w + 2 * ow + p.omap_pw;
 }
 
@@ -583,8 +602,23 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // spends ~600 VALU instructions per wave on (image, row, column) splits and tap geometry that such a layer does not need -- and
 // these launches are VALU-ISSUE bound, not memory bound (rocprofv3 SQ_INSTS_VALU: 1544 per wave for a tile whose K loop is 16 MFMAs;
 // 16 resident waves per CU x 1544 x 4 cycles = 94 of the 111 us of the 64 -> 256 layer at 128^2; profiles/LEDGER.md, round 3).
-template <int TBM, int BN, int NW, int NBUF, int MINW = 1, bool S3 = false, bool LIN = false>
-__global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const ConvArgs p) {
+template <int TBM, int BN, int NW, int NBUF, int MINW = 1, bool S3 = false, bool LIN = false, bool CLS = false>
+__global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const ConvArgs pk) {
+    // CLS: the launch holds several convolution problems over the same input (pk.cls: the parity classes of a stride-2 data
+    // gradient); this workgroup's class replaces the per-problem fields.  All of it is workgroup-uniform (scalar registers).
+    ConvArgs pc;
+    long cls_tile0 = 0;
+    if constexpr (CLS) {
+        pc = pk;
+        int c = 0;
+        while (c + 1 < pk.n_cls && blockIdx.x >= pk.cls[c].tile_end) ++c;
+        cls_tile0 = c ? pk.cls[c - 1].tile_end : 0;
+        const ConvArgs::Cls& k = pk.cls[c];
+        pc.KH = k.KH, pc.KW = k.KW, pc.pad = k.pad, pc.pad_w = k.pad_w, pc.Ho = k.Ho, pc.Wo = k.Wo;
+        pc.omap_ph = k.ph, pc.omap_pw = k.pw;
+        pc.w_hi = pk.w_hi + k.w_off;
+    }
+    const ConvArgs& p = CLS ? pc : pk;
     constexpr int BK = 64;
     // wave grid WM x WN over the TBM x BN tile; wave tile (MT*32) x (NT*32)
     constexpr int WN = (BN >= 256) ? 4 : (BN >= 64 ? 2 : 1);
@@ -607,7 +641,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
     const long M = (long)p.N * p.Ho * p.Wo;
     // 1-D launch (pair_chunks > 0): the Cout chunks of an M tile sit 8 workgroup ids apart = on the same XCD at about the
     // same time, so the A rows come from HBM once and from that XCD's L2 for the other chunks
-    long m_tile = blockIdx.x;
+    long m_tile = blockIdx.x - cls_tile0;
     int co_chunk = blockIdx.y;
     if (p.pair_chunks > 0) {
         const unsigned group = 8u * (unsigned)p.pair_chunks, within = blockIdx.x % group;
@@ -1117,6 +1151,7 @@ static int g_patch_tile512_min_wgs = 512;
 static int g_patch_tile512_launches = 0;                    // launches that took a 512-pixel tile (tests read it to see the dispatch)
 static int g_patch_unroll = 1;                              // 128-channel tile: tap loop unrolled
 static int g_wgrad1x1_narrow = 1;                           // 64-output-channel 1x1 weight gradients (stem patch matrix, 64 -> 64) on the LDS-DMA kernel
+static int g_wgrad3x3_fill = 1;                             // nine-tap weight gradients: slabs sized to one full round of resident workgroups (0: r3's split)
 static int g_wgrad3x3_s2 = 1;                               // stride-2 3x3 weight gradients on the nine-tap kernel (0: the per-tap kernel, r3)
 
 int conv_set_option(const char* key, int value) {
@@ -1128,6 +1163,15 @@ int conv_set_option(const char* key, int value) {
     if (key && !strcmp(key, "conv_wgrad1x1_narrow")) {
         const int prev = g_wgrad1x1_narrow;
         g_wgrad1x1_narrow = value;
+        return prev;
+    }
+    if (key && !strcmp(key, "conv_dgrad_s2_merge")) {
+        extern int dgrad_s2_merge_option(int);
+        return dgrad_s2_merge_option(value);
+    }
+    if (key && !strcmp(key, "conv_wgrad3x3_fill")) {
+        const int prev = g_wgrad3x3_fill;
+        g_wgrad3x3_fill = value;
         return prev;
     }
     if (key && !strcmp(key, "conv_wgrad3x3_stride2")) {
@@ -1658,6 +1702,122 @@ hipError_t launch_dgrad_s2(const void* gy, const unsigned short* w_hi, const uns
         off += (size_t)Cin * nh * nw * Cp;
     }
     return hipGetLastError();
+}
+
+static int g_dgrad_s2_merge = 1;                            // stride-2 3x3 data gradients: one launch, unpadded output (0: four launches + fold / crop)
+int dgrad_s2_merge_option(int value) {
+    const int prev = g_dgrad_s2_merge;
+    if (value >= 0) g_dgrad_s2_merge = value ? 1 : 0;
+    return prev;
+}
+
+long dgrad_s2_fold_rows(int N, int H, int W, int reflect) {
+    return (long)N * H * W + (reflect ? (long)N * (W + 1 + H) : 0) + 1;
+}
+
+// x row 1 += padded row 0 (columns 1..W -> x columns 0..W-1), x column 1 += padded column 0 (rows 1..H -> x rows 0..H-1),
+// x (1, 1) += the padded corner: the reflect-padding fold of a stride-2 layer (padded row H+1 / column W+1 carry no gradient:
+// H, W even).  ring [N][W + 1 + H][C] as out_row writes it; fp32 sums, one rounding.  8 channels per thread.
+__global__ __launch_bounds__(256) void reflect_s2_ring_add_kernel(const __bf16* __restrict__ ring, int N, int H, int W, int C, __bf16* __restrict__ gx) {
+    const int cv = C / 8, rl = W + 1 + H;
+    const long total = (long)N * (W + H - 1) * cv;         // row 1 (W pixels) + column 1 without (1, 1)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv) * 8;
+        long t = i / cv;
+        const int q = (int)(t % (W + H - 1)), n = (int)(t / (W + H - 1));
+        const __bf16* rn = ring + (long)n * rl * C;
+        int xr, xc;
+        float v[8];
+        if (q < W) {                                        // x (1, q)
+            xr = 1, xc = q;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(rn + (long)(q + 1) * C + c);
+            unpack8(a, v);
+            if (q == 1) {                                   // + padded (2, 0) + padded (0, 0)
+                float w8[8];
+                unpack8(*reinterpret_cast<const u32x4*>(rn + (long)(W + 2) * C + c), w8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += w8[e];
+                unpack8(*reinterpret_cast<const u32x4*>(rn + c), w8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += w8[e];
+            }
+        } else {                                            // x (r, 1), r != 1: padded (r + 1, 0) = ring slot W + r + 1
+            int r = q - W;
+            if (r >= 1) ++r;
+            xr = r, xc = 1;
+            unpack8(*reinterpret_cast<const u32x4*>(rn + (long)(W + r + 1) * C + c), v);
+        }
+        __bf16* dst = gx + (((long)n * H + xr) * W + xc) * C + c;
+        float g[8];
+        unpack8(*reinterpret_cast<const u32x4*>(dst), g);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2(g[2 * e] + v[2 * e], g[2 * e + 1] + v[2 * e + 1]);
+        *reinterpret_cast<u32x4*>(dst) = o;
+    }
+}
+
+hipError_t launch_dgrad_s2_fold(const void* gy, const unsigned short* w_hi, void* gx, int N, int Ho, int Wo, int Cout, int Cin, int H, int W,
+                                int reflect, hipStream_t st) {
+    // (Cout: channels of gy = the contraction; Cin: channels of gx = the GEMM's output channels)
+    if (!g_dgrad_s2_merge || H != 2 * Ho || W != 2 * Wo || Cout % 64 || Cin % 8 || Cin < 64 || H < 4 || W < 4) return hipErrorInvalidValue;
+    const long body = dgrad_s2_fold_rows(N, H, W, reflect);
+    if ((long)N * (Ho + 1) * (Wo + 1) >= (1L << 31) || body >= (1L << 31)) return hipErrorInvalidValue;
+    const int Cp = (Cout + 31) / 32 * 32;
+    ConvArgs a;
+    a.x = gy; a.x2 = nullptr; a.C1 = Cout; a.w_hi = w_hi; a.w_lo = nullptr; a.y = gx; a.stat_partial = nullptr;
+    a.N = N; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Cout = Cin; a.stride = 1; a.reflect = 0; a.up = 1;
+    a.ep_scale = nullptr; a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_relu = 0;
+    a.omap = 1; a.omap_h = H; a.omap_w = W; a.omap_fold = reflect ? 1 : 2; a.prof_k = 3;
+    const int bn = Cin >= 128 ? 128 : 64;
+    size_t off = 0;
+    unsigned tiles = 0;
+    a.n_cls = 4;
+    for (int cls = 0; cls < 4; ++cls) {                     // the padded grid's parity classes, as launch_dgrad_s2 (OH = H + 2)
+        const int ph = cls >> 1, pw = cls & 1;
+        ConvArgs::Cls& k = a.cls[cls];
+        k.KH = ph ? 1 : 2, k.KW = pw ? 1 : 2, k.pad = ph ? 0 : 1, k.pad_w = pw ? 0 : 1, k.ph = ph, k.pw = pw;
+        k.Ho = (H + 2 - ph + 1) / 2, k.Wo = (W + 2 - pw + 1) / 2;
+        k.w_off = (unsigned)off;
+        tiles += (unsigned)(((long)N * k.Ho * k.Wo + 127) / 128);
+        k.tile_end = tiles;
+        off += (size_t)Cin * k.KH * k.KW * Cp;
+    }
+    a.KH = 2, a.KW = 2, a.pad = 1, a.pad_w = 1, a.Ho = a.cls[0].Ho, a.Wo = a.cls[0].Wo;      // (class 0; the kernel substitutes)
+    const bool rec = g_cprof.enabled && g_cprof.count < g_cprof.capacity;
+    const int slot = g_cprof.count;
+    if (rec) {
+        g_cprof.flops[slot] = 2.0 * 9 * (double)Cout * Cin * (double)N * Ho * Wo;
+        g_cprof.kind[slot] = 300;
+        g_cprof.shape[4 * slot + 0] = (int)(((long)N * H * W) >> 10);
+        g_cprof.shape[4 * slot + 1] = Cout;
+        g_cprof.shape[4 * slot + 2] = Cin;
+        g_cprof.shape[4 * slot + 3] = 13;
+        ++g_cprof.count;
+        (void)hipEventRecord(g_cprof.ev[2 * slot], st);
+    }
+    const dim3 grid(tiles, (unsigned)((Cin + bn - 1) / bn));
+    if (bn == 128 && 4 * (Cout / 64) <= g_short_k_single) {   // K loops of a few stages: epilogue-bound -- single buffer, four workgroups per CU
+        const size_t lds = (size_t)128 * (128 + 8) * 2;       // (the output tile is the larger of the two uses)
+        hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128, 4, 1, SHORTK_MINW, false, false, true>), grid, dim3(256), lds, st, a);
+    } else if (bn == 128) {
+        const size_t lds = (size_t)(128 + 128) * 64 * 2 * 2;
+        hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128, 4, 2, 1, false, false, true>), grid, dim3(256), lds, st, a);
+    } else {
+        const size_t lds = (size_t)(128 + 64) * 64 * 2 * 3;
+        hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 64, 4, 3, 1, false, false, true>), grid, dim3(256), lds, st, a);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && reflect) {
+        const __bf16* ring = reinterpret_cast<const __bf16*>(gx) + (long)N * H * W * Cin;
+        const long total = (long)N * (W + H - 1) * (Cin / 8);
+        long blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(reflect_s2_ring_add_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ring, N, H, W, Cin, reinterpret_cast<__bf16*>(gx));
+        e = hipGetLastError();
+    }
+    if (rec) (void)hipEventRecord(g_cprof.ev[2 * slot + 1], st);
+    return e;
 }
 
 // ring [N][2 (W + 2) + 2 H][Cgx] = the full 3x3 correlation of gy [N][H][W][Cgy] with the tap-flipped transposed weights, evaluated
@@ -2458,11 +2618,30 @@ static Wg3Plan wgrad3x3_plan(const WgradArgs& a, int precise, bool shape_only, i
     if (n_blk > (1L << 30)) return pl;
     // every workgroup writes its whole (co x ci x 9) fp32 tile once, so the partial volume is (#workgroups x tile
     // bytes) whatever the layer: one resident round of workgroups is the cheapest split
-    const long target = (cot == 4 && cit == 2) ? 256 : 512;
+    long target = (cot == 4 && cit == 2) ? 256 : 512;
     long s = (target + tiles - 1) / tiles;
+    long cap = 256;
+    if (g_wgrad3x3_fill) {
+        // r4: ONE FULL round, never one workgroup more.  192 -> 32 at 256^2 ran 3 x 171 = 513 workgroups on 512 slots (two 54 KB
+        // workgroups per CU): the 513th ran alone after the others -- twice the time (647 us).  And the narrow tiles left the chip
+        // mostly empty (32 -> 32: 256 four-wave workgroups = one per CU where four fit).  Slots = CUs x workgroups per CU by LDS and
+        // wave slots; slabs = slots / tiles rounded DOWN, up to 1024 of them while the partials stay under 64 MB.
+        const int bh = s2 ? 2 : 4, npatch = s2 ? 165 : 108, nw = (cot == 4 && cit == 2) ? 8 : 4;
+        const long g_bytes = (long)bh * 16 * cot * 64;
+        const long p_instr = ((long)npatch * cit * 64 + 1023) / 1024;
+        const long stage = g_bytes + (p_instr + nw - 1) / nw * nw * 1024;
+        long per_cu = (160 * 1024) / (3 * stage);
+        if (per_cu > 32 / nw) per_cu = 32 / nw;
+        if (per_cu < 1) per_cu = 1;
+        target = 256 * per_cu;
+        s = target / tiles;
+        cap = 1024;
+        const long tile_bytes = (long)cot * 32 * cit * 32 * 9 * 4;
+        while (cap > 256 && cap * tiles * tile_bytes > (64L << 20)) cap >>= 1;
+    }
     const long max_s = s2 ? (n_blk + 15) / 16 : (n_blk + 7) / 8;   // at least 512 pixels per slab
     if (s > max_s) s = max_s;
-    if (s > 256) s = 256;
+    if (s > cap) s = cap;
     if (s < 1) s = 1;
     const long bps = (n_blk + s - 1) / s;
     s = (n_blk + bps - 1) / bps;                            // no empty slabs

@@ -309,6 +309,22 @@ int vqseg_conv2d_dgrad_s2_f(const void* gy, const void* w_hi, const void* w_lo, 
     return e == hipSuccess ? 0 : hipfail(e, "conv2d_dgrad_s2");
 }
 
+int64_t vqseg_conv2d_dgrad_s2_fold_rows(int n, int h, int w, int reflect) {
+    return (n > 0 && h > 0 && w > 0) ? (int64_t)vqseg::dgrad_s2_fold_rows(n, h, w, reflect) : 0;
+}
+
+int vqseg_conv2d_dgrad_s2_fold_f(const void* gy, const void* w_hi, void* gx, int n, int ho, int wo, int cout, int cin, int h, int w,
+                                 int reflect, void* stream) {
+    if (!gy || !w_hi || !gx) return bad("conv2d_dgrad_s2_fold: null pointer");
+    if (n <= 0 || ho <= 0 || wo <= 0 || h != 2 * ho || w != 2 * wo || h < 4 || w < 4) return bad("conv2d_dgrad_s2_fold: needs H = 2 Ho, W = 2 Wo, H, W >= 4");
+    if (cout <= 0 || cin < 64 || cout % 64 || cin % 8) return bad("conv2d_dgrad_s2_fold: needs Cout % 64 == 0, Cin % 8 == 0, Cin >= 64");
+    if (!a16(gy) || !a16(w_hi) || !a16(gx)) return bad("conv2d_dgrad_s2_fold: pointers must be 16-byte aligned");
+    hipError_t e = vqseg::launch_dgrad_s2_fold(gy, static_cast<const unsigned short*>(w_hi), gx, n, ho, wo, cout, cin, h, w, reflect,
+                                               static_cast<hipStream_t>(stream));
+    if (e == hipErrorInvalidValue) return bad("conv2d_dgrad_s2_fold: shape outside the merged path (or option conv_dgrad_s2_merge = 0)");
+    return e == hipSuccess ? 0 : hipfail(e, "conv2d_dgrad_s2_fold");
+}
+
 int vqseg_reflect_ring_f(const void* gy, const void* t_hi, void* ring, void* gx, int n, int h, int w, int cgy, int cgx, void* stream) {
     if (!gy || !t_hi || !ring || !gx) return bad("reflect_ring: null pointer");
     if (n <= 0 || h < 4 || w < 4 || cgy <= 0 || cgx <= 0 || cgy % 64 || cgx % 8) return bad("reflect_ring: needs H, W >= 4, Cgy % 64 == 0, Cgx % 8 == 0");

@@ -722,6 +722,20 @@ class _ConvBNAct(torch.autograd.Function):
                                                        kh, kw, 1, dpad, 0, hp, wp, int(precise), _stream()), "vqseg_conv2d_affine_f")
                     extra = None
                     return gp
+                if (stride == 2 and x2r is None and kh == 3 and kw == 3 and pad == 1 and bf and h == 2 * ho and w == 2 * wo and h >= 4 and w >= 4
+                        and cout % 64 == 0 and c_cnt % 8 == 0 and c_cnt >= 64 and py_opt("py_dgrad_s2", 1) and py_opt("py_dgrad_s2_fold", 1)):
+                    # r4: the four parity classes in ONE launch, written straight into the unpadded gradient (reflect padding: the
+                    # padded top row / left column go to a small ring behind the pixel rows and are added onto row 1 / column 1) --
+                    # no (H+2) x (W+2) tensor, no fold / crop pass over it
+                    s_hi, _s_lo = _s2_weights(weight, precise)
+                    rows = int(L.vqseg_conv2d_dgrad_s2_fold_rows(n, h, w, int(reflect)))
+                    buf = torch.empty((rows, c_cnt), dtype=g_y.dtype, device=dev)
+                    with _hip.on_device(dev):
+                        _check(L.vqseg_conv2d_dgrad_s2_fold_f(_T(g_y, "conv output gradient", bf=1, numel=m * cout),
+                                                              _w16(s_hi, "parity-class image", L.vqseg_conv_packed_s2_elems(cout, c_cnt, 3)),
+                                                              _T(buf, "input gradient (+ ring)", bf=1, numel=rows * c_cnt),
+                                                              n, ho, wo, cout, c_cnt, h, w, int(reflect), _stream()), "vqseg_conv2d_dgrad_s2_fold_f")
+                    return buf[:n * h * w].view(n, h, w, c_cnt)
                 if stride == 2 and x2r is None and kh == kw and ((kh == 1 and pad == 0) or (kh == 3 and pad == 1)) and py_opt("py_dgrad_s2", 1):
                     # stride-2 layer: parity classes of the output pixel instead of a dilated gradient grid (vqseg_conv2d_dgrad_s2_f)
                     s_hi, s_lo = _s2_weights(weight, precise)
