@@ -421,15 +421,16 @@ def test_stem_patch_matrix_strip_kernel_is_bit_identical_to_the_gather_kernel(sh
     for opt in (1, 0):
         prev = _hip.set_option("im2col_strip", opt)
         try:
-            for kind, dt, width in ((0, torch.float32, kp), (1, torch.bfloat16, kp), (2, torch.bfloat16, 2 * kp)):
+            for kind, dt, width, kpk in ((0, torch.float32, kp, kp), (1, torch.bfloat16, kp, kp), (2, torch.bfloat16, 2 * kp, kp),
+                                         (3, torch.bfloat16, 2 * 192, 192)):        # 3: split-3 rows of 192 columns (the s3 forward's width)
                 out = torch.full((n * ho * wo, width), float("nan"), dtype=dt, device=dev())
-                rc = L.vqseg_im2col_f(kind, xd.data_ptr(), n, h, w, 3, 7, 7, 2, 3, int(reflect), ho, wo, kp, out.data_ptr(), st)
+                rc = L.vqseg_im2col_f(min(kind, 2), xd.data_ptr(), n, h, w, 3, 7, 7, 2, 3, int(reflect), ho, wo, kpk, out.data_ptr(), st)
                 assert rc == 0, L.vqseg_last_error()
                 torch.cuda.synchronize()
                 outs[(opt, kind)] = out.cpu()
         finally:
             _hip.set_option("im2col_strip", prev)
-    for kind in (0, 1, 2):
+    for kind in (0, 1, 2, 3):
         assert torch.equal(outs[(1, kind)].view(torch.int16 if kind else torch.int32), outs[(0, kind)].view(torch.int16 if kind else torch.int32)), kind
     xp = F.pad(x.permute(0, 3, 1, 2), (3, 3, 3, 3), mode="reflect" if reflect else "constant")
     ref = F.unfold(xp, 7, stride=2).reshape(n, 3, 7, 7, ho * wo).permute(0, 4, 2, 3, 1).reshape(n * ho * wo, 147)   # columns (kh, kw, ci)

@@ -1291,12 +1291,12 @@ __global__ __launch_bounds__(256) void im2col_stem7_kernel(const float* __restri
 #ifndef IM2COL_ABL
 #define IM2COL_ABL 0              // debug builds only (results wrong): 1 no global stores, 2 no global loads
 #endif
-template <typename TO, int TP>
-__global__ __launch_bounds__(320) void im2col_stem7_strip_kernel(const float* __restrict__ x, int N, int H, int W, int reflect, int Ho, int Wo,
+template <typename TO, int TP, int KP>
+__global__ __launch_bounds__(2 * KP) void im2col_stem7_strip_kernel(const float* __restrict__ x, int N, int H, int W, int reflect, int Ho, int Wo,
                                                                  TO* __restrict__ out) {
-    constexpr int NCOL = (2 * (TP - 1) + 7) * 3, KP = 160, CPR = KP / 8;   // NCOL floats of an input row feed the strip
+    constexpr int NCOL = (2 * (TP - 1) + 7) * 3, CPR = KP / 8, NT = 16 * CPR;   // threads: 16 pixels x CPR column chunks (KP = 160: 320, 192: 384)   // NCOL floats of an input row feed the strip
     constexpr int ROW = (NCOL + 31 - 22) / 32 * 32 + 22;    // >= NCOL, = 22 mod 32 (406 for 64-pixel strips)
-    constexpr int NH = (NCOL + 319) / 320;
+    constexpr int NH = (NCOL + NT - 1) / NT;
     __shared__ float strip[7 * ROW];
     const int strips = (Wo + TP - 1) / TP;
     const int sx = blockIdx.x % strips;
@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(320) void im2col_stem7_strip_kernel(const float* __
     float r[NH][7];
 #pragma unroll
     for (int half = 0; half < NH; ++half) {
-        const int c = t + 320 * half;
+        const int c = t + NT * half;
         const int px = c / 3, ci = c - 3 * px;
         int iw = iw0 + px;
         if (reflect) {
@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(320) void im2col_stem7_strip_kernel(const float* __
     for (int half = 0; half < NH; ++half)
 #pragma unroll
         for (int kh = 0; kh < 7; ++kh)
-            if (t + 320 * half < NCOL) strip[kh * ROW + t + 320 * half] = r[half][kh];
+            if (t + NT * half < NCOL) strip[kh * ROW + t + NT * half] = r[half][kh];
     __syncthreads();
     const int ch = t % CPR, p0 = t / CPR;                   // this thread's column chunk; pixels p0, p0 + 16, ...
     int off[8];
@@ -1864,15 +1864,17 @@ int im2col_strip_option(int value) {
 }
 hipError_t launch_im2col_stem(int out_bf16, const float* x, int N, int H, int W, int Cin, int KH, int KW, int stride, int pad,
                               int reflect, int Ho, int Wo, int Kp, void* out, hipStream_t st_) {
-    if (g_im2col_strip && KH == 7 && KW == 7 && Cin == 3 && stride == 2 && pad == 3 && Kp == 160 && (long)H * W * 3 < (1L << 31) &&
-        (long)N * Ho * ((Wo + 63) / 64) < (1L << 31)) {
+    if (g_im2col_strip && KH == 7 && KW == 7 && Cin == 3 && stride == 2 && pad == 3 && (Kp == 160 || (Kp == 192 && out_bf16 == 2)) &&
+        (long)H * W * 3 < (1L << 31) && (long)N * Ho * ((Wo + 63) / 64) < (1L << 31)) {
         const unsigned g64 = (unsigned)((long)N * Ho * ((Wo + 63) / 64)), g128 = (unsigned)((long)N * Ho * ((Wo + 127) / 128));
-        if (out_bf16 == 2)
-            hipLaunchKernelGGL((im2col_stem7_strip_kernel<S3Out, 64>), dim3(g64), dim3(320), 0, st_, x, N, H, W, reflect, Ho, Wo, (S3Out*)out);
+        if (out_bf16 == 2 && Kp == 192)                     // (the split-3 forward pads its patch rows to 64 columns)
+            hipLaunchKernelGGL((im2col_stem7_strip_kernel<S3Out, 64, 192>), dim3(g64), dim3(384), 0, st_, x, N, H, W, reflect, Ho, Wo, (S3Out*)out);
+        else if (out_bf16 == 2)
+            hipLaunchKernelGGL((im2col_stem7_strip_kernel<S3Out, 64, 160>), dim3(g64), dim3(320), 0, st_, x, N, H, W, reflect, Ho, Wo, (S3Out*)out);
         else if (out_bf16)
-            hipLaunchKernelGGL((im2col_stem7_strip_kernel<__bf16, 128>), dim3(g128), dim3(320), 0, st_, x, N, H, W, reflect, Ho, Wo, (__bf16*)out);
+            hipLaunchKernelGGL((im2col_stem7_strip_kernel<__bf16, 128, 160>), dim3(g128), dim3(320), 0, st_, x, N, H, W, reflect, Ho, Wo, (__bf16*)out);
         else
-            hipLaunchKernelGGL((im2col_stem7_strip_kernel<float, 64>), dim3(g64), dim3(320), 0, st_, x, N, H, W, reflect, Ho, Wo, (float*)out);
+            hipLaunchKernelGGL((im2col_stem7_strip_kernel<float, 64, 160>), dim3(g64), dim3(320), 0, st_, x, N, H, W, reflect, Ho, Wo, (float*)out);
         return hipGetLastError();
     }
     if (KH == 7 && KW == 7 && Cin == 3 && Kp % 8 == 0 && (long)N * Ho * Wo * (Kp / 8) < (1L << 31)) {
