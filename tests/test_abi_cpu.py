@@ -188,3 +188,17 @@ def test_hip_adam_has_no_cpu_path_and_keeps_torch_adams_layout():
     assert L.vqseg_adam_step_f32(None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1, None) == -1
     # the second source of a two-use weight gradient must come with its tensors
     assert L.vqseg_conv2d_wgrad2_f(None, None, None, 1, None, None, None, 1, 8, 4, 4, 8, 4, 4, 8, 3, 3, 1, 1, 0, 0, 8, 0, 0, None, 0, None, None) == -1
+
+
+def test_a_failed_fused_batchnorm_launch_zeroes_the_modules_counters():
+    """the opt-in fused BatchNorm launches hand over through per-module counters that must read zero between launches; an
+    entry point that returns an error may leave them dirty -- the host wrapper zeroes them before raising."""
+    import torch
+    from torch import nn
+    from vq_seg_amd import _hip, nnf
+    bn = nn.BatchNorm2d(8)
+    bn._vq_sync = torch.tensor([3, 0, 1, 0], dtype=torch.int32)
+    with pytest.raises(_hip.HipLibraryError):
+        nnf._check_fused_bn(_hip.lib().vqseg_bn_apply_f(1, None, None, None, None, 0, 0, 0, None, None), "vqseg_bn_apply_f (null arguments)", bn)
+    assert int(bn._vq_sync.abs().sum()) == 0
+    nnf._check_fused_bn(0, "ok", bn)                            # a clean return code touches nothing

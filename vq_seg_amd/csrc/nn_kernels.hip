@@ -166,6 +166,9 @@ __global__ __launch_bounds__(256) void bn_stats_merge_kernel(float* __restrict__
 // The results handed over travel through st_agent / ld_agent: device-coherent accesses (sc1: written through / read past this XCD's
 // L2).  NOT __threadfence(): on gfx950 an agent-scope release / acquire fence writes back and invalidates the XCD's whole L2
 // (buffer_wbl2 / buffer_inv), per workgroup -- measured: the step 165 -> 225 ms, mostly in the OTHER stream's kernels.
+// The ordering this relies on (sc1 write-through stores performed at vmcnt(0), then a relaxed agent-scope ticket) is what gfx942 /
+// gfx950 hardware does, NOT a guarantee of the HIP memory model: the path is opt-in (py_bn_fused, default off), and the host side
+// zeroes a module's counters whenever one of the fused entry points returns an error (nnf._check_fused_bn).
 
 __device__ __forceinline__ bool last_workgroup_of(int* sync, int group, unsigned total) {
     __shared__ int s_last;

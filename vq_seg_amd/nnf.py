@@ -176,6 +176,17 @@ def _bn_sync(bn, backward: bool):
     return buf[g:] if backward else buf[:g]
 
 
+def _check_fused_bn(rc: int, what: str, bn) -> None:
+    """`_check` for the two entry points that take a module's hand-over counters: a launch that failed midway may leave them
+    non-zero, and every later fused launch on that module would then never elect a last workgroup (scale / shift / dgamma / dbeta
+    silently stale).  On a non-zero return code the module's counters are zeroed before the error is raised."""
+    if rc != 0:
+        buf = getattr(bn, "_vq_sync", None)
+        if buf is not None:
+            buf.zero_()
+    _check(rc, what)
+
+
 # Side streams for the weight-gradient kernels: {cuda_stream handle of a network's stream: torch.cuda.Stream}.  A trainer that owns
 # the parameters' .grad storage registers one per network stream (trainer.CPSTrainer), adds it to the buckets' producer streams
 # and joins it before the optimiser step.  Empty: everything stays on the calling stream.
@@ -575,14 +586,14 @@ class _ConvBNAct(torch.autograd.Function):
         y = _conv_raw(xr, x2r, c1, w_hi, w_lo, (n, ho, wo, cout), stat, n, h, w, cin, cout, kh, kw, stride, pad, reflect, 1,
                       ho, wo)
         with _hip.on_device(dev):
-            _check(L.vqseg_bn_finalize_f(_f32(stat, "BN partials"), m, cout, _f32(gamma, "bn.weight", cout), _f32(beta, "bn.bias", cout),
+            _check_fused_bn(L.vqseg_bn_finalize_f(_f32(stat, "BN partials"), m, cout, _f32(gamma, "bn.weight", cout), _f32(beta, "bn.bias", cout),
                                          _f32(bn.running_mean, "bn.running_mean", cout), _f32(bn.running_var, "bn.running_var", cout),
                                          float(bn.momentum), float(bn.eps), int(training), _f32(coef[0], "scale", cout),
                                          _f32(coef[1], "shift", cout), _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout),
                                          _T(bn.num_batches_tracked, "bn.num_batches_tracked", dtype=torch.int64, numel=1) if training else None,
                                          _T(_bn_sync(bn, False), "bn sync", dtype=torch.int32) if training else None,
                                          _stream()),   # += 1 in the kernel
-                   "vqseg_bn_finalize_f")
+                   "vqseg_bn_finalize_f", bn)
             rr = _rows(residual) if residual is not None else None
             if rr is not None and rr.dtype != y.dtype:
                 raise _hip.HipLibraryError("residual dtype differs from the activation dtype")
@@ -621,13 +632,13 @@ class _ConvBNAct(torch.autograd.Function):
         dgamma, dbeta = (p_g.grad, p_b.grad) if sink_bn else (dgb[0], dgb[1])
         with _hip.on_device(dev):
             # without a residual the ReLU mask is recomputed from y with the forward's scale / shift: `out` is not re-read
-            _check(L.vqseg_bn_backward_f(bf, _T(g, "output gradient", bf=bf, numel=m * cout),
+            _check_fused_bn(L.vqseg_bn_backward_f(bf, _T(g, "output gradient", bf=bf, numel=m * cout),
                                          _T(out, "BN output", bf=bf, numel=m * cout) if has_res else None, _T(y, "conv output", bf=bf, numel=m * cout),
                                          _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout), _f32(gamma.detach(), "bn.weight", cout),
                                          _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout), m, cout, int(relu), int(training), int(sink_bn),
                                          _f32(ws, "BN backward workspace"), _f32(dgamma, "bn.weight.grad", cout), _f32(dbeta, "bn.bias.grad", cout),
                                          _T(g_y, "conv output gradient", bf=bf, numel=m * cout), _T(g_res, "residual gradient", bf=bf, numel=m * cout),
-                                         _T(_bn_sync(ctx.bn, True), "bn sync", dtype=torch.int32), _stream()), "vqseg_bn_backward_f")
+                                         _T(_bn_sync(ctx.bn, True), "bn sync", dtype=torch.int32), _stream()), "vqseg_bn_backward_f", ctx.bn)
         if sink_bn:
             _sink_done(p_g), _sink_done(p_b)
         link_in, link_out, link_x = ctx.links
