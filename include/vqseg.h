@@ -451,6 +451,19 @@ int vqseg_confusion_counts_f(const float* logits, int64_t stride_b, int64_t stri
  * (clamped to the last).  The two values bracket the virtual index of np.percentile in make_regularized_pseudo_label
  * (deprecated/train_with_test_pt_pseudo_entropy_reg.py:35); the host interpolates.  Replaces the full device sort of
  * torch.quantile (and its 2^24-element input limit).  0 <= k < n < 2^32. */
+/* The loss combination of a CPS iteration in ONE launch (r4; train_vqreptunet1x1v2.py:165-192: sup_1 + sup_2 + cps_weight * (cps_1 +
+ * cps_2) + commitment + prototype, each supervised / CPS term = ce_weight * CE + Dice loss from the sums of vqseg_dice[_ce]_sums_*):
+ *   term_i = ce_weight * ce_i[:, 0].sum() / ce_i[:, 1].sum() + (1 - mean_c mean_b 2 inter_i / (sets_i + eps))     (dice_loss.py:27-37)
+ *   commitment = sum_l (sum_k commit[k][l]) * commit_weight,  prototype = (sum_k *proto[k]) * proto_weight  (float64 inputs)
+ *   out[0] = total, out[1] = commitment, out[2] = prototype, out[3] = cps_1 + cps_2, out[4 + i] = term_i (supervised terms first)
+ * and the gradient of the total with respect to every inter / sets / ce entry (g_*: same shapes; the commitment / prototype inputs'
+ * gradients are the constants commit_weight / proto_weight).  It replaces ~45 scalar autograd nodes forward and ~70 tiny kernels
+ * backward that ran one by one with the GPU idle.  ce / g_ce (and their entries) nullable: no cross-entropy part.  Pointer arrays
+ * are host arrays of device pointers. */
+int vqseg_cps_loss_combine_f(int n_sup, int n_cps, int c, const float* const* inter, const float* const* sets, const float* const* ce,
+                             const int* b, float cps_weight, float ce_weight, float eps, const float* const* commit, int n_commit,
+                             int levels, float commit_weight, const double* const* proto, int n_proto, float proto_weight,
+                             float* const* g_inter, float* const* g_sets, float* const* g_ce, float* out, void* stream);
 size_t vqseg_order_stats_workspace_bytes(void);
 int vqseg_order_stats_f(const float* x, int64_t n, int64_t k, void* workspace, size_t workspace_bytes, float* out2,
                         void* stream);

@@ -258,3 +258,51 @@ def test_fused_ce_dice_matches_the_two_reference_losses(layout, weighted):
     assert abs(l_hip.item() - l_ref.item()) <= 1e-5 * abs(l_ref.item())
     assert rel(g_hip, g_ref) < 1e-5
     assert (g_hip[3] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_ce", [False, True])
+def test_cps_loss_combination_in_one_launch_matches_the_scalar_torch_graph(with_ce):
+    """nnf.cps_loss_combine (vqseg_cps_loss_combine_f, r4): sup_1 + sup_2 + w (cps_1 + cps_2) + commitment + prototype from the Dice
+    (+ CE) sums, total and the gradient with respect to EVERY input, against the same expression written with torch ops (the graph
+    the trainers build: dice_loss.py:27-37, train_vqreptunet1x1v2.py:165-192).  Values 2e-7 relative (the reductions associate
+    differently), gradients 1e-6 of their scale."""
+    from vq_seg_amd import nnf
+    d = torch.device("cuda:0")
+    torch.manual_seed(3)
+    c, cps_w, ce_w, com_w, pro_w = 3, 1.5, (0.5 if with_ce else 0.0), 0.25, 0.01
+
+    def term(b):
+        inter = (torch.rand(b, c, device=d) * 1000).requires_grad_(True)
+        sets = (torch.rand(b, c, device=d) * 3000 + 1000).requires_grad_(True)
+        if not with_ce:
+            return (inter, sets)
+        ce = torch.stack([torch.rand(b, device=d) * 5000, torch.randint(1000, 4000, (b,), device=d).float()], dim=1).requires_grad_(True)
+        return (inter, sets, ce)
+
+    sup, cps = [term(32), term(32)], [term(64), term(64)]
+    commits = [(torch.rand(3, device=d)).requires_grad_(True) for _ in range(4)]
+    protos = [(torch.rand((), device=d, dtype=torch.float64)).requires_grad_(True) for _ in range(4)]
+
+    def scalar(t):
+        dice = 1 - (2 * t[0] / (t[1] + 1e-6)).mean(dim=0).mean()
+        return dice if not with_ce else ce_w * (t[2][:, 0].sum() / t[2][:, 1].sum()) + dice
+    commitment = (commits[0] + commits[1] + commits[2] + commits[3]) * com_w
+    prototype = (protos[0] + protos[1] + protos[2] + protos[3]) * pro_w
+    ref = scalar(sup[0]) + scalar(sup[1]) + cps_w * (scalar(cps[0]) + scalar(cps[1])) + commitment.sum() + prototype.float()
+    leaves = [x for t in sup + cps for x in t] + commits + protos
+    gref = torch.autograd.grad(ref * 1.25, leaves)               # (an upstream factor: backward must scale)
+    got = nnf.cps_loss_combine(sup, cps, cps_w, ce_w, commits, com_w, protos, pro_w)
+    assert got is not None
+    total, stats = got
+    assert not stats.requires_grad and total.requires_grad
+    ggot = torch.autograd.grad(total * 1.25, leaves)
+    rel1 = lambda a, b: (a.double() - b.double()).abs().max().item() / max(b.double().abs().max().item(), 1e-30)
+    assert rel1(total, ref) < 2e-7
+    assert rel1(stats[0], ref) < 2e-7 and rel1(stats[1], commitment.sum()) < 2e-7 and rel1(stats[2], prototype) < 2e-7
+    assert rel1(stats[3], scalar(cps[0]) + scalar(cps[1])) < 2e-7 and rel1(stats[4], scalar(sup[0])) < 2e-7 and rel1(stats[7], scalar(cps[1])) < 2e-7
+    for i, (a, b) in enumerate(zip(ggot, gref)):
+        assert a.shape == b.shape and a.dtype == b.dtype, i
+        assert rel1(a, b) < 1e-6, i
+    # inputs the kernel does not take (class count mismatch, fp64 sums): the caller's torch path
+    assert nnf.cps_loss_combine([(sup[0][0].double(), sup[0][1].double())], [], 1.0, 0.0, [], 0.0, [], 0.0) is None

@@ -102,6 +102,8 @@ SYMBOLS = {
     "vqseg_conv_pack_weights_s2_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vqseg_conv2d_dgrad_s2_f": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "vqseg_conv2d_dgrad_s2_fold_rows": (ctypes.c_int64, [c_int] * 4),
+    "vqseg_cps_loss_combine_f": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_int, c_int,
+                                         c_float, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqseg_conv2d_dgrad_s2_fold_f": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "vqseg_head1x1_backward_add_f": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
                                             c_void_p, c_void_p, c_void_p]),

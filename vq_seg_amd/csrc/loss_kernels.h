@@ -47,4 +47,19 @@ hipError_t launch_dice_forward(const DiceArgs& a, double* partial, float* inter,
 hipError_t launch_dice_backward(const DiceArgs& a, const float* g_inter, const float* g_sets, const float* g_ce, float* g_logits,
                                 hipStream_t st);
 
+// ---- the CPS step's loss combination in one launch (r4): term_i = ce_weight * CE_i + (1 - mean_c mean_b 2 inter / (sets + eps)), i over
+// n_sup supervised terms then n_cps CPS terms; total = ((sum of sup terms + cps_weight * sum of cps terms) + commitment) + prototype with
+// commitment = sum_l (sum_k commit[k][l]) * commit_weight, prototype = (sum_k proto[k]) * proto_weight; and d total / d every input.
+struct CombineArgs {
+    const float* inter[4]; const float* sets[4]; const float* ce[4];       // ce[i] nullable: [b][2]
+    float* g_inter[4]; float* g_sets[4]; float* g_ce[4];
+    int b[4];
+    int n_sup, n_cps, c;
+    float cps_weight, ce_weight, eps;
+    const float* commit[4]; int n_commit, levels; float commit_weight;
+    const double* proto[4]; int n_proto; float proto_weight;
+    float* out;                  // [4 + n_sup + n_cps]: total, commitment, prototype, cps sum (unweighted), term values
+};
+hipError_t launch_loss_combine(const CombineArgs& a, hipStream_t st);
+
 }  // namespace vqseg

@@ -488,6 +488,38 @@ int vqseg_confusion_counts_f(const float* logits, int64_t stride_b, int64_t stri
     return e == hipSuccess ? 0 : hipfail(e, "confusion_kernel");
 }
 
+int vqseg_cps_loss_combine_f(int n_sup, int n_cps, int c, const float* const* inter, const float* const* sets, const float* const* ce,
+                             const int* b, float cps_weight, float ce_weight, float eps, const float* const* commit, int n_commit,
+                             int levels, float commit_weight, const double* const* proto, int n_proto, float proto_weight,
+                             float* const* g_inter, float* const* g_sets, float* const* g_ce, float* out, void* stream) {
+    const int nt = n_sup + n_cps;
+    if (n_sup < 0 || n_cps < 0 || nt < 1 || nt > 4 || c < 1 || c > 8) return bad("cps_loss_combine: 1..4 terms, 1..8 classes");
+    if (!inter || !sets || !b || !g_inter || !g_sets || !out) return bad("cps_loss_combine: null pointer");
+    if (n_commit < 0 || n_commit > 4 || n_proto < 0 || n_proto > 4 || levels < 0 || (n_commit && !commit) || (n_proto && !proto))
+        return bad("cps_loss_combine: at most 4 commitment vectors / prototype scalars");
+    vqseg::CombineArgs a{};
+    for (int i = 0; i < nt; ++i) {
+        if (!inter[i] || !sets[i] || !g_inter[i] || !g_sets[i] || b[i] <= 0) return bad("cps_loss_combine: bad term");
+        a.inter[i] = inter[i]; a.sets[i] = sets[i]; a.g_inter[i] = g_inter[i]; a.g_sets[i] = g_sets[i]; a.b[i] = b[i];
+        a.ce[i] = ce ? ce[i] : nullptr;
+        a.g_ce[i] = (ce && ce[i] && g_ce) ? g_ce[i] : nullptr;
+        if (a.ce[i] && !a.g_ce[i]) return bad("cps_loss_combine: a cross-entropy term needs its gradient buffer");
+    }
+    for (int k = 0; k < n_commit; ++k) {
+        if (!commit[k]) return bad("cps_loss_combine: null commitment vector");
+        a.commit[k] = commit[k];
+    }
+    for (int k = 0; k < n_proto; ++k) {
+        if (!proto[k]) return bad("cps_loss_combine: null prototype loss");
+        a.proto[k] = proto[k];
+    }
+    a.n_sup = n_sup; a.n_cps = n_cps; a.c = c; a.cps_weight = cps_weight; a.ce_weight = ce_weight; a.eps = eps;
+    a.n_commit = n_commit; a.levels = levels; a.commit_weight = commit_weight; a.n_proto = n_proto; a.proto_weight = proto_weight;
+    a.out = out;
+    hipError_t e = vqseg::launch_loss_combine(a, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hipfail(e, "loss_combine_kernel");
+}
+
 size_t vqseg_order_stats_workspace_bytes(void) { return vqseg::order_stats_workspace_bytes(); }
 
 int vqseg_order_stats_f(const float* x, int64_t n, int64_t k, void* workspace, size_t workspace_bytes, float* out2, void* stream) {

@@ -10,6 +10,7 @@ Every function here has exactly one implementation; CPU tensors are refused (no 
 from __future__ import annotations
 
 import contextlib
+import ctypes
 from typing import Optional
 import weakref
 
@@ -1234,6 +1235,87 @@ def dice_ce_sums(pred, target, ignore_index):
     target != ignore_index -- nn.CrossEntropyLoss(ignore_index)'s mean is ce[:, 0].sum() / ce[:, 1].sum() -- in the same pass
     over the logits, forward and backward (vqseg_dice_ce_sums_*)."""
     return _DiceSums.apply(pred, target, ignore_index, True)
+
+
+class _CPSCombine(torch.autograd.Function):
+    """vqseg_cps_loss_combine_f: total = sup terms + cps_w * cps terms + commitment + prototype from the Dice (+ CE) sums, in one launch,
+    with the gradient of the total with respect to every input written in the same launch (backward = one scaling)."""
+
+    @staticmethod
+    def forward(ctx, spec, *ts):
+        n_sup, n_cps, has_ce, cps_w, ce_w, eps, commit_w, proto_w, n_commit, n_proto = spec
+        nt, per = n_sup + n_cps, (3 if has_ce else 2)
+        terms = [ts[i * per:(i + 1) * per] for i in range(nt)]
+        commits = ts[nt * per: nt * per + n_commit]
+        protos = ts[nt * per + n_commit:]
+        dev = terms[0][0].device
+        c = terms[0][0].shape[1]
+        bs = [int(t[0].shape[0]) for t in terms]
+        levels = int(commits[0].numel()) if commits else 0
+        sizes = []
+        for b in bs:
+            sizes += [b * c, b * c] + ([b * 2] if has_ce else [])
+        gbuf = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        views = list(torch.split(gbuf, sizes))
+        out = torch.empty(4 + nt, dtype=torch.float32, device=dev)
+        P4 = ctypes.c_void_p * 4
+
+        def arr(tensors, what, dtype=torch.float32):
+            a = P4()
+            for i, t in enumerate(tensors):
+                a[i] = _T(t, what, dtype=dtype) if t is not None else None
+            return a
+
+        inter = arr([t[0] for t in terms], "intersections")
+        sets = arr([t[1] for t in terms], "set sizes")
+        ce = arr([t[2] for t in terms], "cross-entropy sums") if has_ce else None
+        g_inter = arr(views[0::per], "gradient of the intersections")
+        g_sets = arr(views[1::per], "gradient of the set sizes")
+        g_ce = arr(views[2::per], "gradient of the cross-entropy sums") if has_ce else None
+        b_arr = (ctypes.c_int * 4)(*(bs + [0] * (4 - nt)))
+        with _hip.on_device(dev):
+            _check(lib().vqseg_cps_loss_combine_f(n_sup, n_cps, c, inter, sets, ce, b_arr, float(cps_w), float(ce_w), float(eps),
+                                                  arr(commits, "commitment losses"), n_commit, levels, float(commit_w),
+                                                  arr(protos, "prototype losses", dtype=torch.float64), n_proto, float(proto_w),
+                                                  g_inter, g_sets, g_ce, _f32(out, "loss terms", 4 + nt), _stream()), "vqseg_cps_loss_combine_f")
+        ctx.gbuf, ctx.sizes, ctx.shapes = gbuf, sizes, [tuple(x.shape) for t in terms for x in t]
+        ctx.tail = (n_commit, n_proto, levels, float(commit_w), float(proto_w), [tuple(x.shape) for x in commits])
+        total = out[0].clone()
+        ctx.mark_non_differentiable(out)
+        return total, out
+
+    @staticmethod
+    def backward(ctx, g, _g_stats):
+        n_commit, n_proto, levels, commit_w, proto_w, cshapes = ctx.tail
+        gb = ctx.gbuf * g
+        grads = [v.reshape(sh) for v, sh in zip(torch.split(gb, ctx.sizes), ctx.shapes)]
+        gc = (g * commit_w)
+        gp = (g.double() * proto_w)
+        return (None, *grads, *[gc.expand(sh) for sh in cshapes], *[gp for _ in range(n_proto)])
+
+
+def cps_loss_combine(sup_terms, cps_terms, cps_weight, ce_weight, commits, commit_weight, protos, proto_weight, eps=1e-6):
+    """-> (total, stats) with stats = [total, commitment, prototype, cps_1 + cps_2, sup_1, .., cps_1, ..] (no gradient through stats).
+    `sup_terms` / `cps_terms`: lists of (inter, sets) or (inter, sets, ce) from dice_sums / dice_ce_sums; `commits`: fp32 vectors of
+    one length; `protos`: float64 scalars.  None when the inputs are not what the kernel takes (the caller combines with torch ops)."""
+    terms = list(sup_terms) + list(cps_terms)
+    if not terms or len(terms) > 4 or len(commits) > 4 or len(protos) > 4 or not py_opt("py_loss_combine", 1):
+        return None
+    has_ce = len(terms[0]) == 3
+    flat = []
+    for t in terms:
+        if len(t) != (3 if has_ce else 2) or not all(torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() for x in t):
+            return None
+        if t[0].dim() != 2 or t[0].shape != t[1].shape or t[0].shape[1] != terms[0][0].shape[1] or (has_ce and tuple(t[2].shape) != (t[0].shape[0], 2)):
+            return None
+        flat += list(t)
+    if not all(torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 1 and x.shape == commits[0].shape for x in commits):
+        return None
+    if not all(torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float64 and x.numel() == 1 for x in protos):
+        return None
+    spec = (len(sup_terms), len(cps_terms), has_ce, float(cps_weight), float(ce_weight), float(eps), float(commit_weight), float(proto_weight),
+            len(commits), len(protos))
+    return _CPSCombine.apply(spec, *flat, *commits, *protos)
 
 
 def softmax_stats(logits, want_label=True, want_entropy=True, want_top=False):

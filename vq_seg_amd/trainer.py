@@ -485,6 +485,16 @@ class CPSTrainer:
         with on(1):
             ps2, pu2, pred_2, mask_2 = own_mask(ps2, pu2)
         exchange(mask_1, mask_2)
+        # r4: with the Dice criterion (no class weights) the four terms stay as their (inter, sets[, ce]) sums and the whole combination
+        # -- terms, commitment, prototype, total, and its gradient -- is one launch (nnf.cps_loss_combine); else scalar torch ops
+        crt = self.criterion
+        fuse = (isinstance(crt, DiceLoss) and crt.weight is None and crt.ignore_index is not None and pred_1.is_cuda
+                and nnf.dice_sums_supported(pred_1, crt.num_classes) and nnf.py_opt("py_loss_combine", 1) == 1)
+        if fuse:
+            def crit(pred, target):                                     # noqa: F811  (the sums; combined below)
+                if cfg.recipe == "v1":
+                    return nnf.dice_sums(pred, target, crt.ignore_index)
+                return nnf.dice_ce_sums(pred, target, crt.ignore_index)
         with on(0):
             cps_1, sup_1 = crit(pred_1, mask_2), crit(ps1, l_target)
         with on(1):
@@ -493,16 +503,32 @@ class CPSTrainer:
             self._pending_sides.update(streams)
             self._join()
             for t in (cps_1, sup_1, cps_2, sup_2, ps1, pu2, mask_1, mask_2, score_1, score_2):
-                t.record_stream(main)
-        cps = cps_1 + cps_2
+                for x in (t if isinstance(t, tuple) else (t,)):
+                    x.record_stream(main)
         if cfg.keep_aux:
             self.aux = dict(mask_1=mask_1, mask_2=mask_2, score_1=score_1, score_2=score_2, pred_sup_1=ps1.detach(), pred_ul_2=pu2.detach())
-        commitment = (c_l1 + c_l2 + c_u1 + c_u2) * cfg.total_commitment_loss_weight
-        prototype = (p_l1 + p_l2 + p_u1 + p_u2) * cfg.total_prototype_loss_weight
         lr = self.sched.get_lr(self.iter)
         for o in self.opts:
             o.param_groups[0]["lr"] = lr
-        loss = sup_1 + sup_2 + cfg.cps_loss_weight * cps + commitment.sum() + prototype.float()
+        combined = None
+        if fuse:
+            combined = nnf.cps_loss_combine([sup_1, sup_2], [cps_1, cps_2], cfg.cps_loss_weight, 0.0 if cfg.recipe == "v1" else 0.5,
+                                            [c_l1, c_l2, c_u1, c_u2], cfg.total_commitment_loss_weight,
+                                            [p_l1, p_l2, p_u1, p_u2], cfg.total_prototype_loss_weight)
+            if combined is None:                                        # inputs the kernel does not take: the same terms with torch ops
+                def scalar(t):
+                    dice = 1 - (2 * t[0] / (t[1] + 1e-6)).mean(dim=0).mean()
+                    return dice if len(t) == 2 else 0.5 * (t[2][:, 0].sum() / t[2][:, 1].sum()) + dice
+                cps_1, sup_1, cps_2, sup_2 = scalar(cps_1), scalar(sup_1), scalar(cps_2), scalar(sup_2)
+        if combined is not None:
+            loss, stats = combined
+            com_sum, prototype, cps, sup_1, sup_2 = stats[1], stats[2], stats[3], stats[4], stats[5]
+        else:
+            cps = cps_1 + cps_2
+            commitment = (c_l1 + c_l2 + c_u1 + c_u2) * cfg.total_commitment_loss_weight
+            prototype = (p_l1 + p_l2 + p_u1 + p_u2) * cfg.total_prototype_loss_weight
+            com_sum = commitment.sum()
+            loss = sup_1 + sup_2 + cfg.cps_loss_weight * cps + com_sum + prototype.float()
         self._wgrad_sides(True)
         try:
             loss.backward()
@@ -535,7 +561,7 @@ class CPSTrainer:
             miou, _ = miou_device(confusion_matrix_device(ps1, l_target, cfg.num_classes))
         self._join()
         return {"loss": loss.detach(), "sup_loss_1": sup_1.detach(), "sup_loss_2": sup_2.detach(), "cps_loss": cps.detach(),
-                "commitment_loss": commitment.detach().sum(), "prototype_loss": prototype.detach(), "miou": miou,
+                "commitment_loss": com_sum.detach(), "prototype_loss": prototype.detach(), "miou": miou,
                 "lr": torch.tensor(lr)}
 
     def sync_buffers(self):
