@@ -832,3 +832,26 @@ def test_exact_2x_bilinear_kernels_are_bit_identical_to_the_generic_ones(shape, 
     yr.backward(g.float().cpu())
     tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
     assert rel(fast[0].float(), yr) < tol and rel(fast[1].float(), xr.grad) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 32, 24, 40, 3), (1, 16, 9, 7, 3), (2, 64, 16, 16, 5)])
+def test_conv_with_bias_head_on_the_hip_kernels(shape):
+    """nnf.conv2d_bias (r4): the plain Unet's 3x3 + bias head (segmentation_head.py:78-83; 32 -> 3 channels, fp32) on the precise-mode
+    kernels, output channels padded to their 4-channel granule, bias in the fused epilogue -- forward and all three gradients against
+    F.conv2d in fp64 (split bf16 hi + lo operands: 2e-5 of the scale)."""
+    from vq_seg_amd import nnf
+    n, cin, h, w, cout = shape
+    x = synth.uniform(sum(shape), (n, cin, h, w), -1, 1)
+    wt = synth.uniform(sum(shape) + 1, (cout, cin, 3, 3), -0.3, 0.3)
+    b = synth.uniform(sum(shape) + 2, (cout,), -0.5, 0.5)
+    g = synth.uniform(sum(shape) + 3, (n, cout, h, w), -1, 1)
+    xr, wr, br = x.double().requires_grad_(True), wt.double().requires_grad_(True), b.double().requires_grad_(True)
+    F.conv2d(xr, wr, br, 1, 1).backward(g.double())
+    xd = cl(x).to(dev()).requires_grad_(True)
+    wd, bd = wt.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    y = nnf.conv2d_bias(xd, wd, bd, 1)
+    assert y.shape == (n, cout, h, w) and y.dtype == torch.float32
+    y.backward(g.to(dev()))
+    assert rel(y.detach(), F.conv2d(x.double(), wt.double(), b.double(), 1, 1)) < 2e-5
+    assert rel(xd.grad, xr.grad) < 2e-5 and rel(wd.grad, wr.grad) < 2e-5 and rel(bd.grad, br.grad) < 2e-5

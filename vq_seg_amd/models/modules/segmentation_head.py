@@ -15,12 +15,15 @@ class _Up(nn.Module):
 
 
 class _Conv(nn.Conv2d):
-    """3x3 conv WITH bias, 32 -> num_classes: only the plain `unet` plumbing model (BASELINE config #1, a CPU
-    wiring check in the reference) has this layer; it is not on the north-star path and stays an ATen call."""
+    """3x3 conv WITH bias, 32 -> num_classes: only the plain `unet` plumbing model (BASELINE config #1, a CPU wiring check in the
+    reference) has this layer.  r4: on the precise-mode HIP kernels like everything else (output channels padded to their 4-channel
+    granule, the bias in the convolution's epilogue: nnf.conv2d_bias); shapes those kernels do not take (input channels not a
+    multiple of 4, stride / rectangular padding) raise there."""
 
     def forward(self, x):
-        import torch.nn.functional as F
-        return F.conv2d(x.float(), self.weight, self.bias, self.stride, self.padding)
+        if self.stride != (1, 1) or self.padding[0] != self.padding[1] or self.dilation != (1, 1) or self.groups != 1:
+            raise NotImplementedError("segmentation head: stride 1, square padding, no dilation / groups on the accelerated path")
+        return nnf.conv2d_bias(x, self.weight, self.bias, self.padding[0])
 
 
 class SegmentationHead(nn.Sequential):

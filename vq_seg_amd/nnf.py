@@ -1237,6 +1237,80 @@ def dice_ce_sums(pred, target, ignore_index):
     return _DiceSums.apply(pred, target, ignore_index, True)
 
 
+class _ConvBias(torch.autograd.Function):
+    """k x k / stride 1 convolution WITH bias and a handful of output channels, fp32 (the plain Unet's segmentation head: 32 -> 3,
+    segmentation_head.py:78-83) on the precise-mode kernels: output channels zero-padded to the kernels' 4-channel granule, the bias in
+    the convolution's fused epilogue (vqseg_conv2d_affine_f: scale 1, shift = bias); backward = the data-gradient / weight-gradient
+    kernels on the padded gradient, the bias gradient a plain sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad):
+        xr = _rows(x.float())
+        n, h, w, cin = xr.shape
+        cout, _, kh, kw = weight.shape
+        cp = (cout + 3) // 4 * 4
+        dev = xr.device
+        wp = torch.zeros(cp, cin, kh, kw, dtype=torch.float32, device=dev)
+        wp[:cout] = weight.detach()
+        shift = torch.zeros(cp, dtype=torch.float32, device=dev)
+        if bias is not None:
+            shift[:cout] = bias.detach()
+        one = torch.ones(cp, dtype=torch.float32, device=dev)
+        L = lib()
+
+        def pack(tr):
+            ne = L.vqseg_conv_packed_elems(cp, cin, kh, kw, int(tr))
+            hi, lo = torch.empty(ne, dtype=torch.int16, device=dev), torch.empty(ne, dtype=torch.int16, device=dev)
+            with _hip.on_device(dev):
+                _check(L.vqseg_conv_pack_weights_f32(_f32(wp, "weight", cp * cin * kh * kw), cp, cin, kh, kw, int(tr), _w16(hi, "packed hi", ne),
+                                                     _w16(lo, "packed lo", ne), _stream()), "vqseg_conv_pack_weights_f32")
+            return hi, lo, ne
+
+        hi, lo, ne = pack(False)
+        ho, wo = _out_size(h, kh, 1, pad), _out_size(w, kw, 1, pad)
+        y = torch.empty((n, ho, wo, cp), dtype=torch.float32, device=dev)
+        with _hip.on_device(dev):
+            _check(L.vqseg_conv2d_affine_f(_T(xr, "conv input", bf=0, numel=n * h * w * cin), None, cin, _w16(hi, "packed weights", ne),
+                                           _w16(lo, "packed weights (lo)", ne), _f32(one, "unit scale", cp), _f32(shift, "bias", cp), None, 0,
+                                           _T(y, "conv output", bf=0, numel=n * ho * wo * cp), n, h, w, cin, cp, kh, kw, 1, pad, 0, ho, wo, 1,
+                                           _stream()), "vqseg_conv2d_affine_f")
+        ctx.save_for_backward(xr)
+        ctx.cfg = (n, h, w, cin, cout, cp, kh, kw, pad, ho, wo, bias is not None)
+        ctx.pack = pack
+        return y[..., :cout].permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        (xr,) = ctx.saved_tensors
+        n, h, w, cin, cout, cp, kh, kw, pad, ho, wo, has_bias = ctx.cfg
+        dev = xr.device
+        L = lib()
+        g4 = torch.zeros((n, ho, wo, cp), dtype=torch.float32, device=dev)
+        g4[..., :cout] = g.permute(0, 2, 3, 1)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            t_hi, t_lo, _ = ctx.pack(True)                      # [Cin][kh][kw][cp], taps flipped
+            gx = _nchw(_conv_raw(g4, None, cp, t_hi, t_lo, (n, h, w, cin), None, n, ho, wo, cp, cin, kh, kw, 1, kh - 1 - pad, False, 1, h, w))
+        if ctx.needs_input_grad[1]:
+            nbytes = L.vqseg_conv2d_wgrad_workspace_bytes(n, h, w, cin, ho, wo, cp, kh, kw)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            gw4 = torch.empty((cp, cin, kh, kw), dtype=torch.float32, device=dev)
+            with _hip.on_device(dev):
+                _check(L.vqseg_conv2d_wgrad_f(_T(g4, "conv output gradient", bf=0, numel=n * ho * wo * cp), _T(xr, "conv input", bf=0, numel=n * h * w * cin),
+                                              None, cin, n, h, w, cin, ho, wo, cp, kh, kw, 1, pad, 0, 1, cin, 0, 0,
+                                              _T(ws, "wgrad workspace", dtype=torch.uint8, numel=nbytes), nbytes, _f32(gw4, "weight gradient", cp * cin * kh * kw),
+                                              _stream()), "vqseg_conv2d_wgrad_f")
+            gw = gw4[:cout]
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(dim=(0, 2, 3))
+        return gx, gw, gb, None
+
+
+def conv2d_bias(x, weight, bias, padding: int):
+    """F.conv2d(x.float(), weight, bias, stride 1, padding) on the HIP kernels (few output channels; fp32 like the reference's head)."""
+    return _ConvBias.apply(x, weight, bias, int(padding))
+
+
 class _CPSCombine(torch.autograd.Function):
     """vqseg_cps_loss_combine_f: total = sup terms + cps_w * cps terms + commitment + prototype from the Dice (+ CE) sums, in one launch,
     with the gradient of the total with respect to every input written in the same launch (backward = one scaling)."""
