@@ -484,7 +484,7 @@ def main():
             one(i)
         torch.cuda.synchronize()
         if rank == 0:
-            conv_recs = _hip.conv_profile_collect(4096)
+            conv_recs = _hip.conv_profile_collect(4096, with_shape=True)
         trainer._two_streams = was_two
     if multi:
         dist.barrier()
@@ -608,6 +608,9 @@ def main():
                                        "what": "forward + backward + Adam of ONE network on the labelled half of the batch "
                                                "(0.5 CE + Dice + commitment + prototype loss), 3 steps after the timed region"}
         if conv_recs:
+            conv_shapes = [r[3] for r in conv_recs]
+            conv_recs = [(r[0], r[1], r[2]) for r in conv_recs]
+
             def rate(sel):
                 fl = sum(f for f, kd, m in conv_recs if sel(kd))
                 ms_ = sum(m for f, kd, m in conv_recs if sel(kd))
@@ -615,11 +618,30 @@ def main():
                 return {"launches_per_step": n_ // 2, "tflop_per_step": round(fl / 2 / 1e12, 3), "ms_per_step": round(ms_ / 2, 3),
                         "tflops": round(fl / ms_ / 1e9, 1) if ms_ > 0 else 0.0}
             k3 = rate(lambda kd: kd == 300)
+            # algorithmic bytes of the same launches: input rows + output rows + the weight, bf16 (pixels from the recorded flops)
+            alg, n3 = 0.0, 0
+            for (f, kd, _m), sh in zip(conv_recs, conv_shapes):
+                if kd == 300 and sh[1] > 0 and sh[2] > 0:
+                    px = f / (2.0 * 9 * sh[1] * sh[2])
+                    st = max(sh[3] // 10, 1)
+                    alg += 2.0 * (px * st * st * sh[1] + px * sh[2] + 9 * sh[1] * sh[2])
+                    n3 += 1
+            conv_traffic, conv_traffic_src = None, "no committed counter summary found"
+            pmc_conv = os.path.join(ROOT, "profiles", "r04_conv_step_pmc.json")
+            if os.path.exists(pmc_conv):
+                with open(pmc_conv) as f_:
+                    conv_traffic = int(json.load(f_)["conv3x3_bf16_fwd_dgrad"]["hbm_bytes_per_launch"])
+                conv_traffic_src = ("profiles/r04_conv_step_pmc.json (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes over this command, tools/pmc_conv_step.sh): average "
+                                    "HBM-side bytes per launch over the step's 3x3 bf16 forward / data-gradient launches (Infinity-Cache hits are counted; a launch "
+                                    "re-reads its input rows once per 128-channel output chunk, its weights once per pixel tile)")
             line["roofline_conv"] = {
                 "kernel": "conv3x3_patch_kernel / conv_igemm_glds_kernel (every 3x3 bf16 launch: forward + data gradient)",
                 "bound": "mfma", "achieved": k3["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(k3["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "traffic_source": "per-layer PMC passes (tools/pmc_conv.sh -> profiles/r04_conv_layers_pmc.md when present, else r02_conv_patch_pmc.md): HBM-side bytes 1.2-4.0x algorithmic, Infinity-Cache hits included; no single per-launch figure exists for an aggregate over 260 launches of 40 shapes",
+                "frac": round(k3["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": conv_traffic,
+                "traffic_source": conv_traffic_src,
+                "algorithmic_bytes_per_launch": int(alg / n3) if n3 else None,
+                "other_roof": {"bound": "hbm", "achieved": round(alg / 2 / (k3["ms_per_step"] * 1e-3) / 1e9, 1) if k3["ms_per_step"] > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "note": "algorithmic bytes of the same launches over the same event time"},
                 "by_kind": {"3x3 bf16": k3, "1x1 bf16": rate(lambda kd: kd == 100), "3x3 split-3 (fp32-precision eval)": rate(lambda kd: kd == 302),
                             "1x1 split-3": rate(lambda kd: kd == 102), "precise (fp32 activations)": rate(lambda kd: kd % 100 == 1),
                             "3x3 weight gradient bf16": rate(lambda kd: kd == 350), "1x1 weight gradient bf16": rate(lambda kd: kd == 150),
