@@ -70,6 +70,12 @@ struct WgradArgs {
     const void* x_b = nullptr;
     const void* x2_b = nullptr;
     int Na = 0;
+    // r4: XCD-aware workgroup order of the LDS-DMA weight-gradient kernels (1-D grid).  The (ci tile, co tile) workgroups of ONE pixel
+    // slab all read that slab's rows (each x slice once per co tile, each g_y slice once per ci tile); dispatched as a 3-D grid they
+    // land on different XCDs (consecutive ids go round-robin) and every XCD fetches its own copy through the fabric (counters: 2.3-2.4 x
+    // the algorithmic bytes).  With xcd_slabs > 0 workgroup id -> XCD = id & 7, slab = 8 * (id / (8 T)) + XCD, tile = (id / 8) % T
+    // (T = ci tiles x co tiles): a slab's tiles run back to back on one XCD and share its L2.  0: plain (ci, co, slab) grid.
+    int xcd_slabs = 0;
 };
 
 hipError_t launch_conv(const ConvArgs& a, int precise, hipStream_t st);

@@ -1151,6 +1151,7 @@ static int g_patch_tile512_min_wgs = 512;
 static int g_patch_tile512_launches = 0;                    // launches that took a 512-pixel tile (tests read it to see the dispatch)
 static int g_patch_unroll = 1;                              // 128-channel tile: tap loop unrolled
 static int g_wgrad1x1_narrow = 1;                           // 64-output-channel 1x1 weight gradients (stem patch matrix, 64 -> 64) on the LDS-DMA kernel
+static int g_wgrad_xcd = 1;                                 // LDS-DMA weight gradients: a slab's (ci, co) tiles on one XCD (WgradArgs::xcd_slabs); 0: 3-D grid
 static int g_wgrad3x3_fill = 1;                             // nine-tap weight gradients: slabs sized to one full round of resident workgroups (0: r3's split)
 static int g_wgrad3x3_s2 = 1;                               // stride-2 3x3 weight gradients on the nine-tap kernel (0: the per-tap kernel, r3)
 
@@ -1163,6 +1164,11 @@ int conv_set_option(const char* key, int value) {
     if (key && !strcmp(key, "conv_wgrad1x1_narrow")) {
         const int prev = g_wgrad1x1_narrow;
         g_wgrad1x1_narrow = value;
+        return prev;
+    }
+    if (key && !strcmp(key, "conv_wgrad_xcd")) {
+        const int prev = g_wgrad_xcd;
+        g_wgrad_xcd = value;
         return prev;
     }
     if (key && !strcmp(key, "conv_dgrad_s2_merge")) {
@@ -2200,10 +2206,18 @@ __global__ __launch_bounds__((Wg3<COT, CIT, S>::NW * 64)) void conv_wgrad3x3_ker
     const int wc = wave % C::WC, wo = (wave / C::WC) % C::WO, wt = wave / (C::WC * C::WO);
     const int t0 = (9 * wt + C::WT - 1) / C::WT, t1 = (9 * (wt + 1) + C::WT - 1) / C::WT;
 
-    const int ci0 = blockIdx.x * (32 * CIT), co0 = blockIdx.y * (32 * COT);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_slabs > 0) {                                  // 1-D grid, a slab's tiles on one XCD (WgradArgs::xcd_slabs)
+        const int cit = p.Cin / (32 * CIT), t_all = cit * (p.Cout / (32 * COT));
+        const int q = blockIdx.x >> 3, t = q % t_all;
+        bz = (q / t_all) * 8 + (int)(blockIdx.x & 7u);
+        if (bz >= p.xcd_slabs) return;
+        bx = t % cit, by = t / cit;
+    }
+    const int ci0 = bx * (32 * CIT), co0 = by * (32 * COT);
     const int bw = p.Wo >> 4, bh = p.Ho / C::BH;
     const int n_blk = p.N * bh * bw;
-    const int b_begin = blockIdx.z * blocks_per_slab;
+    const int b_begin = bz * blocks_per_slab;
     int b_end = b_begin + blocks_per_slab;
     if (b_end > n_blk) b_end = n_blk;
     const int ns = b_end > b_begin ? b_end - b_begin : 0;
@@ -2338,7 +2352,7 @@ __global__ __launch_bounds__((Wg3<COT, CIT, S>::NW * 64)) void conv_wgrad3x3_ker
     // sum.  The accumulators (row = co on registers, column = ci on lanes, tap = register array) go through LDS
     // 16 output channels at a time as [co][ci][tap] and leave as contiguous 16-byte stores.
     const int r = lane & 31, h = lane >> 5;
-    float* slab = p.partial + (long)blockIdx.z * p.Cout * 9 * p.Cin;
+    float* slab = p.partial + (long)bz * p.Cout * 9 * p.Cin;
     float* tile = reinterpret_cast<float*>(smem);
     constexpr int ROW = 32 * CIT * 9;                      // floats per output channel of this workgroup's tile
     __syncthreads();                                       // ring slots are free
@@ -2424,10 +2438,18 @@ __global__ __launch_bounds__((Wg1<COT, CIT>::NW * 64)) void conv_wgrad1x1_kernel
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave % C::WO, wc = wave / C::WO;
-    const int ci0 = blockIdx.x * (32 * CIT), co0 = blockIdx.y * (32 * COT);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_slabs > 0) {                                  // 1-D grid, a slab's tiles on one XCD (WgradArgs::xcd_slabs)
+        const int cit = p.Cin / (32 * CIT), t_all = cit * (p.Cout / (32 * COT));
+        const int q = blockIdx.x >> 3, t = q % t_all;
+        bz = (q / t_all) * 8 + (int)(blockIdx.x & 7u);
+        if (bz >= p.xcd_slabs) return;
+        bx = t % cit, by = t / cit;
+    }
+    const int ci0 = bx * (32 * CIT), co0 = by * (32 * COT);
     const long M = (long)p.N * p.Ho * p.Wo;
     const long n_stage_all = (M + 63) / 64;
-    const long s_begin = (long)blockIdx.z * stages_per_slab;
+    const long s_begin = (long)bz * stages_per_slab;
     long s_end = s_begin + stages_per_slab;
     if (s_end > n_stage_all) s_end = n_stage_all;
     const int ns = s_end > s_begin ? (int)(s_end - s_begin) : 0;
@@ -2539,7 +2561,7 @@ __global__ __launch_bounds__((Wg1<COT, CIT>::NW * 64)) void conv_wgrad1x1_kernel
 
     // ---- slab [z][Cout][Cin] fp32 (row = co on registers, column = ci on lanes: 128-byte runs)
     const int r = lane & 31, h = lane >> 5;
-    float* slab = p.partial + (long)blockIdx.z * p.Cout * p.Cin;
+    float* slab = p.partial + (long)bz * p.Cout * p.Cin;
 #pragma unroll
     for (int a = 0; a < C::PM; ++a)
 #pragma unroll
@@ -2592,6 +2614,14 @@ static Wg1Plan wgrad1x1_plan(const WgradArgs& a, int precise, bool shape_only) {
 template <int COT, int CIT>
 static void wgrad1x1_launch_t(const WgradArgs& a, const Wg1Plan& pl, hipStream_t st) {
     using C = Wg1<COT, CIT>;
+    const unsigned tiles = (unsigned)(a.Cin / (32 * CIT)) * (unsigned)(a.Cout / (32 * COT));
+    if (g_wgrad_xcd && tiles > 1 && pl.slabs >= 8) {
+        WgradArgs b = a;
+        b.xcd_slabs = pl.slabs;
+        hipLaunchKernelGGL((conv_wgrad1x1_kernel<COT, CIT>), dim3(8u * tiles * (unsigned)((pl.slabs + 7) / 8)), dim3(C::NW * 64), (size_t)C::NBUF * C::STAGE, st,
+                           b, pl.stages_per_slab);
+        return;
+    }
     dim3 grid((unsigned)(a.Cin / (32 * CIT)), (unsigned)(a.Cout / (32 * COT)), (unsigned)pl.slabs);
     hipLaunchKernelGGL((conv_wgrad1x1_kernel<COT, CIT>), grid, dim3(C::NW * 64), (size_t)C::NBUF * C::STAGE, st, a, pl.stages_per_slab);
 }
@@ -2656,6 +2686,14 @@ static Wg3Plan wgrad3x3_plan(const WgradArgs& a, int precise, bool shape_only, i
 template <int COT, int CIT, int S = 1>
 static void wgrad3x3_launch_t(const WgradArgs& a, const Wg3Plan& pl, hipStream_t st) {
     using C = Wg3<COT, CIT, S>;
+    const unsigned tiles = (unsigned)(a.Cin / (32 * CIT)) * (unsigned)(a.Cout / (32 * COT));
+    if (g_wgrad_xcd && tiles > 1 && pl.slabs >= 8) {
+        WgradArgs b = a;
+        b.xcd_slabs = pl.slabs;
+        hipLaunchKernelGGL((conv_wgrad3x3_kernel<COT, CIT, S>), dim3(8u * tiles * (unsigned)((pl.slabs + 7) / 8)), dim3(C::NW * 64), (size_t)C::NBUF * C::STAGE,
+                           st, b, pl.blocks_per_slab);
+        return;
+    }
     dim3 grid((unsigned)(a.Cin / (32 * CIT)), (unsigned)(a.Cout / (32 * COT)), (unsigned)pl.slabs);
     hipLaunchKernelGGL((conv_wgrad3x3_kernel<COT, CIT, S>), grid, dim3(C::NW * 64), (size_t)C::NBUF * C::STAGE, st, a, pl.blocks_per_slab);
 }
