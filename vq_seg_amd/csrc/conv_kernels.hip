@@ -2197,6 +2197,9 @@ __device__ __forceinline__ bf16x8 tr_frag_swz(const char* tile, int pix0, int co
     return __builtin_bit_cast(bf16x8, v);
 }
 
+#ifndef WGRAD_WALK_DOWN
+#define WGRAD_WALK_DOWN 1
+#endif
 template <int COT, int CIT, int S = 1>
 __global__ __launch_bounds__((Wg3<COT, CIT, S>::NW * 64)) void conv_wgrad3x3_kernel(const WgradArgs p, int blocks_per_slab) {
     using C = Wg3<COT, CIT, S>;
@@ -2272,10 +2275,20 @@ __global__ __launch_bounds__((Wg3<COT, CIT, S>::NW * 64)) void conv_wgrad3x3_ker
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][t][i] = 0.0f;
 
-    // block being issued: (image, block row, block column), advanced without divisions
+    // block being issued: (image, block column, block row), advanced without divisions.  r4: the walk goes DOWN a column of blocks
+    // first (WGRAD_WALK_DOWN): consecutive blocks then share the 2 halo rows of the same 18 / 33 patch columns, re-read by the very
+    // next stage out of L2, instead of 16+ blocks later when a row-major walk comes back one block row further down (the vertical
+    // halo was 1/3 of the patch traffic: counters 1.5 x the input bytes; the horizontal one, 2 of 18 columns, still comes around late).
+    // Any bijection of the block index is a valid order: a slab is a range of it.
+#if WGRAD_WALK_DOWN
+    int in_ = b_begin / (bh * bw);
+    int ibx = (b_begin - in_ * bh * bw) / bh;
+    int iby = b_begin - (in_ * bw + ibx) * bh;
+#else
     int in_ = b_begin / (bh * bw);
     int iby = (b_begin - in_ * bh * bw) / bw;
     int ibx = b_begin - (in_ * bh + iby) * bw;
+#endif
 
     auto stage = [&](int buf) {
         char* Gs = smem + buf * C::STAGE;
@@ -2299,6 +2312,15 @@ __global__ __launch_bounds__((Wg3<COT, CIT, S>::NW * 64)) void conv_wgrad3x3_ker
             const long off = (((long)img * p.H + ih) * p.W + iw) * csrc + p_ch[i];
             glds16(ok ? xsrc + off * 2 : zero, Ps + (wave + C::NW * i) * 1024);
         }
+#if WGRAD_WALK_DOWN
+        if (++iby == bh) {
+            iby = 0;
+            if (++ibx == bw) {
+                ibx = 0;
+                ++in_;
+            }
+        }
+#else
         if (++ibx == bw) {
             ibx = 0;
             if (++iby == bh) {
@@ -2306,6 +2328,7 @@ __global__ __launch_bounds__((Wg3<COT, CIT, S>::NW * 64)) void conv_wgrad3x3_ker
                 ++in_;
             }
         }
+#endif
     };
 
     auto compute = [&](int buf) {
