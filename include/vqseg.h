@@ -72,6 +72,8 @@ const char* vqseg_kernel_name(const char* entry_point);
  *                                   four-launch path with the padded grid)
  *   "conv_wgrad3x3_fill"            1 (default): nine-tap weight gradients split into one FULL round of resident workgroups (r4);
  *                                   0: r3's split
+ *   "stem_fused"                    1 (default): vqseg_stem7_conv_f available (r4); 0: it returns VQSEG_EINVAL (patch-matrix path)
+ *   "conv_wgrad_xcd"                1 (default): a pixel slab's (ci, co) tiles of the LDS-DMA weight-gradient kernels on one XCD (r4); 0: 3-D grid
  *   "im2col_strip"                  1 (default): the stem's patch matrix from LDS-staged strips (r4, bit-identical); 0: the gather kernel
  * The environment variable VQSEG_OPTS="key=value,..." applies options when the Python binding loads the library.
  * Returns the previous value, or VQSEG_EINVAL for an unknown key / negative value.  Not thread safe. */
@@ -336,6 +338,16 @@ int vqseg_maxpool3x3s2_backward_add_f(int bf16, const void* g, const unsigned ch
 int vqseg_im2col_f(int out_bf16, const float* x, int n, int h, int w, int cin, int kh, int kw, int stride,
                    int pad, int reflect, int ho, int wo, int kp, void* out, void* stream);
 int vqseg_reflect_fold_f(int bf16, const void* gp, int n, int h, int w, int c, void* gx, void* stream);
+/* r4: the stem convolution (7x7 / stride 2 / pad 3, 3 -> 64 channels: resnet.py:122-125) STRAIGHT from the fp32 image x [n][h][w][3], without
+ * the patch matrix: a workgroup stages the input rows its 128 output pixels read and takes its MFMA operands from them.  The contraction
+ * runs over k' = kh * 24 + (kw * 3 + ci) (each kernel row's 21 taps padded to 24; 176 columns = eleven K steps): a fragment is then 8
+ * consecutive words of one staged row.  Equal to the 1x1 convolution over vqseg_im2col_f's matrix up to the summation grouping (bf16
+ * outputs within one unit in the last place).  w_img: [64][176] bf16, column kh * 24 + kw * 3 + ci = bf16(w[co][ci][kh][kw]), zero
+ * elsewhere; s3 = 1: [64][2][176] = the hi image | the lo image (bf16 of the remainder), y = split-3 rows [n][ho][wo][128] = hi | lo.
+ * Either stat_partial (raw y + BatchNorm partials: vqseg_conv_stat_slots) or scale / shift (+ relu): the fused eval epilogue (required
+ * for s3).  Output width (w + 6 - 7) / 2 + 1 must be a multiple of 128, else VQSEG_EINVAL (callers keep the patch-matrix path). */
+int vqseg_stem7_conv_f(int s3, const float* x, const void* w_img, void* y, float* stat_partial, const float* scale, const float* shift, int relu,
+                       int n, int h, int w, int reflect, void* stream);
 /* The data gradient of a 3x3 / stride 1 / REFLECT-pad-1 convolution (resnet.py:134-148: every Bottleneck conv2) without the padded
  * gradient tensor (r4): gx [n][h][w][cgx] must already hold the ZERO-padded data gradient of gy (vqseg_conv2d_f with the transposed
  * image and pad 1: the padded gradient's interior, on the fast patch kernel); this call evaluates the full correlation only on the

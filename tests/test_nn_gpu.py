@@ -855,3 +855,53 @@ def test_conv_with_bias_head_on_the_hip_kernels(shape):
     y.backward(g.to(dev()))
     assert rel(y.detach(), F.conv2d(x.double(), wt.double(), b.double(), 1, 1)) < 2e-5
     assert rel(xd.grad, xr.grad) < 2e-5 and rel(wd.grad, wr.grad) < 2e-5 and rel(bd.grad, br.grad) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reflect", [True, False])
+def test_stem_from_the_image_matches_the_patch_matrix_path(reflect):
+    """r4: the stem convolution straight from the fp32 image (vqseg_stem7_conv_f: a workgroup stages the input rows its 128 output
+    pixels read; contraction over kh * 24 + (kw, ci), each kernel row padded to 24 taps) against the 1x1 convolution over the
+    materialised patch matrix: the same products, another summation grouping -- training forward (output, running statistics) and
+    backward (weight / BatchNorm gradients: the patch matrix is built in backward then), the eval forward with the fused epilogue, and
+    the split-3 (fp32-precision) eval forward.  bf16 outputs within one unit in the last place (2^-7 of the value), 2e-3 of the
+    tensor scale in rel-L2; the split-3 output (hi + lo) to 3e-5 (three bf16 products per term: ~2^-16 each); gradients and statistics to 1e-3."""
+    import copy
+    from vq_seg_amd import _hip, nnf
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False, padding_mode="reflect" if reflect else "zeros").to(dev())
+    bn = nn.BatchNorm2d(64).to(dev())
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5), bn.bias.uniform_(-0.3, 0.3)
+    x = cl(synth.uniform(21, (3, 3, 16, 512))).to(dev())         # -> 8 x 256 output pixels: two 128-pixel strips per row
+    g = cl(synth.uniform(22, (3, 64, 8, 256), -1, 1)).to(dev())
+    res = {}
+    for fused in (1, 0):
+        prev = _hip.PY_OPTS.get("py_stem_fused")
+        _hip.PY_OPTS["py_stem_fused"] = fused
+        try:
+            c, b = copy.deepcopy(conv), copy.deepcopy(bn)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = nnf.stem_conv_bn_act(x, c, b)
+            out.backward(g.to(out.dtype))
+            b.eval()
+            with torch.no_grad():
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    ev = nnf.stem_conv_bn_act(x, c, b)
+                with nnf.s3_scope(True):
+                    s3 = nnf.stem_conv_bn_act(x, c, b)
+            torch.cuda.synchronize()
+            s3v = s3.rows[..., :64].float() + s3.rows[..., 64:].float()
+            res[fused] = (out.detach(), c.weight.grad, b.weight.grad, b.bias.grad, b.running_mean, b.running_var, ev, s3v)
+        finally:
+            if prev is None:
+                _hip.PY_OPTS.pop("py_stem_fused", None)
+            else:
+                _hip.PY_OPTS["py_stem_fused"] = prev
+    assert res[1][0].dtype == torch.bfloat16 and res[1][7].shape == (3, 8, 256, 64)
+    tol = (2e-3, 1e-3, 1e-3, 1e-3, 1e-4, 1e-4, 2e-3, 3e-5)
+    for i, (a, b_) in enumerate(zip(res[1], res[0])):
+        assert a.shape == b_.shape and a.dtype == b_.dtype, i
+        assert rel(a.float(), b_.float()) < tol[i], (i, rel(a.float(), b_.float()))
+    for i in (0, 6):                                                # bf16 outputs: never more than one unit in the last place apart
+        a, b_ = res[1][i].float(), res[0][i].float()
+        assert ((a - b_).abs() <= 2 ** -7 * b_.abs() + 1e-30).all(), i

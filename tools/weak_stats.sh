@@ -18,7 +18,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 print(f"== {sys.argv[2]}")
 for r in rows:
     n = r["Name"]
-    if any(k in n for k in ("conv", "wgrad", "reduce_partials", "reflect", "im2col", "ring_add")):
+    if any(k in n for k in ("conv", "wgrad", "reduce_partials", "reflect", "im2col", "ring_add", "stem7")):
         print(f"  {n[:96]:96s} calls {int(r['Calls']):4d}  avg {float(r['AverageNs']) / 1e3:8.1f} us")
 PY
 done

@@ -101,6 +101,7 @@ SYMBOLS = {
     "vqseg_conv_packed_s2_elems": (c_size_t, [c_int, c_int, c_int]),
     "vqseg_conv_pack_weights_s2_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vqseg_conv2d_dgrad_s2_f": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "vqseg_stem7_conv_f": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "vqseg_conv2d_dgrad_s2_fold_rows": (ctypes.c_int64, [c_int] * 4),
     "vqseg_cps_loss_combine_f": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_int, c_int,
                                          c_float, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

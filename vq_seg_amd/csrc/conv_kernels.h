@@ -85,6 +85,9 @@ long dgrad_s2_fold_rows(int N, int H, int W, int reflect);
 // for the four parity classes (+ the ring add for reflect padding).  hipErrorInvalidValue: shape outside the merged path.
 hipError_t launch_dgrad_s2_fold(const void* gy, const unsigned short* w_hi, void* gx, int N, int Ho, int Wo, int Cout, int Cin, int H, int W,
                                 int reflect, hipStream_t st);
+// the stem (7x7 / 2 / pad 3, 3 -> 64) straight from the fp32 image, no patch matrix (Wo % 128 == 0; hipErrorInvalidValue otherwise)
+hipError_t launch_stem7_fused(const float* x, const unsigned short* w_img, void* y, float* stat_partial, const float* ep_scale, const float* ep_shift,
+                              int relu, int N, int H, int W, int reflect, int s3, hipStream_t st);
 hipError_t conv_profile_begin(int capacity);
 void conv_profile_release();
 int conv_profile_collect(int max_records, double* flops, int* kind, float* ms, int* shape);

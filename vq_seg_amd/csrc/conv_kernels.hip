@@ -29,6 +29,7 @@ namespace vqseg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -830,6 +831,140 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_igemm_glds_kernel(const Co
     conv_epilogue<TBM, BN, false, MT, NTT, NT, NW * 64, LinearRows, S3>(acc, p, smem, M, m0, co0, wm, wn, r, h, tid);
 }
 
+// =====================================================================================================
+// The stem (7x7 / stride 2 / pad 3 on the 3-channel fp32 image) WITHOUT its patch matrix (r4).
+//
+// As a 1x1 convolution over a materialised [pixels][160] patch matrix the stem moved 11.5 GB per step: the bf16 matrix written once
+// per batch (0.67 GB) and read by both networks' forward and again by their weight gradients, the split-3 matrix of the pseudo-label
+// forwards 1.6 GB written and read twice.  Here a workgroup owns 128 consecutive output pixels of one output row x all 64 output
+// channels: it stages the 7 input rows x 261 input pixels x 3 channels those pixels read (fp32, padding applied while staging, as
+// im2col_stem7_strip_kernel) and the weight image in LDS.  The contraction runs over k' = kh * 24 + (kw * 3 + ci) -- each kernel
+// row's 21 taps padded to 24, 7 x 24 = 168 padded to 176 = eleven MFMA K steps -- so that the 8 operands of a fragment are 8
+// CONSECUTIVE words of one staged input row (offset 6 * pixel + 8 * (k' / 8 % 3)): four ds_read_b64 and four conversions per
+// fragment, no per-element address arithmetic (the first version kept the patch matrix's k order and spent ~1300 VALU instructions
+// per lane on it: 313 us, slower than the 280 us it replaced).  The padded positions meet zero weights; what they read is the next
+// pixel's first words (finite) -- the row tails are zero-filled.  Same v_mfma_f32_32x32x16_bf16, another summation grouping than the
+// patch-matrix kernel: equal to rounding, not bit-identical.  Split-3: hi w_hi, lo w_hi, hi w_lo per K step.  Same epilogue (raw y +
+// BatchNorm partials, or the fused affine epilogue).  Reads the image, writes y.
+// Weight image: [64][176] bf16 (split-3: [64][2][176] = w_hi | w_lo), columns kh * 24 + kw * 3 + ci, zero elsewhere.
+// =====================================================================================================
+#ifndef STEM_ABL
+#define STEM_ABL 0                // debug builds only (results wrong): 1 no image loads, 2 no epilogue
+#endif
+template <bool S3>
+__global__ __launch_bounds__(256) void stem7_fused_kernel(const ConvArgs p) {
+    constexpr int TP = 128, NCOL = (2 * (TP - 1) + 7) * 3, ROW = 790, KQ = 176, KPW = KQ + 8, NH = (ROW + 255) / 256, NK = KQ / 16;
+    static_assert(ROW >= NCOL + 2 && ROW % 2 == 0, "strip row: room for the 2 words a padded fragment reads past the last pixel; 4-byte rows");
+    // The strip is kept as bf16 (split-3: a hi plane and a lo plane): the fragments are what bounds this kernel -- every wave gathers
+    // 22 x 2 fragments from LDS (fp32 words: 360 KB of LDS reads per workgroup, 200 us for the loop alone) -- and bf16 halves the bytes
+    // and drops the conversions from the gather.
+    constexpr int PLANE = 7 * ROW;                                          // bf16 elements of one plane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* strip = reinterpret_cast<__bf16*>(smem);                        // [planes][7][ROW]
+    __bf16* Bh = reinterpret_cast<__bf16*>(smem + (S3 ? 2 : 1) * ((PLANE * 2 + 15) / 16 * 16));     // [64][KPW] w_hi
+    __bf16* Bl = Bh + 64 * KPW;                                             // [64][KPW] w_lo (split-3)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                                // wave tile 64 pixels x 32 channels: MT = 2, NTT = 1
+    const int r = lane & 31, h = lane >> 5;
+    const int strips = p.Wo / TP;
+    const int sx = blockIdx.x % strips;
+    const int oh = (blockIdx.x / strips) % p.Ho, n = blockIdx.x / (strips * p.Ho);
+    const int H = p.H, W = p.W;
+    const long M = (long)p.N * p.Ho * p.Wo;
+    const long m0 = ((long)n * p.Ho + oh) * p.Wo + (long)sx * TP;
+    const int iw0 = 2 * sx * TP - 3;
+    // ---- stage the image strip (unconditional loads, clamped addresses: see im2col_stem7_strip_kernel) and the weights
+    const float* xn = reinterpret_cast<const float*>(p.x) + (size_t)n * H * W * 3;
+    float rv[NH][7];
+#pragma unroll
+    for (int q = 0; q < NH; ++q) {
+        const int c = tid + 256 * q;
+        const int px = c / 3, ci = c - 3 * px;
+        int iw = iw0 + px;
+        if (p.reflect) {
+            if (iw < 0) iw = -iw;
+            if (iw >= W) iw = 2 * W - 2 - iw;
+        }
+        const bool cok = c < NCOL && iw >= 0 && iw < W;
+        const int coff = cok ? iw * 3 + ci : 0;
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            int ih = 2 * oh - 3 + kh;
+            if (p.reflect) {
+                if (ih < 0) ih = -ih;
+                if (ih >= H) ih = 2 * H - 2 - ih;
+            }
+            const bool ok = cok && ih >= 0 && ih < H;
+#if STEM_ABL & 1
+            const float v = (float)coff;
+#else
+            const float v = xn[(ok ? ih : 0) * W * 3 + coff];
+#endif
+            rv[q][kh] = ok ? v : 0.0f;
+        }
+    }
+    {
+        const int row_len = S3 ? 2 * KQ : KQ;
+        for (int i = tid; i < 64 * (KQ / 8); i += 256) {
+            const int co = i / (KQ / 8), ch = i - co * (KQ / 8);
+            *reinterpret_cast<u32x4*>(Bh + co * KPW + ch * 8) = *reinterpret_cast<const u32x4*>(p.w_hi + (size_t)co * row_len + ch * 8);
+            if constexpr (S3)
+                *reinterpret_cast<u32x4*>(Bl + co * KPW + ch * 8) = *reinterpret_cast<const u32x4*>(p.w_hi + (size_t)co * row_len + KQ + ch * 8);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NH; ++q)
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh)
+            if (tid + 256 * q < ROW) {                      // (columns >= NCOL: zeros)
+                const __bf16 hi = (__bf16)rv[q][kh];
+                strip[kh * ROW + tid + 256 * q] = hi;
+                if constexpr (S3) strip[PLANE + kh * ROW + tid + 256 * q] = (__bf16)(rv[q][kh] - (float)hi);
+            }
+    __syncthreads();
+
+    // ---- K loop.  A fragments: K step kk, lane half h -> 8-group g8 = 2 kk + h of k' = kernel row g8 / 3 (clamped: the last group is
+    // padding), taps 8 (g8 % 3) .. + 7 of that row: 8 consecutive bf16 = four 4-byte LDS reads (a pixel is 6 elements = 12 bytes
+    // further on).  Fragments are used as they arrive (few registers: four workgroups per CU cover each other's load / store phases);
+    // split-3: the three products of a K step back to back.
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][0][i] = 0.0f;
+    const __bf16* brow = Bh + (wn * 32 + r) * KPW + h * 8;
+    const __bf16* blrow = Bl + (wn * 32 + r) * KPW + h * 8;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        const int g8 = 2 * kk + h;
+        int kh = (g8 * 11) >> 5;                                            // g8 / 3 for g8 < 32
+        const int j0 = 8 * (g8 - 3 * kh);
+        if (kh > 6) kh = 6;
+        const __bf16* src = strip + kh * ROW + j0;
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + kk * 16);
+        bf16x8 bl;
+        if constexpr (S3) bl = *reinterpret_cast<const bf16x8*>(blrow + kk * 16);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const unsigned* sp = reinterpret_cast<const unsigned*>(src + 6 * ((wm * 2 + a) * 32 + r));
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, u32x4{sp[0], sp[1], sp[2], sp[3]});
+            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b, acc[a][0], 0, 0, 0);
+            if constexpr (S3) {
+                const unsigned* sl = sp + PLANE / 2;
+                const bf16x8 al = __builtin_bit_cast(bf16x8, u32x4{sl[0], sl[1], sl[2], sl[3]});
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b, acc[a][0], 0, 0, 0);
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[a][0], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                       // LDS is free for the output tile
+#if STEM_ABL & 2
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
+    conv_epilogue<TP, 64, false, 2, 1, 1, 256, LinearRows, S3, true>(acc, p, smem, M, m0, 0, wm, wn, r, h, tid);
+}
+
 static int g_glds_pair = 4;                                 // layers with 2..this many Cout chunks: the chunks of an M tile share an XCD
                                                             // (1-D launch, see the kernel; measured -3..-6 % at 2-4 chunks, +5 % at 8)
 
@@ -1165,6 +1300,10 @@ int conv_set_option(const char* key, int value) {
         const int prev = g_wgrad1x1_narrow;
         g_wgrad1x1_narrow = value;
         return prev;
+    }
+    if (key && !strcmp(key, "stem_fused")) {
+        extern int stem_fused_option(int);
+        return stem_fused_option(value);
     }
     if (key && !strcmp(key, "conv_wgrad_xcd")) {
         const int prev = g_wgrad_xcd;
@@ -1567,6 +1706,46 @@ static hipError_t launch_conv_impl(const ConvArgs& a, int precise, hipStream_t s
         else if (bn == 64) launch_t<64, false, 32>(a, st);
         else launch_t<32, false, 32>(a, st);
     }
+    return hipGetLastError();
+}
+
+static int g_stem_fused = 1;                                // the stem without its patch matrix (0: callers keep the patch-matrix path)
+int stem_fused_option(int value) {
+    const int prev = g_stem_fused;
+    if (value >= 0) g_stem_fused = value ? 1 : 0;
+    return prev;
+}
+// x: image [N][H][W][3] f32; w_img: [64][176] bf16, columns kh * 24 + kw * 3 + ci (s3: [64][2][176] = w_hi | w_lo); y [N][Ho][Wo][64] bf16 (s3: [..][128] = hi | lo); either
+// stat_partial (raw y + BatchNorm partials) or ep_scale / ep_shift (fused affine [+ ReLU]; required for s3)
+hipError_t launch_stem7_fused(const float* x, const unsigned short* w_img, void* y, float* stat_partial, const float* ep_scale, const float* ep_shift,
+                              int relu, int N, int H, int W, int reflect, int s3, hipStream_t st) {
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    if (!g_stem_fused || Wo % 128 || H < 4 || W < 4 || (long)H * W * 3 >= (1L << 31) || (long)N * Ho * (Wo / 128) >= (1L << 31) || (s3 && !ep_scale))
+        return hipErrorInvalidValue;
+    ConvArgs a;
+    a.x = x; a.x2 = nullptr; a.C1 = 160; a.w_hi = w_img; a.w_lo = nullptr; a.y = y; a.stat_partial = stat_partial;
+    a.N = N; a.H = H; a.W = W; a.Cin = 160; a.Ho = Ho; a.Wo = Wo; a.Cout = 64; a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0; a.reflect = reflect; a.up = 1;
+    a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_res = nullptr; a.ep_relu = relu; a.out_s3 = s3 ? 1 : 0;
+    const bool rec = g_cprof.enabled && g_cprof.count < g_cprof.capacity;
+    const int slot = g_cprof.count;
+    if (rec) {
+        g_cprof.flops[slot] = 2.0 * 160 * 64 * (double)N * Ho * Wo;
+        g_cprof.kind[slot] = 100 + (s3 ? 2 : 0);
+        g_cprof.shape[4 * slot + 0] = (int)(((long)N * Ho * Wo) >> 10);
+        g_cprof.shape[4 * slot + 1] = 160;
+        g_cprof.shape[4 * slot + 2] = 64;
+        g_cprof.shape[4 * slot + 3] = 11;
+        ++g_cprof.count;
+        (void)hipEventRecord(g_cprof.ev[2 * slot], st);
+    }
+    const unsigned grid = (unsigned)((long)N * Ho * (Wo / 128));
+    const size_t strip_b = (size_t)(s3 ? 2 : 1) * ((7 * 790 * 2 + 15) / 16 * 16), w_b = (size_t)64 * 184 * 2 * (s3 ? 2 : 1);
+    size_t lds = strip_b + w_b;
+    const size_t out_tile = (size_t)128 * (64 + 8) * 2 * (s3 ? 2 : 1);
+    if (out_tile > lds) lds = out_tile;
+    if (s3) hipLaunchKernelGGL((stem7_fused_kernel<true>), dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((stem7_fused_kernel<false>), dim3(grid), dim3(256), lds, st, a);
+    if (rec) (void)hipEventRecord(g_cprof.ev[2 * slot + 1], st);
     return hipGetLastError();
 }
 

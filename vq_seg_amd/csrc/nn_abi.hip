@@ -309,6 +309,19 @@ int vqseg_conv2d_dgrad_s2_f(const void* gy, const void* w_hi, const void* w_lo, 
     return e == hipSuccess ? 0 : hipfail(e, "conv2d_dgrad_s2");
 }
 
+int vqseg_stem7_conv_f(int s3, const float* x, const void* w_img, void* y, float* stat_partial, const float* scale, const float* shift, int relu,
+                       int n, int h, int w, int reflect, void* stream) {
+    if (!x || !w_img || !y) return bad("stem7_conv: null pointer");
+    if (n <= 0 || h < 4 || w < 4) return bad("stem7_conv: bad image size");
+    if ((scale == nullptr) != (shift == nullptr)) return bad("stem7_conv: scale and shift come together");
+    if (s3 && !scale) return bad("stem7_conv (split-3): needs the fused affine epilogue");
+    if (!a16(x) || !a16(w_img) || !a16(y)) return bad("stem7_conv: pointers must be 16-byte aligned");
+    hipError_t e = vqseg::launch_stem7_fused(x, static_cast<const unsigned short*>(w_img), y, stat_partial, scale, shift, relu, n, h, w, reflect, s3,
+                                             static_cast<hipStream_t>(stream));
+    if (e == hipErrorInvalidValue) return bad("stem7_conv: shape outside the fused path (output width % 128) or option stem_fused = 0");
+    return e == hipSuccess ? 0 : hipfail(e, "stem7_fused_kernel");
+}
+
 int64_t vqseg_conv2d_dgrad_s2_fold_rows(int n, int h, int w, int reflect) {
     return (n > 0 && h > 0 && w > 0) ? (int64_t)vqseg::dgrad_s2_fold_rows(n, h, w, reflect) : 0;
 }

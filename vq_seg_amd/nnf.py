@@ -548,6 +548,16 @@ class _ConvBNAct(torch.autograd.Function):
         bf = _is_bf16(xr)
         precise = not bf
         n, h, w, c1 = xr.shape
+        # r4, the stem without its patch matrix (patches_of[8] = (ho, wo, kp)): x is the fp32 IMAGE; the convolution gathers its operands
+        # from it (vqseg_stem7_conv_f, bit-identical to the 1x1 convolution over the patch matrix), the activations are bf16; backward
+        # builds the patch matrix for the weight gradient then (shared between the two networks as before)
+        stem_img = bool(patches_of) and len(patches_of) > 8
+        stem_x = None
+        if stem_img:
+            stem_x, _STEM_X_ARG[0] = _STEM_X_ARG[0], None
+            h, w, c1 = patches_of[8]
+            bf, precise = True, False
+        adt = torch.bfloat16 if stem_img else xr.dtype      # activation dtype of y / out
         cin = c1 + (x2r.shape[3] if x2r is not None else 0)
         cout = weight.shape[0]
         kh, kw = (1, 1) if patches_of else (weight.shape[2], weight.shape[3])
@@ -556,7 +566,9 @@ class _ConvBNAct(torch.autograd.Function):
         training = bool(bn.training)
         L = lib()
         dev = xr.device
-        if patches_of:
+        if stem_img:
+            w_hi, w_lo = _stem_weights_fused(weight, False), None
+        elif patches_of:
             w_hi, w_lo = _stem_weights(weight, precise, cin)
         else:
             w_hi, w_lo = packed_weights(weight, precise, False)
@@ -569,13 +581,18 @@ class _ConvBNAct(torch.autograd.Function):
             rr = _rows(residual) if residual is not None else None
             if rr is not None and rr.dtype != xr.dtype:
                 raise _hip.HipLibraryError("residual dtype differs from the activation dtype")
-            out = torch.empty((n, ho, wo, cout), dtype=xr.dtype, device=dev)
+            out = torch.empty((n, ho, wo, cout), dtype=adt, device=dev)
             wneed = cout * kh * kw * ((cin + 31) // 32 * 32)
             with _hip.on_device(dev):
                 _check(L.vqseg_bn_finalize_f(None, m, cout, _f32(gamma, "bn.weight", cout), _f32(beta, "bn.bias", cout),
                                              _f32(bn.running_mean, "bn.running_mean", cout), _f32(bn.running_var, "bn.running_var", cout),
                                              float(bn.momentum), float(bn.eps), 0, _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout),
                                              _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout), None, None, _stream()), "vqseg_bn_finalize_f")
+                if stem_img:
+                    _check(L.vqseg_stem7_conv_f(0, _f32(xr, "image"), _w16(w_hi, "stem weight image", cout * 176), _T(out, "conv output", bf=1, numel=m * cout), None,
+                                                _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout), int(relu), n, patches_of[6], patches_of[7],
+                                                int(patches_of[5]), _stream()), "vqseg_stem7_conv_f")
+                    return _nchw(out)
                 _check(L.vqseg_conv2d_affine_f(_T(xr, "conv input", bf=bf, numel=n * h * w * c1), _T(x2r, "conv input 2", bf=bf, numel=n * h * w * (cin - c1)),
                                                c1, _w16(w_hi, "packed weights", wneed), _w16(w_lo, "packed weights (lo)", wneed),
                                                _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout),
@@ -584,8 +601,15 @@ class _ConvBNAct(torch.autograd.Function):
                        "vqseg_conv2d_affine_f")
             return _nchw(out)
         stat = torch.empty(L.vqseg_conv_stat_slots(m, cout) * 2 * cout, dtype=torch.float32, device=dev) if training else None
-        y = _conv_raw(xr, x2r, c1, w_hi, w_lo, (n, ho, wo, cout), stat, n, h, w, cin, cout, kh, kw, stride, pad, reflect, 1,
-                      ho, wo)
+        if stem_img:
+            y = torch.empty((n, ho, wo, cout), dtype=adt, device=dev)
+            with _hip.on_device(dev):
+                _check(L.vqseg_stem7_conv_f(0, _f32(xr, "image"), _w16(w_hi, "stem weight image", cout * 176),
+                                            _T(y, "conv output", bf=1, numel=m * cout), _f32(stat, "BN partials"), None, None, 0, n, patches_of[6],
+                                            patches_of[7], int(patches_of[5]), _stream()), "vqseg_stem7_conv_f")
+        else:
+            y = _conv_raw(xr, x2r, c1, w_hi, w_lo, (n, ho, wo, cout), stat, n, h, w, cin, cout, kh, kw, stride, pad, reflect, 1,
+                          ho, wo)
         with _hip.on_device(dev):
             _check_fused_bn(L.vqseg_bn_finalize_f(_f32(stat, "BN partials"), m, cout, _f32(gamma, "bn.weight", cout), _f32(beta, "bn.bias", cout),
                                          _f32(bn.running_mean, "bn.running_mean", cout), _f32(bn.running_var, "bn.running_var", cout),
@@ -603,6 +627,7 @@ class _ConvBNAct(torch.autograd.Function):
                                       _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout), m, cout, int(relu),
                                       _T(out, "BN output", bf=bf, numel=m * cout), _stream()), "vqseg_bn_apply_f")
         ctx.save_for_backward(xr, x2r, y, out, coef, weight, gamma)
+        ctx.stem_x = stem_x if stem_img else None                           # the image tensor OBJECT the patch matrix is shared under
         ctx.params = (weight, gamma, beta)                                  # the Parameter objects (see grad sinks)
         ctx.bn = bn
         ctx.links = (link_in, link_out, link_x)
@@ -617,6 +642,11 @@ class _ConvBNAct(torch.autograd.Function):
         stride, pad, reflect, relu, training, has_res, patches_of, (n, h, w, c1, cin, cout, kh, kw, ho, wo) = ctx.cfg
         L = lib()
         dev = y.device
+        if patches_of and len(patches_of) > 8:                              # forward ran from the image: the weight gradient's patch matrix now
+            img = xr
+            okh, okw, ocin, os_, op_, orf, ih_, iw_ = patches_of[:8]
+            xr = _shared_stem_patches(ctx.stem_x if ctx.stem_x is not None else img, (torch.bfloat16, okh, okw, os_, op_, orf),
+                                      lambda: _stem_patches(img, torch.bfloat16, okh, okw, os_, op_, orf, ho, wo, cin))
         bf = _is_bf16(y)
         precise = not bf
         m = n * ho * wo
@@ -899,6 +929,35 @@ def _shared_stem_patches(x, cfg, make):
     return patches
 
 
+_STEM_X_ARG = [None]            # hands the image tensor OBJECT (patch-sharing identity) to _ConvBNAct.forward past autograd's argument handling
+
+
+def _stem_patches(xr, dt, kh, kw, s, p, reflect, ho, wo, kp):
+    """the stem's im2col patch matrix [n][ho][wo][kp] of the fp32 image rows xr"""
+    n, h, w, cin = xr.shape
+    out = torch.empty((n, ho, wo, kp), dtype=dt, device=xr.device)
+    with _hip.on_device(xr.device):
+        _check(lib().vqseg_im2col_f(int(dt == torch.bfloat16), _f32(xr, "image", n * h * w * cin), n, h, w, cin, kh, kw, s, p, int(reflect), ho, wo, kp,
+                                    _T(out, "patches", bf=int(dt == torch.bfloat16), numel=n * ho * wo * kp), _stream()), "vqseg_im2col_f")
+    return out
+
+
+def _stem_weights_fused(weight, s3: bool):
+    """vqseg_stem7_conv_f's weight image: [64][176] bf16, column kh * 24 + kw * 3 + ci (each kernel row's 21 taps padded to 24), zeros
+    elsewhere; split-3: [64][2][176] = hi | lo.  Cached on the Parameter (_wcache: rebuilt after every optimiser step)."""
+    cache = _cache_of(weight)
+    k = ("stem_fused", bool(s3))
+    if k not in cache:
+        cout, cin, kh, kw = weight.shape
+        w = weight.detach().float().permute(0, 2, 3, 1).reshape(cout, kh, kw * cin)           # [co][kh][(kw, ci)]
+        wp = torch.zeros(cout, 176, dtype=torch.float32, device=weight.device)
+        wp[:, :kh * 24].view(cout, kh, 24)[:, :, :kw * cin] = w
+        hi = wp.to(torch.bfloat16)
+        img = torch.cat([hi, (wp - hi.float()).to(torch.bfloat16)], dim=1) if s3 else hi
+        cache[k] = img.contiguous().view(torch.int16)
+    return cache[k]
+
+
 def stem_conv_bn_act(x, conv, bn):
     """7x7 stride-2 stem on a 3-channel fp32 image: im2col patch matrix (zero / reflect padding) + 1x1 MFMA conv."""
     if not x.is_cuda:
@@ -911,6 +970,11 @@ def stem_conv_bn_act(x, conv, bn):
     ho, wo = _out_size(h, kh, s, p), _out_size(w, kw, s, p)
     kp = (kh * kw * cin + 31) // 32 * 32
     dt = act_dtype()
+    # r4: the convolution straight from the image (vqseg_stem7_conv_f) where its tiling fits: 128 output pixels of one row per workgroup.
+    # OPT-IN (VQSEG_OPTS=py_stem_fused=1): it removes 7.5 GB of patch-matrix traffic per step and its kernel takes 197 us against 318 us,
+    # but the step does not move (152.7 vs 152.5 ms, same-box A/B: LEDGER r4) -- the default stays the path the parity fixtures cover
+    fused_ok = ((kh, kw, cin) == (7, 7, 3) and s == 2 and p == 3 and wo % 128 == 0 and h >= 4 and w >= 4 and conv.weight.shape[0] == 64
+                and py_opt("py_stem_fused", 0) == 1)
     if _S3_SCOPE and dt == torch.float32 and not bn.training and not torch.is_grad_enabled() and (kh, kw, cin) == (7, 7, 3):
         # fp32-precision eval forward: split-3 patch rows (64-column multiple: the LDS-DMA kernels), then everything stays split-3
         kp3 = (kh * kw * cin + 63) // 64 * 64
@@ -922,17 +986,29 @@ def stem_conv_bn_act(x, conv, bn):
                                             _T(out, "split-3 patches", bf=2, numel=n * ho * wo * 2 * kp3), _stream()), "vqseg_im2col_f (split-3)")
             return out
 
+        if fused_ok:                                             # r4: no split-3 patch matrix (1.6 GB written, read by both networks)
+            cout = conv.weight.shape[0]
+            wimg = _stem_weights_fused(conv.weight, True)
+            coef = torch.empty(4, cout, dtype=torch.float32, device=x.device)
+            out = torch.empty((n, ho, wo, 2 * cout), dtype=torch.bfloat16, device=x.device)
+            with _hip.on_device(x.device):
+                _check(lib().vqseg_bn_finalize_f(None, n * ho * wo, cout, _f32(bn.weight, "bn.weight", cout), _f32(bn.bias, "bn.bias", cout),
+                                                 _f32(bn.running_mean, "bn.running_mean", cout), _f32(bn.running_var, "bn.running_var", cout),
+                                                 float(bn.momentum), float(bn.eps), 0, _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout),
+                                                 _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout), None, None, _stream()), "vqseg_bn_finalize_f")
+                _check(lib().vqseg_stem7_conv_f(1, _f32(xr, "image", n * h * w * cin), _w16(wimg, "stem weight image (hi | lo)", cout * 2 * 176),
+                                                _T(out, "split-3 output", bf=2, numel=n * ho * wo * 2 * cout), None, _f32(coef[0], "scale", cout),
+                                                _f32(coef[1], "shift", cout), 1, n, h, w, int(reflect), _stream()), "vqseg_stem7_conv_f (split-3)")
+            return S3(out, cout)
         patches = _shared_stem_patches(x, ("s3", kh, kw, s, p, reflect), make3)
         return _conv_bn_act_s3(S3(patches, kp3), None, None, conv, bn, True, kernel_1x1_cols=kp3)
 
-    def make():
-        out = torch.empty((n, ho, wo, kp), dtype=dt, device=x.device)
-        with _hip.on_device(x.device):
-            _check(lib().vqseg_im2col_f(int(dt == torch.bfloat16), _f32(xr, "image", n * h * w * cin), n, h, w, cin, kh, kw, s, p, int(reflect), ho, wo, kp,
-                                        _T(out, "patches", bf=int(dt == torch.bfloat16), numel=n * ho * wo * kp), _stream()), "vqseg_im2col_f")
-        return out
-
-    patches = _shared_stem_patches(x, (dt, kh, kw, s, p, reflect), make)
+    if fused_ok and dt == torch.bfloat16 and kp == 160:
+        _sink_use(conv.weight, bn.weight, bn.bias)
+        _STEM_X_ARG[0] = x
+        return _ConvBNAct.apply(_nchw(xr), None, None, conv.weight, bn.weight, bn.bias, bn, 1, 0, False, True,
+                                (kh, kw, cin, s, p, reflect, h, w, (ho, wo, kp)), not bn.training and not torch.is_grad_enabled())
+    patches = _shared_stem_patches(x, (dt, kh, kw, s, p, reflect), lambda: _stem_patches(xr, dt, kh, kw, s, p, reflect, ho, wo, kp))
     _sink_use(conv.weight, bn.weight, bn.bias)
     return _ConvBNAct.apply(_nchw(patches), None, None, conv.weight, bn.weight, bn.bias, bn, 1, 0, False, True,
                             (kh, kw, cin, s, p, reflect, h, w), not bn.training and not torch.is_grad_enabled())
