@@ -905,3 +905,42 @@ def test_stem_from_the_image_matches_the_patch_matrix_path(reflect):
     for i in (0, 6):                                                # bf16 outputs: never more than one unit in the last place apart
         a, b_ = res[1][i].float(), res[0][i].float()
         assert ((a - b_).abs() <= 2 ** -7 * b_.abs() + 1e-30).all(), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(16, 64, 256, 64, 64, True), (16, 64, 512, 64, 64, False)])     # >= 256 (pixel tile, 256-channel chunk) workgroups: the dispatch takes the wide tile
+def test_conv3x3_patch_kernel_256_channel_tile(case):
+    """The 256-channel tile of the 3x3 patch kernel (default from r4 where it still fills the chip: the input rows are read once per 256
+    instead of per 128 output channels) against the 128-channel tile (option off): same outputs AND BatchNorm partials, bit for bit
+    (the same K order per output element); fp64 reference 2^-7 (bf16 output)."""
+    from vq_seg_amd import _hip
+    n, cin, cout, h, w, reflect = case
+    L = _hip.lib()
+    seed = sum(case[:5]) + 9
+    x = synth.uniform(seed, (n, h, w, cin), -1, 1).bfloat16()
+    wt = (synth.uniform(seed + 1, (cout, cin, 3, 3), -1, 1) * (2.0 / (cin * 9)) ** 0.5).bfloat16().float()
+    xp = F.pad(x.double().permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect" if reflect else "constant")
+    ref = F.conv2d(xp, wt.double()).permute(0, 2, 3, 1)
+    wd = wt.to(dev())
+    ne = L.vqseg_conv_packed_elems(cout, cin, 3, 3, 0)
+    hi = torch.empty(ne, dtype=torch.int16, device=dev())
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.vqseg_conv_pack_weights_f32(wd.data_ptr(), cout, cin, 3, 3, 0, hi.data_ptr(), None, st) == 0
+    xa = x.to(dev())
+    slots = L.vqseg_conv_stat_slots(n * h * w, cout)
+    res = {}
+    for wide in (1, 0):
+        prev = _hip.set_option("conv3x3_patch_wide_tile", wide)
+        try:
+            y = torch.full((n, h, w, cout), float("nan"), dtype=torch.bfloat16, device=dev())
+            stat = torch.full((slots, 2, cout), float("nan"), dtype=torch.float32, device=dev())
+            rc = L.vqseg_conv2d_f(xa.data_ptr(), None, cin, hi.data_ptr(), None, y.data_ptr(), stat.data_ptr(), n, h, w, cin, cout, 3, 3, 1, 1,
+                                  int(reflect), 1, h, w, 0, st)
+            assert rc == 0, L.vqseg_last_error()
+            torch.cuda.synchronize()
+            res[wide] = (y.cpu(), stat.cpu())
+        finally:
+            _hip.set_option("conv3x3_patch_wide_tile", prev)
+    assert rel(res[1][0].float(), ref) < 2 ** -7
+    assert torch.equal(res[1][0].view(torch.int16), res[0][0].view(torch.int16))
+    assert torch.equal(res[1][1], res[0][1])

@@ -1275,7 +1275,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
 static int g_patch_min_wgs = 256;
 static int g_patch_pair = 0;                                // 1: Cout chunks of a pixel tile share an XCD (1-D launch, see the kernel)
 static int g_patch_chunk_stage = 1;                         // 32-channel chunks: chunk stages instead of the per-tap weight ring
-static int g_patch_wide = 0;                                // 1: take the 256-channel tile where it fills the chip (measured 3-5 % slower than the unrolled 128 tile)
+static int g_patch_wide = 1;                                // 1 (r4): the 256-channel tile where it fills the chip -- 3-5 % slower than the unrolled 128 tile ALONE, but it reads the input rows once
+                                                            // per 256 instead of per 128 output channels: in the two-stream step (fabric-bound as a whole) -0.9 ms; 0: r3
 #ifndef SHORTK_MINW
 #define SHORTK_MINW 4               // waves per SIMD the short-K tiles are compiled for (4: 128 registers, the epilogue spills ~18)
 #endif
@@ -1680,7 +1681,7 @@ static hipError_t launch_conv_impl(const ConvArgs& a, int precise, hipStream_t s
         // 256-wide channel tile (wave tile 128 px x 64 co: 25 % fewer LDS fragment reads per MFMA) when it still fills the chip
         if (a.Cout == 64) launch_patch_t<64, 3, true>(a, st);
         else if (a.Cout == 32) launch_patch_t<32, 3, true>(a, st);
-        else if (a.Cout % 256 == 0 && g_patch_wide && tiles * (a.Cout / 256) >= g_patch_min_wgs)
+        else if (a.Cout % 256 == 0 && g_patch_wide && !a.out_s3 && tiles * (a.Cout / 256) >= g_patch_min_wgs)   // (split-3: its output tile does not fit LDS)
             launch_patch_t<256, 2, false>(a, st);
         else if (g_patch_unroll == 2)
             launch_patch_t<128, 4, true>(a, st);
