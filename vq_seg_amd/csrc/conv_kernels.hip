@@ -965,8 +965,8 @@ __global__ __launch_bounds__(256) void stem7_fused_kernel(const ConvArgs p) {
     conv_epilogue<TP, 64, false, 2, 1, 1, 256, LinearRows, S3, true>(acc, p, smem, M, m0, 0, wm, wn, r, h, tid);
 }
 
-static int g_glds_pair = 4;                                 // layers with 2..this many Cout chunks: the chunks of an M tile share an XCD
-                                                            // (1-D launch, see the kernel; measured -3..-6 % at 2-4 chunks, +5 % at 8)
+static int g_glds_pair = 8;                                 // layers with 2..this many Cout chunks: the chunks of an M tile share an XCD
+                                                            // (1-D launch, see the kernel; alone: -3..-6 % at 2-4 chunks, +5 % at 8; in the two-stream step 8 wins: r4)
 
 template <int TBM, int BN, int NW, int NBUF, int MINW = 1, bool LIN = false>
 static void launch_glds_lin(const ConvArgs& a, hipStream_t st);
@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
     conv_epilogue<TBM, BN, false, MT, NT, NT, NW * 64, TileRows, S3>(acc, p, smem, M, (long)tile_id * TBM, co0, wm, wn, r, h, tid, rows);
 }
 
-static int g_patch_min_wgs = 256;
+static int g_patch_min_wgs = 128;                          // (r4: 256 -> 128: in the two-stream step the other network's kernels fill what a 128-workgroup launch leaves idle)
 static int g_patch_pair = 0;                                // 1: Cout chunks of a pixel tile share an XCD (1-D launch, see the kernel)
 static int g_patch_chunk_stage = 1;                         // 32-channel chunks: chunk stages instead of the per-tap weight ring
 static int g_patch_wide = 1;                                // 1 (r4): the 256-channel tile where it fills the chip -- 3-5 % slower than the unrolled 128 tile ALONE, but it reads the input rows once
