@@ -1287,6 +1287,7 @@ static int g_patch_tile512_min_wgs = 512;
 static int g_patch_tile512_launches = 0;                    // launches that took a 512-pixel tile (tests read it to see the dispatch)
 static int g_patch_unroll = 1;                              // 128-channel tile: tap loop unrolled
 static int g_wgrad1x1_narrow = 1;                           // 64-output-channel 1x1 weight gradients (stem patch matrix, 64 -> 64) on the LDS-DMA kernel
+static int g_wgrad_round_pct = 100;                         // LDS-DMA weight gradients: workgroups aimed at, in percent of one resident round (fewer slabs = less partial traffic)
 static int g_wgrad_xcd = 1;                                 // LDS-DMA weight gradients: a slab's (ci, co) tiles on one XCD (WgradArgs::xcd_slabs); 0: 3-D grid
 static int g_wgrad3x3_fill = 1;                             // nine-tap weight gradients: slabs sized to one full round of resident workgroups (0: r3's split)
 static int g_wgrad3x3_s2 = 1;                               // stride-2 3x3 weight gradients on the nine-tap kernel (0: the per-tap kernel, r3)
@@ -1305,6 +1306,11 @@ int conv_set_option(const char* key, int value) {
     if (key && !strcmp(key, "stem_fused")) {
         extern int stem_fused_option(int);
         return stem_fused_option(value);
+    }
+    if (key && !strcmp(key, "conv_wgrad_round_pct")) {
+        const int prev = g_wgrad_round_pct;
+        if (value >= 10 && value <= 400) g_wgrad_round_pct = value;
+        return prev;
     }
     if (key && !strcmp(key, "conv_wgrad_xcd")) {
         const int prev = g_wgrad_xcd;
@@ -2800,7 +2806,7 @@ static Wg1Plan wgrad1x1_plan(const WgradArgs& a, int precise, bool shape_only) {
     const long tiles = (long)(a.Cin / (32 * cit)) * (a.Cout / (32 * cot));
     const long n_stage = ((long)a.N * a.Ho * a.Wo + 63) / 64;
     if (n_stage > (1L << 30)) return pl;
-    long s = ((cit == 2 && cot == 2 ? 768 : 256) + tiles - 1) / tiles;   // one resident round of workgroups (4-wave ones: three per CU)
+    long s = ((cit == 2 && cot == 2 ? 768 : 256) * g_wgrad_round_pct / 100 + tiles - 1) / tiles;   // one resident round of workgroups (4-wave ones: three per CU)
     const long max_s = (n_stage + 3) / 4;                   // at least 4 stages (256 pixels) per slab
     if (s > max_s) s = max_s;
     if (s > 256) s = 256;
@@ -2866,7 +2872,7 @@ static Wg3Plan wgrad3x3_plan(const WgradArgs& a, int precise, bool shape_only, i
         long per_cu = (160 * 1024) / (3 * stage);
         if (per_cu > 32 / nw) per_cu = 32 / nw;
         if (per_cu < 1) per_cu = 1;
-        target = 256 * per_cu;
+        target = 256 * per_cu * g_wgrad_round_pct / 100;
         s = target / tiles;
         cap = 1024;
         const long tile_bytes = (long)cot * 32 * cit * 32 * 9 * 4;
