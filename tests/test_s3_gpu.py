@@ -59,16 +59,16 @@ def test_conv_bn_act_split3_matches_cpu_fp32(cin, c2, cout, k, stride, reflect, 
     conv, bn = conv.to(dev()), bn.to(dev())
     cl = lambda t: t.to(dev()).contiguous(memory_format=torch.channels_last)
     L = _hip.lib()
-    L.vqseg_set_option(b"conv3x3_patch_min_workgroups", 1)                                # small test shapes reach the patch kernels too,
-    L.vqseg_set_option(b"conv3x3_patch_tile512_min_workgroups", 1)                        # ... and their 512-pixel tiles (32 / 64 outputs)
+    prev_min = L.vqseg_set_option(b"conv3x3_patch_min_workgroups", 1)                     # small test shapes reach the patch kernels too,
+    prev_512 = L.vqseg_set_option(b"conv3x3_patch_tile512_min_workgroups", 1)             # ... and their 512-pixel tiles (32 / 64 outputs)
     L.vqseg_set_option(b"conv3x3_patch_tile512_launches", 0)
     try:
         with torch.no_grad():
             got = nnf.conv_bn_act(nnf.to_s3(cl(x)), conv, bn, relu=True, x2=nnf.to_s3(cl(x2)) if c2 else None,
                                   residual=nnf.to_s3(cl(r)) if res else None)
     finally:
-        L.vqseg_set_option(b"conv3x3_patch_min_workgroups", 256)
-        L.vqseg_set_option(b"conv3x3_patch_tile512_min_workgroups", 512)
+        L.vqseg_set_option(b"conv3x3_patch_min_workgroups", prev_min)
+        L.vqseg_set_option(b"conv3x3_patch_tile512_min_workgroups", prev_512)
     tall = L.vqseg_set_option(b"conv3x3_patch_tile512_launches", 0)
     assert (tall >= 1) == (k == 3 and stride == 1 and cout == 32 and hw % 32 == 0), "512-pixel split-3 tile dispatch"
     assert isinstance(got, nnf.S3) and got.shape == want.shape
@@ -176,3 +176,41 @@ def test_split3_exact_2x_resize_is_bit_identical_to_the_generic_kernel():
         finally:
             L.vqseg_set_option(b"bilinear_up2", prev)
         assert torch.equal(fast, generic)
+
+
+@pytest.mark.parametrize("res", [False, True])
+def test_split3_conv_on_the_256_channel_tile_is_bit_identical_to_the_128_channel_tile(res):
+    """r4: the split-3 3x3 convolution on the patch kernel's 256-channel tile (its [hi | lo] output leaves LDS in two column halves:
+    both staging tiles of a 256 x 256 tile would need 270 KB) against the 128-channel tile: the same bits, with and without a
+    residual; and against nn.Conv2d + eval BatchNorm2d (+ residual) + ReLU on the CPU in fp32 (2e-5 of scale)."""
+    from vq_seg_amd import nnf, _hip
+    torch.manual_seed(11)
+    n, cin, cout, hw = 2, 64, 512, 32
+    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=False)
+    bn = nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5), bn.bias.uniform_(-0.5, 0.5), bn.running_mean.uniform_(-0.2, 0.2), bn.running_var.uniform_(0.5, 1.5)
+    bn.eval()
+    x = synth.relu_features(3, (n, cin, hw, hw))
+    r = synth.uniform(5, (n, cout, hw, hw), -1, 1) if res else None
+    with torch.no_grad():
+        want = bn(conv(x))
+        want = F.relu(want + r) if res else F.relu(want)
+    conv, bn = conv.to(dev()), bn.to(dev())
+    cl = lambda t: t.to(dev()).contiguous(memory_format=torch.channels_last)
+    L = _hip.lib()
+    prev_min = L.vqseg_set_option(b"conv3x3_patch_min_workgroups", 1)
+    got = {}
+    try:
+        for wide in (1, 0):
+            prev = L.vqseg_set_option(b"conv3x3_patch_wide_tile_s3", wide)
+            try:
+                with torch.no_grad():
+                    got[wide] = nnf.conv_bn_act(nnf.to_s3(cl(x)), conv, bn, relu=True, residual=nnf.to_s3(cl(r)) if res else None)
+            finally:
+                L.vqseg_set_option(b"conv3x3_patch_wide_tile_s3", prev)
+    finally:
+        L.vqseg_set_option(b"conv3x3_patch_min_workgroups", prev_min)
+    torch.cuda.synchronize()
+    assert torch.equal(got[1].rows.view(torch.int16), got[0].rows.view(torch.int16))
+    assert rel(got[1].float(), want) < 2e-5

@@ -132,56 +132,64 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
         // lo = bf16(v - hi): 2 * Cout channels per pixel row (the consumer's K loop reads hi twice: a_source).  Staged through LDS as two bf16 tiles so that the stores (and the
         // residual loads) are whole 16-byte row segments.  Host side guarantees Cout % 8 == 0 and a fused epilogue.
         static_assert(!PRECISE, "split-3 output belongs to the bf16 kernels");
-        constexpr int OS = BN + 8;
+        // (r4: a tile whose two staging tiles do not fit LDS -- the 256 x 256 tile: 270 KB -- leaves in two column halves)
+        constexpr int HALVES = ((size_t)TBM * (BN + 8) * 4 > 160u * 1024u) ? 2 : 1;
+        constexpr int BNH = BN / HALVES, OS = BNH + 8;
         __bf16* th = reinterpret_cast<__bf16*>(smem);
         __bf16* tl = th + TBM * OS;
         const bool ep_res = p.ep_res != nullptr;
-#pragma unroll
-        for (int b = 0; b < NTT; ++b) {
-            const int col = (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
-            const bool cok = co0 + col < p.Cout;
-            const float esc = cok ? p.ep_scale[co0 + col] : 1.0f, esh = cok ? p.ep_shift[co0 + col] : 0.0f;
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = (wm * MT + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    float v = __builtin_fmaf(acc[a][b][i], esc, esh);
-                    if (p.ep_relu && !ep_res && !(v > 0.0f)) v = 0.0f;
-                    const __bf16 vh = (__bf16)v;
-                    th[row * OS + col] = vh;
-                    tl[row * OS + col] = (__bf16)(v - (float)vh);
-                }
-        }
-        __syncthreads();
-        constexpr int CPR = BN / 8;
+        constexpr int CPR = BNH / 8;
         const long rs = 2L * p.Cout;                         // output (and residual) row stride in elements: [hi | lo]
-        for (int idx = tid; idx < TBM * CPR; idx += NTHR) {
-            const int row = idx / CPR, ch = idx % CPR;
-            const long m = row_to_m(row);
-            const int co = co0 + ch * 8;
-            if (m < M && co < p.Cout) {
-                u32x4 vh = *reinterpret_cast<const u32x4*>(th + (size_t)row * OS + ch * 8);
-                u32x4 vl = *reinterpret_cast<const u32x4*>(tl + (size_t)row * OS + ch * 8);
-                if (ep_res) {
-                    const unsigned short* rp = reinterpret_cast<const unsigned short*>(p.ep_res) + m * rs + co;
-                    const u32x4 rh = *reinterpret_cast<const u32x4*>(rp);
-                    const u32x4 rl = *reinterpret_cast<const u32x4*>(rp + p.Cout);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v0 = (__builtin_bit_cast(float, vh[e] << 16) + __builtin_bit_cast(float, vl[e] << 16)) +
-                                   (__builtin_bit_cast(float, rh[e] << 16) + __builtin_bit_cast(float, rl[e] << 16));
-                        float v1 = (__builtin_bit_cast(float, vh[e] & 0xFFFF0000u) + __builtin_bit_cast(float, vl[e] & 0xFFFF0000u)) +
-                                   (__builtin_bit_cast(float, rh[e] & 0xFFFF0000u) + __builtin_bit_cast(float, rl[e] & 0xFFFF0000u));
-                        if (p.ep_relu && !(v0 > 0.0f)) v0 = 0.0f;
-                        if (p.ep_relu && !(v1 > 0.0f)) v1 = 0.0f;
-                        vh[e] = pack2(v0, v1);
-                        vl[e] = pack2(v0 - bf16_round(v0), v1 - bf16_round(v1));
+        for (int hf = 0; hf < HALVES; ++hf) {
+            if (hf) __syncthreads();                         // the previous half has been read out of LDS
+#pragma unroll
+            for (int b = 0; b < NTT; ++b) {
+                const int col = (BN >= 64 ? (wn * NT + b) * 32 : 0) + r;
+                if (HALVES > 1 && ((BN >= 64 ? (wn * NT + b) * 32 : 0) / BNH) != hf) continue;      // wave-uniform
+                const int lc = col - hf * BNH;
+                const bool cok = co0 + col < p.Cout;
+                const float esc = cok ? p.ep_scale[co0 + col] : 1.0f, esh = cok ? p.ep_shift[co0 + col] : 0.0f;
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = (wm * MT + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        float v = __builtin_fmaf(acc[a][b][i], esc, esh);
+                        if (p.ep_relu && !ep_res && !(v > 0.0f)) v = 0.0f;
+                        const __bf16 vh = (__bf16)v;
+                        th[row * OS + lc] = vh;
+                        tl[row * OS + lc] = (__bf16)(v - (float)vh);
                     }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < TBM * CPR; idx += NTHR) {
+                const int row = idx / CPR, ch = idx % CPR;
+                const long m = row_to_m(row);
+                const int co = co0 + hf * BNH + ch * 8;
+                if (m < M && co < p.Cout) {
+                    u32x4 vh = *reinterpret_cast<const u32x4*>(th + (size_t)row * OS + ch * 8);
+                    u32x4 vl = *reinterpret_cast<const u32x4*>(tl + (size_t)row * OS + ch * 8);
+                    if (ep_res) {
+                        const unsigned short* rp = reinterpret_cast<const unsigned short*>(p.ep_res) + m * rs + co;
+                        const u32x4 rh = *reinterpret_cast<const u32x4*>(rp);
+                        const u32x4 rl = *reinterpret_cast<const u32x4*>(rp + p.Cout);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v0 = (__builtin_bit_cast(float, vh[e] << 16) + __builtin_bit_cast(float, vl[e] << 16)) +
+                                       (__builtin_bit_cast(float, rh[e] << 16) + __builtin_bit_cast(float, rl[e] << 16));
+                            float v1 = (__builtin_bit_cast(float, vh[e] & 0xFFFF0000u) + __builtin_bit_cast(float, vl[e] & 0xFFFF0000u)) +
+                                       (__builtin_bit_cast(float, rh[e] & 0xFFFF0000u) + __builtin_bit_cast(float, rl[e] & 0xFFFF0000u));
+                            if (p.ep_relu && !(v0 > 0.0f)) v0 = 0.0f;
+                            if (p.ep_relu && !(v1 > 0.0f)) v1 = 0.0f;
+                            vh[e] = pack2(v0, v1);
+                            vl[e] = pack2(v0 - bf16_round(v0), v1 - bf16_round(v1));
+                        }
+                    }
+                    unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + m * rs + co;
+                    *reinterpret_cast<u32x4*>(yp) = vh;
+                    *reinterpret_cast<u32x4*>(yp + p.Cout) = vl;
                 }
-                unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + m * rs + co;
-                *reinterpret_cast<u32x4*>(yp) = vh;
-                *reinterpret_cast<u32x4*>(yp + p.Cout) = vl;
             }
         }
         return;
@@ -1275,6 +1283,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs p) {
 static int g_patch_min_wgs = 128;                          // (r4: 256 -> 128: in the two-stream step the other network's kernels fill what a 128-workgroup launch leaves idle)
 static int g_patch_pair = 0;                                // 1: Cout chunks of a pixel tile share an XCD (1-D launch, see the kernel)
 static int g_patch_chunk_stage = 1;                         // 32-channel chunks: chunk stages instead of the per-tap weight ring
+static int g_patch_wide_s3 = 1;                             // ... also for the split-3 launches (their output tile leaves in two column halves)
 static int g_patch_wide = 1;                                // 1 (r4): the 256-channel tile where it fills the chip -- 3-5 % slower than the unrolled 128 tile ALONE, but it reads the input rows once
                                                             // per 256 instead of per 128 output channels: in the two-stream step (fabric-bound as a whole) -0.9 ms; 0: r3
 #ifndef SHORTK_MINW
@@ -1381,6 +1390,11 @@ int conv_set_option(const char* key, int value) {
         g_patch_tile512_min_wgs = value;
         return prev;
     }
+    if (key && !strcmp(key, "conv3x3_patch_wide_tile_s3")) {
+        const int prev = g_patch_wide_s3;
+        g_patch_wide_s3 = value ? 1 : 0;
+        return prev;
+    }
     if (key && !strcmp(key, "conv3x3_patch_wide_tile")) {
         const int prev = g_patch_wide;
         g_patch_wide = value ? 1 : 0;
@@ -1409,7 +1423,8 @@ static void launch_patch_t(const ConvArgs& a, hipStream_t st) {
         const int nb = a.Cin / CK > 1 ? 2 : 1;
         lds = (size_t)nb * ((size_t)PI * 8 * 1024 + 9 * (size_t)BN * ROWB);
     }
-    const size_t out_tile = (size_t)TBM * (BN + 8) * 2 * (a.out_s3 ? 2 : 1);
+    size_t out_tile = (size_t)TBM * (BN + 8) * 2 * (a.out_s3 ? 2 : 1);
+    if (a.out_s3 && out_tile > 160u * 1024u) out_tile = (size_t)TBM * (BN / 2 + 8) * 4;      // (conv_epilogue: split-3 tiles this large leave in two column halves)
     if (out_tile > lds) lds = out_tile;
     const int tw = (a.W % 32 == 0) ? 32 : 16, th = TBM / tw;
     const long tiles = (long)a.N * (a.H / th) * (a.W / tw);
@@ -1687,7 +1702,7 @@ static hipError_t launch_conv_impl(const ConvArgs& a, int precise, hipStream_t s
         // 256-wide channel tile (wave tile 128 px x 64 co: 25 % fewer LDS fragment reads per MFMA) when it still fills the chip
         if (a.Cout == 64) launch_patch_t<64, 3, true>(a, st);
         else if (a.Cout == 32) launch_patch_t<32, 3, true>(a, st);
-        else if (a.Cout % 256 == 0 && g_patch_wide && !a.out_s3 && tiles * (a.Cout / 256) >= g_patch_min_wgs)   // (split-3: its output tile does not fit LDS)
+        else if (a.Cout % 256 == 0 && g_patch_wide && (!a.out_s3 || g_patch_wide_s3) && tiles * (a.Cout / 256) >= g_patch_min_wgs)
             launch_patch_t<256, 2, false>(a, st);
         else if (g_patch_unroll == 2)
             launch_patch_t<128, 4, true>(a, st);
