@@ -291,6 +291,7 @@ WGRAD_CASES = [
     # n, c1, c2, cout, h, w, reflect
     (2, 64, 0, 128, 8, 32, True), (3, 128, 64, 64, 12, 16, False), (2, 32, 0, 32, 16, 48, False), (1, 96, 32, 32, 8, 16, False),
     (2, 64, 0, 32, 20, 16, True), (3, 32, 0, 128, 4, 16, False), (2, 32, 0, 64, 8, 16, True), (5, 256, 256, 128, 16, 16, False),
+    (4, 128, 0, 128, 32, 32, False), (4, 64, 64, 256, 32, 32, True),      # r4: >= 8 slabs of several (ci, co) tiles: the XCD-aware 1-D grid
 ]
 
 
@@ -332,6 +333,7 @@ WGRAD_S2_CASES = [
     # n, cin, cout, h, w (input size; output h / 2, w / 2), reflect, second source (two-use launch)
     (2, 128, 128, 32, 32, True, False), (3, 64, 128, 8, 64, False, False), (1, 96, 256, 12, 32, True, False),
     (2, 256, 128, 4, 32, False, True), (3, 128, 256, 16, 32, True, True),
+    (4, 128, 256, 64, 64, True, False), (4, 128, 128, 64, 64, False, True),     # >= 8 slabs of several tiles: the XCD-aware 1-D grid
 ]
 
 
@@ -377,6 +379,7 @@ WGRAD1_CASES = [
     (2, 128, 256, 16, 16, 1), (3, 64, 256, 9, 7, 1), (2, 128, 128, 8, 24, 1), (1, 64, 128, 20, 20, 1), (2, 256, 64, 12, 12, 1),
     (2, 256, 512, 16, 16, 2), (1, 128, 256, 15, 9, 2), (4, 1024, 256, 8, 8, 1),
     (2, 64, 64, 16, 16, 1), (3, 64, 64, 9, 7, 1), (2, 192, 64, 12, 20, 1),      # r4: 64 output channels on four waves (<2, 2>)
+    (2, 256, 256, 32, 32, 1), (2, 256, 512, 64, 32, 2),                         # r4: >= 8 slabs of several tiles: the XCD-aware 1-D grid
 ]
 
 
