@@ -43,8 +43,9 @@ const char* vqseg_kernel_name(const char* entry_point);
 
 /* Dispatch tunables (tests use them to reach every kernel with small shapes).  Keys:
  *   "conv3x3_patch_min_workgroups"  minimum grid of the patch-reuse 3x3 kernel before the generic implicit-GEMM
- *                                   kernel is preferred (default 256 = one workgroup per CU)
- *   "conv3x3_patch_unroll", "conv3x3_patch_wide_tile"   variants of that kernel (tap loop unrolled; 256-channel tile)
+ *                                   kernel is preferred, and of its 256-channel tile (default 128, r4; r3: 256 = one workgroup per CU)
+ *   "conv3x3_patch_unroll", "conv3x3_patch_wide_tile"   variants of that kernel (tap loop unrolled; 256-channel tile: default ON from r4 -- half
+ *                                   the input re-reads; slower on a layer alone, faster in the two-stream step)
  *   "vq_max_tiles_per_wave"         cap (8, 4, 2, 1) on the 32-code accumulator tiles a wave of the VQ distance kernel
  *                                   holds (default 8; 4 measured equal within 2 % on every benchmark shape)
  *   "vq_bf16_filter"                1 (default): bf16 rows of layers with K % 256 == 0 and C % 32 == 0 take the bf16-MFMA candidate
@@ -52,7 +53,7 @@ const char* vqseg_kernel_name(const char* entry_point);
  *                                   "vq_filter_force_all" = 1 (tests): the filter decides nothing, every row is re-scored;
  *                                   "vq_filter_launches": returns the number of launches that took the filter so far, sets the counter
  *   "conv_xcd_pair"                 implicit-GEMM layers with 2..value Cout chunks launch 1-D so that the chunks of an
- *                                   M tile run on the same XCD and share the input rows through its L2 (default 4; 0: off)
+ *                                   M tile run on the same XCD and share the input rows through its L2 (default 8, r4; r3: 4; 0: off)
  *   "conv3x3_patch_chunk_stage"     1 (default): 3x3 layers with 32-channel K chunks and <= 64 outputs (or 32 inputs) load all nine
  *                                   taps' weights with the patch -- one wait and barrier per chunk instead of per tap; 0: tap ring
  *   "conv3x3_patch_tile512"         512-pixel tiles of the patch kernel (32-channel chunks) for 32 / 64 output channels: 2 (default) on, 0
@@ -72,6 +73,8 @@ const char* vqseg_kernel_name(const char* entry_point);
  *                                   four-launch path with the padded grid)
  *   "conv_wgrad3x3_fill"            1 (default): nine-tap weight gradients split into one FULL round of resident workgroups (r4);
  *                                   0: r3's split
+ *   "conv3x3_patch_wide_tile_s3"    1 (default): the split-3 3x3 launches take the 256-channel tile too (r4); "conv_wgrad_round_pct": workgroups the
+ *                                   LDS-DMA weight gradients aim at, in percent of one resident round (default 100; 10..400)
  *   "stem_fused"                    1 (default): vqseg_stem7_conv_f available (r4); 0: it returns VQSEG_EINVAL (patch-matrix path)
  *   "conv_wgrad_xcd"                1 (default): a pixel slab's (ci, co) tiles of the LDS-DMA weight-gradient kernels on one XCD (r4); 0: 3-D grid
  *   "im2col_strip"                  1 (default): the stem's patch matrix from LDS-staged strips (r4, bit-identical); 0: the gather kernel
