@@ -947,3 +947,37 @@ def test_conv3x3_patch_kernel_256_channel_tile(case):
     assert rel(res[1][0].float(), ref) < 2 ** -7
     assert torch.equal(res[1][0].view(torch.int16), res[0][0].view(torch.int16))
     assert torch.equal(res[1][1], res[0][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_residual_batchnorm_backward_with_the_masked_gradient_written_by_the_reduce_pass(dtype):
+    """r4: for a layer with a residual branch the backward's reduce pass writes the ReLU-masked gradient (= the residual branch's
+    gradient) and the apply pass reads that instead of (g_out, out) -- one tensor read less; every output (input / residual /
+    weight / BatchNorm gradients) bit-identical to the two-pass form that reads g_out and out twice (option bn_bwd_premask = 0)."""
+    import copy
+    from vq_seg_amd import _hip, nnf
+    torch.manual_seed(2)
+    conv = nn.Conv2d(64, 128, 1, bias=False).to(dev())
+    bn = nn.BatchNorm2d(128).to(dev())
+    x = cl(synth.uniform(1, (3, 64, 12, 20), -1, 1)).to(dev())
+    r = cl(synth.uniform(2, (3, 128, 12, 20), -1, 1)).to(dev())
+    g = cl(synth.uniform(3, (3, 128, 12, 20), -1, 1)).to(dev())
+    res = {}
+    for opt in (1, 0):
+        prev = _hip.set_option("bn_bwd_premask", opt)
+        try:
+            c, b = copy.deepcopy(conv), copy.deepcopy(bn)
+            xx, rr = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+            if dtype == torch.bfloat16:
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    out = nnf.conv_bn_act(xx.to(dtype), c, b, relu=True, residual=rr.to(dtype))
+            else:
+                out = nnf.conv_bn_act(xx, c, b, relu=True, residual=rr)
+            out.backward(g.to(out.dtype))
+            torch.cuda.synchronize()
+            res[opt] = (out.detach().float(), xx.grad, rr.grad, c.weight.grad, b.weight.grad, b.bias.grad)
+        finally:
+            _hip.set_option("bn_bwd_premask", prev)
+    for i, (a, b_) in enumerate(zip(res[1], res[0])):
+        assert torch.equal(a, b_), i

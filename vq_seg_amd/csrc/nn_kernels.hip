@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const T* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ fsc,
                                                             const float* __restrict__ fsh, long M, int C, int relu,
-                                                            float* partial, int rows_per_block, const BnBwdFin fin) {
+                                                            float* partial, int rows_per_block, const BnBwdFin fin, T* __restrict__ gz_out = nullptr) {
     constexpr int V = VecN<T>::N;
     __shared__ float sh[2][256 * V];                       // [sum kind][row lane][channel in group]
     const int cg = C < BNB_CG ? C : BNB_CG;                // channels handled by this block
@@ -386,7 +386,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                     const float gz = (MASK != 0 && !(o[e] > 0.0f)) ? 0.0f : g[e];
                     s0[e] += gz;
                     s1[e] = __builtin_fmaf(gz, (yy[e] - mu[e]) * is[e], s1[e]);
+                    g[e] = gz;
                 }
+                // r4 (residual layers, MASK == 1): the masked gradient IS the residual branch's gradient -- written here, the apply pass
+                // then reads it instead of (g_out, out): one tensor read less per backward of a residual layer
+                if (MASK == 1 && gz_out) stv(gz_out, m * C + c0 + cv, g);
             }
         }
     } else {                                               // scalar fallback (odd channel counts): one channel per thread
@@ -402,6 +406,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 float gz = ld(g_out, m * C + c0 + cv);
                 const float yv = ld(y, m * C + c0 + cv);
                 if (MASK != 0 && !((MASK == 1 ? ld(out, m * C + c0 + cv) : yv * fsc[c0 + cv] + fsh[c0 + cv]) > 0.0f)) gz = 0.0f;
+                if (MASK == 1 && gz_out) st(gz_out, m * C + c0 + cv, gz);
                 s0[0] += gz;
                 s1[0] = __builtin_fmaf(gz, (yv - mu) * is, s1[0]);
             }
@@ -1626,6 +1631,10 @@ int nn_set_option(const char* key, int value) {
         g_debug_skip_small = value;
         return prev;
     }
+    if (key && !strcmp(key, "bn_bwd_premask")) {
+        extern int bn_bwd_premask_option(int);
+        return bn_bwd_premask_option(value);
+    }
     if (key && !strcmp(key, "im2col_strip")) {
         extern int im2col_strip_option(int);
         return im2col_strip_option(value);
@@ -1690,6 +1699,12 @@ static int bn_bwd_rows_per_block(long M) {
     return (int)r;
 }
 
+static int g_bn_bwd_premask = 1;                            // residual layers: masked gradient written by the reduce pass (0: r3, both passes read g_out + out)
+int bn_bwd_premask_option(int value) {
+    const int prev = g_bn_bwd_premask;
+    g_bn_bwd_premask = value ? 1 : 0;
+    return prev;
+}
 template <typename T, int MASK>
 static hipError_t bn_bwd_t(const void* g_out, const void* out, const void* y, const float* mean, const float* invstd,
                            const float* gamma, const float* fsc, const float* fsh, long M, int C, int relu, int training,
@@ -1698,11 +1713,18 @@ static hipError_t bn_bwd_t(const void* g_out, const void* out, const void* y, co
     const int rpb = sync ? bn_bwd_rows_per_block(M) : BNB_ROWS_MIN;
     const long nb = (M + rpb - 1) / rpb;
     const BnBwdFin fin{gamma, training, accumulate, dgamma, dbeta, coef, (g_debug_skip_small & 2) ? nullptr : sync};
+    // residual layers (MASK == 1 with a g_res output): the reduce pass writes the masked gradient = g_res, the apply pass runs unmasked on it
+    const bool premask = MASK == 1 && g_res != nullptr && g_bn_bwd_premask;
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK>), dim3((unsigned)nb, (unsigned)((C + BNB_CG - 1) / BNB_CG)), dim3(256), 0, st_,
-                       (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, fsc, fsh, M, C, relu, partial, rpb, fin);
+                       (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, fsc, fsh, M, C, relu, partial, rpb, fin,
+                       premask ? (T*)g_res : (T*)nullptr);
     if (!(g_debug_skip_small & 2) && !sync)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st_, partial, nb, M, C, gamma, invstd, training, accumulate, dgamma,
                        dbeta, coef);
+    if (premask)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0>), dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_,
+                           (const T*)g_res, (const T*)nullptr, (const T*)y, mean, invstd, coef, fsc, fsh, M, C, 0, (T*)g_y, (T*)nullptr);
+    else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK>), dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_,
                        (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, coef, fsc, fsh, M, C, relu, (T*)g_y, (T*)g_res);
     return hipGetLastError();
