@@ -307,6 +307,15 @@ int vqseg_bn_backward_f(int bf16, const void* g_out, const void* out, const void
                         const float* invstd, const float* gamma, const float* fwd_scale, const float* fwd_shift,
                         int64_t m_rows, int c, int relu, int training, int accumulate,
                         float* workspace, float* dgamma, float* dbeta, void* g_y, void* g_res, int* sync, void* stream);
+/* r4, residual layers in bf16 (out = relu(y*scale + shift + res), resnet.py:106-108 / 67-69; c % 8 == 0): the apply pass also
+ * writes the ReLU mask as a bit field, bits[i / 8] bit (i % 8) = (out[i] > 0) over the flat [m_rows * c] index (m_rows * c / 8
+ * bytes), and the backward reads that instead of `out` (1/16 of its bytes).  g_res (required) = g_out * mask, the residual
+ * branch's gradient.  Results are bit-identical to vqseg_bn_apply_f / vqseg_bn_backward_f with `out`. */
+int vqseg_bn_apply_bits_f(const void* y, const void* res, const float* scale, const float* shift, int64_t m_rows, int c,
+                          void* out, unsigned char* bits, void* stream);
+int vqseg_bn_backward_bits_f(const void* g_out, const unsigned char* bits, const void* y, const float* mean,
+                             const float* invstd, const float* gamma, int64_t m_rows, int c, int training, int accumulate,
+                             float* workspace, float* dgamma, float* dbeta, void* g_y, void* g_res, int* sync, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) (resnet.py:167) forward / backward (first maximum in scan order).
  * idx (nullable, uint8 [n, ho, wo, c]): forward writes the window position (kh*3+kw) of each maximum; backward

@@ -953,8 +953,10 @@ def test_conv3x3_patch_kernel_256_channel_tile(case):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_residual_batchnorm_backward_with_the_masked_gradient_written_by_the_reduce_pass(dtype):
     """r4: for a layer with a residual branch the backward's reduce pass writes the ReLU-masked gradient (= the residual branch's
-    gradient) and the apply pass reads that instead of (g_out, out) -- one tensor read less; every output (input / residual /
-    weight / BatchNorm gradients) bit-identical to the two-pass form that reads g_out and out twice (option bn_bwd_premask = 0)."""
+    gradient) and the apply pass reads that instead of (g_out, out) -- one tensor read less; in bf16 the forward also leaves the
+    ReLU mask as a bit field and the reduce pass reads that instead of `out` (vqseg_bn_apply_bits_f / vqseg_bn_backward_bits_f).
+    Every output (activation, input / residual / weight / BatchNorm gradients) bit-identical between the three forms: bit field,
+    masked gradient from `out` (py_bn_bits = 0), r3's two passes over g_out and out (bn_bwd_premask = 0)."""
     import copy
     from vq_seg_amd import _hip, nnf
     torch.manual_seed(2)
@@ -964,8 +966,11 @@ def test_residual_batchnorm_backward_with_the_masked_gradient_written_by_the_red
     r = cl(synth.uniform(2, (3, 128, 12, 20), -1, 1)).to(dev())
     g = cl(synth.uniform(3, (3, 128, 12, 20), -1, 1)).to(dev())
     res = {}
-    for opt in (1, 0):
+    nnf.lib()
+    for bits, opt in ((1, 1), (0, 1), (0, 0)):
         prev = _hip.set_option("bn_bwd_premask", opt)
+        prev_bits = _hip.PY_OPTS.get("py_bn_bits")
+        _hip.PY_OPTS["py_bn_bits"] = bits
         try:
             c, b = copy.deepcopy(conv), copy.deepcopy(bn)
             xx, rr = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
@@ -974,10 +979,45 @@ def test_residual_batchnorm_backward_with_the_masked_gradient_written_by_the_red
                     out = nnf.conv_bn_act(xx.to(dtype), c, b, relu=True, residual=rr.to(dtype))
             else:
                 out = nnf.conv_bn_act(xx, c, b, relu=True, residual=rr)
+            assert out.grad_fn.mask_bits == (bits == 1 and dtype == torch.bfloat16)
             out.backward(g.to(out.dtype))
             torch.cuda.synchronize()
-            res[opt] = (out.detach().float(), xx.grad, rr.grad, c.weight.grad, b.weight.grad, b.bias.grad)
+            res[bits, opt] = (out.detach().float(), xx.grad, rr.grad, c.weight.grad, b.weight.grad, b.bias.grad)
         finally:
             _hip.set_option("bn_bwd_premask", prev)
-    for i, (a, b_) in enumerate(zip(res[1], res[0])):
-        assert torch.equal(a, b_), i
+            if prev_bits is None:
+                _hip.PY_OPTS.pop("py_bn_bits", None)
+            else:
+                _hip.PY_OPTS["py_bn_bits"] = prev_bits
+    for key in ((1, 1), (0, 1)):
+        for i, (a, b_) in enumerate(zip(res[key], res[0, 0])):
+            assert torch.equal(a, b_), (key, i)
+
+
+@pytest.mark.gpu
+def test_batchnorm_apply_writes_the_relu_mask_as_a_bit_field():
+    """vqseg_bn_apply_bits_f: out as vqseg_bn_apply_f's; bit (i % 8) of bits[i / 8] = (out[i] > 0) over the flat index -- tested
+    on the value as STORED (bf16), incl. pre-activations that round to zero; rejects channel counts that are not multiples of 8."""
+    from vq_seg_amd import _hip, nnf
+    L = nnf.lib()
+    m, c = 1000, 72
+    y = synth.uniform(5, (m, c), -2, 2).to(dev()).to(torch.bfloat16)
+    r = synth.uniform(6, (m, c), -2, 2).to(dev()).to(torch.bfloat16)
+    y[:, 0] = 1e-30                                                          # 1e-30 * 1e-12 is positive in fp32, below bf16's smallest subnormal
+    r[:, 0] = 0
+    sc = synth.uniform(7, (c,), 0.5, 1.5).to(dev())
+    sh = synth.uniform(8, (c,), -0.5, 0.5).to(dev())
+    sc[0], sh[0] = 1e-12, 0.0
+    out = torch.empty_like(y)
+    ref = torch.empty_like(y)
+    bits = torch.zeros(m * c // 8, dtype=torch.uint8, device=dev())
+    s = torch.cuda.current_stream().cuda_stream
+    assert L.vqseg_bn_apply_bits_f(y.data_ptr(), r.data_ptr(), sc.data_ptr(), sh.data_ptr(), m, c, out.data_ptr(), bits.data_ptr(), s) == 0
+    assert L.vqseg_bn_apply_f(1, y.data_ptr(), r.data_ptr(), sc.data_ptr(), sh.data_ptr(), m, c, 1, ref.data_ptr(), s) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    want = (out.reshape(-1, 8) > 0).to(torch.int32)
+    want = (want << torch.arange(8, device=dev(), dtype=torch.int32)).sum(1).to(torch.uint8)
+    assert torch.equal(bits, want)
+    assert not bool((out[:, 0] > 0).any())
+    assert L.vqseg_bn_apply_bits_f(y.data_ptr(), r.data_ptr(), sc.data_ptr(), sh.data_ptr(), m * 2, c // 2, out.data_ptr(), bits.data_ptr(), s) != 0

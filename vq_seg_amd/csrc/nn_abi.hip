@@ -196,6 +196,14 @@ int vqseg_bn_apply_f(int bf16, const void* y, const void* res, const float* scal
     return e == hipSuccess ? 0 : hipfail(e, "bn_apply_kernel");
 }
 
+int vqseg_bn_apply_bits_f(const void* y, const void* res, const float* scale, const float* shift, int64_t m_rows, int c, void* out,
+                          unsigned char* bits, void* stream) {
+    if (!y || !scale || !shift || !out || !bits || c <= 0 || m_rows <= 0) return bad("bn_apply_bits: bad argument");
+    if (c % 8) return bad("bn_apply_bits: the channel count must be a multiple of 8");
+    hipError_t e = vqseg::launch_bn_apply(1, y, res, scale, shift, m_rows, c, 1, out, static_cast<hipStream_t>(stream), bits);
+    return e == hipSuccess ? 0 : hipfail(e, "bn_apply_kernel");
+}
+
 size_t vqseg_bn_backward_workspace_floats(int64_t m_rows, int c) {
     if (m_rows <= 0 || c <= 0) return 0;
     return (size_t)vqseg::bn_bwd_blocks(m_rows) * 2 * c + 3 * (size_t)c;
@@ -214,6 +222,19 @@ int vqseg_bn_backward_f(int bf16, const void* g_out, const void* out, const void
     hipError_t e = vqseg::launch_bn_backward(bf16, g_out, out, y, mean, invstd, gamma, fwd_scale, fwd_shift, m_rows, c, relu, training, accumulate, partial, coef,
                                              dgamma, dbeta, g_y, g_res, sync, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hipfail(e, "bn_backward");
+}
+
+int vqseg_bn_backward_bits_f(const void* g_out, const unsigned char* bits, const void* y, const float* mean, const float* invstd,
+                             const float* gamma, int64_t m_rows, int c, int training, int accumulate, float* workspace, float* dgamma,
+                             float* dbeta, void* g_y, void* g_res, int* sync, void* stream) {
+    if (!g_out || !bits || !y || !mean || !invstd || !gamma || !workspace || !dgamma || !dbeta || !g_y || !g_res)
+        return bad("bn_backward_bits: null pointer");
+    if (c <= 0 || c % 8) return bad("bn_backward_bits: the channel count must be a multiple of 8");
+    float* partial = workspace;
+    float* coef = workspace + (size_t)vqseg::bn_bwd_blocks(m_rows) * 2 * c;
+    hipError_t e = vqseg::launch_bn_backward(1, g_out, nullptr, y, mean, invstd, gamma, nullptr, nullptr, m_rows, c, 1, training, accumulate, partial,
+                                             coef, dgamma, dbeta, g_y, g_res, sync, static_cast<hipStream_t>(stream), bits);
+    return e == hipSuccess ? 0 : hipfail(e, "bn_backward_bits");
 }
 
 int vqseg_maxpool3x3s2_f(int bf16, int backward, const void* x, const void* g, int n, int h, int w, int c, void* out,

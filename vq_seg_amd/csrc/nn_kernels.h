@@ -14,12 +14,12 @@ hipError_t launch_bn_finalize(float* partial, long n_slots, int rows_per_slot, l
 hipError_t launch_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var,
                                  float eps, float* scale, float* shift, float* save_mean, float* save_invstd, hipStream_t st);
 hipError_t launch_bn_apply(int bf16, const void* y, const void* res, const float* scale, const float* shift, long M, int C,
-                           int relu, void* out, hipStream_t st);
+                           int relu, void* out, hipStream_t st, unsigned char* bits = nullptr);
 long bn_bwd_blocks(long M);
 hipError_t launch_bn_backward(int bf16, const void* g_out, const void* out, const void* y, const float* mean,
                               const float* invstd, const float* gamma, const float* fwd_scale, const float* fwd_shift, long M,
                               int C, int relu, int training, int accumulate, float* partial, float* coef, float* dgamma, float* dbeta, void* g_y,
-                              void* g_res, int* sync, hipStream_t st);
+                              void* g_res, int* sync, hipStream_t st, const unsigned char* bits = nullptr);
 hipError_t launch_maxpool(int bf16, int backward, const void* x, const void* g, int N, int H, int W, int C, void* out,
                           unsigned char* idx, hipStream_t st);
 hipError_t launch_bilinear(int bf16, int backward, const void* src, int N, int H, int W, int C, int Ho, int Wo, int align,

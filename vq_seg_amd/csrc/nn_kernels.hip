@@ -265,11 +265,23 @@ __global__ __launch_bounds__(256) void bn_eval_coeffs_kernel(int C, const float*
     save_invstd[c] = invstd;
 }
 
+// (stored value > 0) of V values as a bit field: the test runs on the value ROUNDED to T, i.e. on what `out > 0` reads back later
+template <typename T, int V>
+__device__ inline unsigned char relu_bits(const float (&v)[V]) {
+    unsigned b = 0;
+#pragma unroll
+    for (int e = 0; e < V; ++e) b |= ((float)(T)v[e] > 0.0f ? 1u : 0u) << e;
+    return (unsigned char)b;
+}
+
 // out = [relu]( y * scale[c] + shift[c] [+ res] )      (16 bytes per thread when C allows, else scalar)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       long M, int C, int relu, T* __restrict__ out) {
+                                                       long M, int C, int relu, T* __restrict__ out,
+                                                       unsigned char* __restrict__ bits = nullptr) {
+    // bits (nullable; 8-element vectors only, i.e. bf16 with C % 8 == 0): bit e of bits[i / 8] = (out[i + e] > 0), the ReLU mask
+    // the backward of a residual layer reads instead of `out` (1/16 of its bytes)
     constexpr int V = VecN<T>::N;
     const long total = M * C;
     if (C % V == 0 && (256 * V) % C == 0) {
@@ -294,6 +306,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
                 v[e] = (relu && !(t > 0.0f)) ? 0.0f : t;
             }
             stv(out, i, v);
+            if (V == 8 && bits) bits[i >> 3] = relu_bits<T, V>(v);
         }
     } else if (C % V == 0) {
         for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * V; i < total; i += (long)gridDim.x * 256 * V) {
@@ -308,6 +321,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
                 v[e] = (relu && !(t > 0.0f)) ? 0.0f : t;
             }
             stv(out, i, v);
+            if (V == 8 && bits) bits[i >> 3] = relu_bits<T, V>(v);
         }
     } else {
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -328,7 +342,8 @@ constexpr int BNB_CG = 64;         // channels per block
 
 // grid (row chunks, channel groups).  Each thread owns V consecutive channels (one 16-byte load) of every
 // (256 / threads-per-row)-th row of the chunk; row lanes are folded through LDS in a fixed order.
-// MASK: 0 no ReLU, 1 mask from `out`, 2 mask recomputed as fma(y, fsc, fsh) > 0 (the forward's expression; no residual)
+// MASK: 0 no ReLU, 1 mask from `out`, 2 mask recomputed as fma(y, fsc, fsh) > 0 (the forward's expression; no residual),
+//       3 mask from the forward's bit field (`out` then points at bytes: bit e of byte i/8 = out[i + e] > 0; 8-element vectors only)
 // Finalize arguments of the fused reduce (sync != null): see bn_bwd_finalize_kernel
 struct BnBwdFin {
     const float* gamma;
@@ -377,6 +392,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 ldv(g_out, m * C + c0 + cv, g);
                 ldv(y, m * C + c0 + cv, yy);
                 if (MASK == 1) ldv(out, m * C + c0 + cv, o);
+                if (MASK == 3) {
+                    const unsigned mb = reinterpret_cast<const unsigned char*>(out)[(m * C + c0 + cv) >> 3];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) o[e] = (mb >> (e & 7)) & 1u ? 1.0f : 0.0f;
+                }
                 if (MASK == 2) {
 #pragma unroll
                     for (int e = 0; e < V; ++e) o[e] = __builtin_fmaf(yy[e], sc[e], sf[e]);
@@ -390,7 +410,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 }
                 // r4 (residual layers, MASK == 1): the masked gradient IS the residual branch's gradient -- written here, the apply pass
                 // then reads it instead of (g_out, out): one tensor read less per backward of a residual layer
-                if (MASK == 1 && gz_out) stv(gz_out, m * C + c0 + cv, g);
+                if ((MASK == 1 || MASK == 3) && gz_out) stv(gz_out, m * C + c0 + cv, g);
             }
         }
     } else {                                               // scalar fallback (odd channel counts): one channel per thread
@@ -1679,15 +1699,16 @@ hipError_t launch_bn_eval_coeffs(int C, const float* gamma, const float* beta, c
 
 template <typename T>
 static hipError_t bn_apply_t(const void* y, const void* res, const float* scale, const float* shift, long M, int C, int relu,
-                             void* out, hipStream_t st_) {
+                             void* out, hipStream_t st_, unsigned char* bits) {
+    if (bits && (VecN<T>::N != 8 || C % 8 != 0)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_, (const T*)y,
-                       (const T*)res, scale, shift, M, C, relu, (T*)out);
+                       (const T*)res, scale, shift, M, C, relu, (T*)out, bits);
     return hipGetLastError();
 }
 hipError_t launch_bn_apply(int bf16, const void* y, const void* res, const float* scale, const float* shift, long M, int C,
-                           int relu, void* out, hipStream_t st_) {
-    return bf16 ? bn_apply_t<__bf16>(y, res, scale, shift, M, C, relu, out, st_)
-                : bn_apply_t<float>(y, res, scale, shift, M, C, relu, out, st_);
+                           int relu, void* out, hipStream_t st_, unsigned char* bits) {
+    return bf16 ? bn_apply_t<__bf16>(y, res, scale, shift, M, C, relu, out, st_, bits)
+                : bn_apply_t<float>(y, res, scale, shift, M, C, relu, out, st_, bits);
 }
 
 long bn_bwd_blocks(long M) { return (M + BNB_ROWS_MIN - 1) / BNB_ROWS_MIN; }       // upper bound (workspace sizing)
@@ -1714,7 +1735,9 @@ static hipError_t bn_bwd_t(const void* g_out, const void* out, const void* y, co
     const long nb = (M + rpb - 1) / rpb;
     const BnBwdFin fin{gamma, training, accumulate, dgamma, dbeta, coef, (g_debug_skip_small & 2) ? nullptr : sync};
     // residual layers (MASK == 1 with a g_res output): the reduce pass writes the masked gradient = g_res, the apply pass runs unmasked on it
-    const bool premask = MASK == 1 && g_res != nullptr && g_bn_bwd_premask;
+    const bool premask = (MASK == 1 && g_res != nullptr && g_bn_bwd_premask) || MASK == 3;
+    if (MASK == 3 && (!g_res || C % VecN<T>::N != 0 || VecN<T>::N != 8)) return hipErrorInvalidValue;
+    constexpr int AMASK = MASK == 3 ? 0 : MASK;             // the bit-field form always runs the apply pass on the masked gradient
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK>), dim3((unsigned)nb, (unsigned)((C + BNB_CG - 1) / BNB_CG)), dim3(256), 0, st_,
                        (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, fsc, fsh, M, C, relu, partial, rpb, fin,
                        premask ? (T*)g_res : (T*)nullptr);
@@ -1725,21 +1748,23 @@ static hipError_t bn_bwd_t(const void* g_out, const void* out, const void* y, co
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0>), dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_,
                            (const T*)g_res, (const T*)nullptr, (const T*)y, mean, invstd, coef, fsc, fsh, M, C, 0, (T*)g_y, (T*)nullptr);
     else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK>), dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, AMASK>), dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_,
                        (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, coef, fsc, fsh, M, C, relu, (T*)g_y, (T*)g_res);
     return hipGetLastError();
 }
 hipError_t launch_bn_backward(int bf16, const void* g_out, const void* out, const void* y, const float* mean,
                               const float* invstd, const float* gamma, const float* fsc, const float* fsh, long M, int C, int relu,
                               int training, int accumulate, float* partial,
-                              float* coef, float* dgamma, float* dbeta, void* g_y, void* g_res, int* sync, hipStream_t st_) {
-    const int mask = !relu ? 0 : (out ? 1 : 2);
+                              float* coef, float* dgamma, float* dbeta, void* g_y, void* g_res, int* sync, hipStream_t st_,
+                              const unsigned char* bits) {
+    const int mask = !relu ? 0 : (bits ? 3 : out ? 1 : 2);
+    if (mask == 3) out = bits;
 #define BN_BWD_CASE(T_, MASK_)                                                                                                   \
     if (mask == MASK_)                                                                                                            \
         return bn_bwd_t<T_, MASK_>(g_out, out, y, mean, invstd, gamma, fsc, fsh, M, C, relu, training, accumulate, partial, coef, dgamma, dbeta, \
                                    g_y, g_res, sync, st_);
     if (bf16) {
-        BN_BWD_CASE(__bf16, 0) BN_BWD_CASE(__bf16, 1) BN_BWD_CASE(__bf16, 2)
+        BN_BWD_CASE(__bf16, 0) BN_BWD_CASE(__bf16, 1) BN_BWD_CASE(__bf16, 2) BN_BWD_CASE(__bf16, 3)
     } else {
         BN_BWD_CASE(float, 0) BN_BWD_CASE(float, 1) BN_BWD_CASE(float, 2)
     }

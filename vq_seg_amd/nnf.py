@@ -623,10 +623,21 @@ class _ConvBNAct(torch.autograd.Function):
             if rr is not None and rr.dtype != y.dtype:
                 raise _hip.HipLibraryError("residual dtype differs from the activation dtype")
             out = torch.empty_like(y)
-            _check(L.vqseg_bn_apply_f(bf, _T(y, "conv output", bf=bf, numel=m * cout), _T(rr, "residual", bf=bf, numel=m * cout),
-                                      _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout), m, cout, int(relu),
-                                      _T(out, "BN output", bf=bf, numel=m * cout), _stream()), "vqseg_bn_apply_f")
-        ctx.save_for_backward(xr, x2r, y, out, coef, weight, gamma)
+            # residual layers in bf16: the ReLU mask goes to the backward as a bit field (1/16 of `out`'s bytes), see vqseg.h
+            bits = (torch.empty(m * cout // 8, dtype=torch.uint8, device=dev)
+                    if (rr is not None and relu and bf and cout % 8 == 0 and training and py_opt("py_bn_bits", 1)) else None)
+            if bits is not None:
+                _check(L.vqseg_bn_apply_bits_f(_T(y, "conv output", bf=1, numel=m * cout), _T(rr, "residual", bf=1, numel=m * cout),
+                                               _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout), m, cout,
+                                               _T(out, "BN output", bf=1, numel=m * cout),
+                                               _T(bits, "ReLU mask bits", dtype=torch.uint8, numel=m * cout // 8), _stream()),
+                       "vqseg_bn_apply_bits_f")
+            else:
+                _check(L.vqseg_bn_apply_f(bf, _T(y, "conv output", bf=bf, numel=m * cout), _T(rr, "residual", bf=bf, numel=m * cout),
+                                          _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout), m, cout, int(relu),
+                                          _T(out, "BN output", bf=bf, numel=m * cout), _stream()), "vqseg_bn_apply_f")
+        ctx.mask_bits = bits is not None
+        ctx.save_for_backward(xr, x2r, y, bits if bits is not None else out, coef, weight, gamma)
         ctx.stem_x = stem_x if stem_img else None                           # the image tensor OBJECT the patch matrix is shared under
         ctx.params = (weight, gamma, beta)                                  # the Parameter objects (see grad sinks)
         ctx.bn = bn
@@ -663,13 +674,22 @@ class _ConvBNAct(torch.autograd.Function):
         dgamma, dbeta = (p_g.grad, p_b.grad) if sink_bn else (dgb[0], dgb[1])
         with _hip.on_device(dev):
             # without a residual the ReLU mask is recomputed from y with the forward's scale / shift: `out` is not re-read
-            _check_fused_bn(L.vqseg_bn_backward_f(bf, _T(g, "output gradient", bf=bf, numel=m * cout),
-                                         _T(out, "BN output", bf=bf, numel=m * cout) if has_res else None, _T(y, "conv output", bf=bf, numel=m * cout),
-                                         _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout), _f32(gamma.detach(), "bn.weight", cout),
-                                         _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout), m, cout, int(relu), int(training), int(sink_bn),
-                                         _f32(ws, "BN backward workspace"), _f32(dgamma, "bn.weight.grad", cout), _f32(dbeta, "bn.bias.grad", cout),
-                                         _T(g_y, "conv output gradient", bf=bf, numel=m * cout), _T(g_res, "residual gradient", bf=bf, numel=m * cout),
-                                         _T(_bn_sync(ctx.bn, True), "bn sync", dtype=torch.int32), _stream()), "vqseg_bn_backward_f", ctx.bn)
+            if ctx.mask_bits:                                               # `out` holds the forward's mask bits here
+                _check_fused_bn(L.vqseg_bn_backward_bits_f(
+                    _T(g, "output gradient", bf=1, numel=m * cout), _T(out, "ReLU mask bits", dtype=torch.uint8, numel=m * cout // 8),
+                    _T(y, "conv output", bf=1, numel=m * cout), _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout),
+                    _f32(gamma.detach(), "bn.weight", cout), m, cout, int(training), int(sink_bn), _f32(ws, "BN backward workspace"),
+                    _f32(dgamma, "bn.weight.grad", cout), _f32(dbeta, "bn.bias.grad", cout),
+                    _T(g_y, "conv output gradient", bf=1, numel=m * cout), _T(g_res, "residual gradient", bf=1, numel=m * cout),
+                    _T(_bn_sync(ctx.bn, True), "bn sync", dtype=torch.int32), _stream()), "vqseg_bn_backward_bits_f", ctx.bn)
+            else:
+                _check_fused_bn(L.vqseg_bn_backward_f(bf, _T(g, "output gradient", bf=bf, numel=m * cout),
+                                           _T(out, "BN output", bf=bf, numel=m * cout) if has_res else None, _T(y, "conv output", bf=bf, numel=m * cout),
+                                           _f32(coef[2], "mean", cout), _f32(coef[3], "invstd", cout), _f32(gamma.detach(), "bn.weight", cout),
+                                           _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout), m, cout, int(relu), int(training), int(sink_bn),
+                                           _f32(ws, "BN backward workspace"), _f32(dgamma, "bn.weight.grad", cout), _f32(dbeta, "bn.bias.grad", cout),
+                                           _T(g_y, "conv output gradient", bf=bf, numel=m * cout), _T(g_res, "residual gradient", bf=bf, numel=m * cout),
+                                           _T(_bn_sync(ctx.bn, True), "bn sync", dtype=torch.int32), _stream()), "vqseg_bn_backward_f", ctx.bn)
         if sink_bn:
             _sink_done(p_g), _sink_done(p_b)
         link_in, link_out, link_x = ctx.links
