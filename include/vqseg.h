@@ -262,6 +262,13 @@ int vqseg_conv2d_affine_f(const void* x, const void* x2, int c1, const void* w_h
                           const float* scale, const float* shift, const void* res, int relu, void* y,
                           int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int reflect,
                           int ho, int wo, int precise, void* stream);
+/* bf16, stride 1, zero padding, no concat: y = conv * scale[c] + shift[c] + res .* bits, with bits as written by
+ * vqseg_bn_apply_bits_f over res's flat [n*ho*wo*cout] index (cout % 8 == 0).  This is the data gradient of a residual block's
+ * first convolution meeting the block's shortcut gradient g_out .* (out > 0) (resnet.py:106-108) without that product ever
+ * being stored. */
+int vqseg_conv2d_affine_bits_f(const void* x, const void* w_hi, const float* scale, const float* shift, const void* res,
+                               const unsigned char* res_bits, void* y, int n, int h, int w, int cin, int cout, int kh, int kw,
+                               int pad, int ho, int wo, void* stream);
 
 /* `accumulate` (here and in vqseg_bn_backward_f): the parameter gradient is ADDED to gw / dgamma / dbeta (the
  * optimiser's gradient buffer) instead of overwriting it -- autograd's own accumulate kernel is then not needed. */
@@ -309,8 +316,10 @@ int vqseg_bn_backward_f(int bf16, const void* g_out, const void* out, const void
                         float* workspace, float* dgamma, float* dbeta, void* g_y, void* g_res, int* sync, void* stream);
 /* r4, residual layers in bf16 (out = relu(y*scale + shift + res), resnet.py:106-108 / 67-69; c % 8 == 0): the apply pass also
  * writes the ReLU mask as a bit field, bits[i / 8] bit (i % 8) = (out[i] > 0) over the flat [m_rows * c] index (m_rows * c / 8
- * bytes), and the backward reads that instead of `out` (1/16 of its bytes).  g_res (required) = g_out * mask, the residual
- * branch's gradient.  Results are bit-identical to vqseg_bn_apply_f / vqseg_bn_backward_f with `out`. */
+ * bytes), and the backward reads that instead of `out` (1/16 of its bytes).  g_res (nullable) = g_out * mask, the residual
+ * branch's gradient; NULL when its consumer applies the bits to g_out itself (vqseg_conv2d_affine_bits_f: the block's first
+ * convolution adds the masked gradient in its data-gradient epilogue), which saves writing and re-reading that tensor.
+ * Results are bit-identical to vqseg_bn_apply_f / vqseg_bn_backward_f with `out`. */
 int vqseg_bn_apply_bits_f(const void* y, const void* res, const float* scale, const float* shift, int64_t m_rows, int c,
                           void* out, unsigned char* bits, void* stream);
 int vqseg_bn_backward_bits_f(const void* g_out, const unsigned char* bits, const void* y, const float* mean,

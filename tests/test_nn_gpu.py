@@ -1021,3 +1021,45 @@ def test_batchnorm_apply_writes_the_relu_mask_as_a_bit_field():
     assert torch.equal(bits, want)
     assert not bool((out[:, 0] > 0).any())
     assert L.vqseg_bn_apply_bits_f(y.data_ptr(), r.data_ptr(), sc.data_ptr(), sh.data_ptr(), m * 2, c // 2, out.data_ptr(), bits.data_ptr(), s) != 0
+
+
+@pytest.mark.gpu
+def test_bottleneck_shortcut_gradient_masked_by_the_first_convs_epilogue():
+    """r4: in an identity Bottleneck (bf16) the shortcut gradient g_out .* (out > 0) is never stored: bn3's backward hands (g_out,
+    mask bits) over the GradLink and conv1's data-gradient epilogue masks while adding (vqseg_conv2d_affine_bits_f).  Every
+    gradient bit-identical to the stored form (py_gres_bits = 0) and to the form without bit fields (py_bn_bits = 0); the stock-
+    operator fallback (_mask_with_bits) agrees with (out > 0)."""
+    import copy
+    from vq_seg_amd import _hip, nnf
+    from vq_seg_amd.models.encoders.resnet import Bottleneck
+    torch.manual_seed(4)
+    blk0 = Bottleneck(256, 64).to(dev()).train()
+    x = cl(synth.uniform(1, (3, 256, 20, 12), -1, 1)).to(dev())
+    g = cl(synth.uniform(2, (3, 256, 20, 12), -1, 1)).to(dev())
+    nnf.lib()
+    res = {}
+    for key in ((1, 1), (1, 0), (0, 0)):
+        saved = {k: _hip.PY_OPTS.get(k) for k in ("py_bn_bits", "py_gres_bits")}
+        _hip.PY_OPTS["py_bn_bits"], _hip.PY_OPTS["py_gres_bits"] = key
+        try:
+            blk = copy.deepcopy(blk0)
+            xx = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = blk(xx.to(torch.bfloat16) * 1.0)
+            out.backward(g.to(out.dtype))
+            torch.cuda.synchronize()
+            res[key] = [out.detach().float(), xx.grad] + [p.grad for p in blk.parameters()]
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    _hip.PY_OPTS.pop(k, None)
+                else:
+                    _hip.PY_OPTS[k] = v
+    for key in ((1, 1), (1, 0)):
+        for i, (a, b_) in enumerate(zip(res[key], res[0, 0])):
+            assert torch.equal(a, b_), (key, i)
+    o = synth.uniform(3, (5, 7, 9, 16), -1, 1).to(dev()).to(torch.bfloat16)
+    gg = synth.uniform(4, (5, 7, 9, 16), -1, 1).to(dev()).to(torch.bfloat16)
+    keep = (o.reshape(-1, 8) > 0).to(torch.int32)
+    bits = (keep << torch.arange(8, device=dev(), dtype=torch.int32)).sum(1).to(torch.uint8)
+    assert torch.equal(nnf._mask_with_bits(gg, bits), torch.where(o > 0, gg, torch.zeros_like(gg)))

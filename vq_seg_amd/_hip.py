@@ -69,6 +69,7 @@ SYMBOLS = {
     "vqseg_bn_apply_f": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "vqseg_bn_backward_workspace_floats": (c_size_t, [c_int64, c_int]),
     "vqseg_bn_backward_f": (c_int, [c_int] + [c_void_p] * 8 + [c_int64, c_int, c_int, c_int, c_int] + [c_void_p] * 7),
+    "vqseg_conv2d_affine_bits_f": (c_int, [c_void_p] * 7 + [c_int] * 10 + [c_void_p]),
     "vqseg_bn_apply_bits_f": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "vqseg_bn_backward_bits_f": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_int] + [c_void_p] * 7),
     "vqseg_maxpool3x3s2_f": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -37,6 +37,8 @@ struct ConvArgs {
     // its interior is the zero-padded data gradient (the fast patch kernel), see launch_reflect_ring / reflect_ring_fold
     int ring = 0, ring_h = 0, ring_w = 0;
     int ep_res_out = 0;         // 1: ep_res is indexed like the OUTPUT (through omap) instead of by GEMM row -- in-place accumulation
+    const unsigned char* ep_res_bits = nullptr;   // bf16 only, Cout % 8 == 0: bit (i % 8) of byte i / 8 over ep_res's flat index = keep that element (else 0):
+                                                 // the ReLU mask of the block's last BatchNorm applied to the shortcut gradient on the way in
                                 // into a tensor of the output's geometry (launch_dgrad_s2 with `accumulate`)
     // r4: the four parity classes of a stride-2 3x3 data gradient in ONE launch (conv_igemm_glds_kernel<..., CLS = true>): a workgroup
     // picks its class from its tile index and takes that class's taps / padding / extent / weight image; and the rows land

@@ -311,7 +311,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NTT], const Conv
                 const long mo = out_row(p, m);
                 if (ep_res) {                               // residual add (+ ReLU) on the way out
                     const long mr = p.ep_res_out ? mo : m;
-                    const u32x4 rv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.ep_res) + (mr * p.Cout + co) * (PRECISE ? 4 : 2));
+                    u32x4 rv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.ep_res) + (mr * p.Cout + co) * (PRECISE ? 4 : 2));
+                    if (!PRECISE && p.ep_res_bits) {            // masked shortcut gradient: one byte of mask bits per 16-byte chunk
+                        const unsigned mb = p.ep_res_bits[(mr * p.Cout + co) >> 3];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            rv[e] &= ((mb >> (2 * e)) & 1u ? 0x0000FFFFu : 0u) | ((mb >> (2 * e + 1)) & 1u ? 0xFFFF0000u : 0u);
+                    }
                     if (PRECISE) {
                         f32x4 a4 = __builtin_bit_cast(f32x4, v);
                         const f32x4 r4 = __builtin_bit_cast(f32x4, rv);

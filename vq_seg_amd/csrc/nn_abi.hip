@@ -49,7 +49,7 @@ int64_t vqseg_conv_stat_slots(int64_t m_rows, int cout) {
 static int conv2d_impl(const void* x, const void* x2, int c1, const void* w_hi, const void* w_lo, void* y, float* stat_partial,
                        const float* ep_scale, const float* ep_shift, const void* ep_res, int ep_relu,
                        int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int reflect, int up, int ho,
-                       int wo, int precise, void* stream) {
+                       int wo, int precise, void* stream, const unsigned char* ep_res_bits = nullptr) {
     if (!x || !w_hi || !y || (precise && !w_lo)) return bad("conv2d: null pointer");
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || ho <= 0 || wo <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || up <= 0)
         return bad("conv2d: non-positive dimension");
@@ -66,7 +66,7 @@ static int conv2d_impl(const void* x, const void* x2, int c1, const void* w_hi, 
     a.y = y; a.stat_partial = stat_partial;
     a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Ho = ho; a.Wo = wo; a.Cout = cout; a.KH = kh; a.KW = kw;
     a.stride = stride; a.pad = pad; a.reflect = reflect; a.up = up;
-    a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_res = ep_res; a.ep_relu = ep_relu;
+    a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_res = ep_res; a.ep_relu = ep_relu; a.ep_res_bits = ep_res_bits;
     hipError_t e = vqseg::launch_conv(a, precise, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hipfail(e, "conv_igemm_kernel");
 }
@@ -105,6 +105,16 @@ int vqseg_conv2d_affine_f(const void* x, const void* x2, int c1, const void* w_h
     }
     return conv2d_impl(x, x2, c1, w_hi, w_lo, y, nullptr, scale, shift, res, relu, n, h, w, cin, cout, kh, kw, stride, pad, reflect, 1,
                        ho, wo, precise, stream);
+}
+
+int vqseg_conv2d_affine_bits_f(const void* x, const void* w_hi, const float* scale, const float* shift, const void* res,
+                               const unsigned char* res_bits, void* y, int n, int h, int w, int cin, int cout, int kh, int kw, int pad,
+                               int ho, int wo, void* stream) {
+    if (!scale || !shift || !res || !res_bits) return bad("conv2d_affine_bits: null pointer");
+    if (!a16(res)) return bad("conv2d_affine_bits: pointers must be 16-byte aligned");
+    if (cout % 8) return bad("conv2d_affine_bits: Cout must be a multiple of 8");
+    return conv2d_impl(x, nullptr, cin, w_hi, nullptr, y, nullptr, scale, shift, res, 0, n, h, w, cin, cout, kh, kw, 1, pad, 0, 1, ho, wo, 0,
+                       stream, res_bits);
 }
 
 int vqseg_conv_profile_begin(int capacity) {
@@ -227,7 +237,7 @@ int vqseg_bn_backward_f(int bf16, const void* g_out, const void* out, const void
 int vqseg_bn_backward_bits_f(const void* g_out, const unsigned char* bits, const void* y, const float* mean, const float* invstd,
                              const float* gamma, int64_t m_rows, int c, int training, int accumulate, float* workspace, float* dgamma,
                              float* dbeta, void* g_y, void* g_res, int* sync, void* stream) {
-    if (!g_out || !bits || !y || !mean || !invstd || !gamma || !workspace || !dgamma || !dbeta || !g_y || !g_res)
+    if (!g_out || !bits || !y || !mean || !invstd || !gamma || !workspace || !dgamma || !dbeta || !g_y)
         return bad("bn_backward_bits: null pointer");
     if (c <= 0 || c % 8) return bad("bn_backward_bits: the channel count must be a multiple of 8");
     float* partial = workspace;

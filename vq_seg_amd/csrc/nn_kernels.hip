@@ -575,6 +575,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
                 for (int e = 0; e < V; ++e) o[e] = __builtin_fmaf(yy[e], sc[e], sf[e]);
             }
+            if (MASK == 3) {                                // the forward's bit field (see bn_bwd_reduce_kernel)
+                const unsigned mb = reinterpret_cast<const unsigned char*>(out)[i >> 3];
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] = (mb >> (e & 7)) & 1u ? 1.0f : 0.0f;
+            }
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const float gz = (MASK != 0 && !(o[e] > 0.0f)) ? 0.0f : g[e];
@@ -595,6 +600,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             if (MASK == 2) {
 #pragma unroll
                 for (int e = 0; e < V; ++e) o[e] = __builtin_fmaf(yy[e], fsc[c + e], fsh[c + e]);
+            }
+            if (MASK == 3) {
+                const unsigned mb = reinterpret_cast<const unsigned char*>(out)[i >> 3];
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] = (mb >> (e & 7)) & 1u ? 1.0f : 0.0f;
             }
 #pragma unroll
             for (int e = 0; e < V; ++e) {
@@ -1735,9 +1745,10 @@ static hipError_t bn_bwd_t(const void* g_out, const void* out, const void* y, co
     const long nb = (M + rpb - 1) / rpb;
     const BnBwdFin fin{gamma, training, accumulate, dgamma, dbeta, coef, (g_debug_skip_small & 2) ? nullptr : sync};
     // residual layers (MASK == 1 with a g_res output): the reduce pass writes the masked gradient = g_res, the apply pass runs unmasked on it
-    const bool premask = (MASK == 1 && g_res != nullptr && g_bn_bwd_premask) || MASK == 3;
-    if (MASK == 3 && (!g_res || C % VecN<T>::N != 0 || VecN<T>::N != 8)) return hipErrorInvalidValue;
-    constexpr int AMASK = MASK == 3 ? 0 : MASK;             // the bit-field form always runs the apply pass on the masked gradient
+    // bit-field form (MASK == 3): with a g_res output as above; without one (the residual branch's consumer masks g_out with the
+    // bits itself, vqseg_conv2d_affine_bits_f) both passes read (g_out, bits) and no masked gradient is written at all
+    const bool premask = (MASK == 1 || MASK == 3) && g_res != nullptr && (g_bn_bwd_premask || MASK == 3);
+    if (MASK == 3 && (C % VecN<T>::N != 0 || VecN<T>::N != 8)) return hipErrorInvalidValue;
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK>), dim3((unsigned)nb, (unsigned)((C + BNB_CG - 1) / BNB_CG)), dim3(256), 0, st_,
                        (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, fsc, fsh, M, C, relu, partial, rpb, fin,
                        premask ? (T*)g_res : (T*)nullptr);
@@ -1748,7 +1759,7 @@ static hipError_t bn_bwd_t(const void* g_out, const void* out, const void* y, co
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0>), dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_,
                            (const T*)g_res, (const T*)nullptr, (const T*)y, mean, invstd, coef, fsc, fsh, M, C, 0, (T*)g_y, (T*)nullptr);
     else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, AMASK>), dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK>), dim3(grid_for(M * C / (C % VecN<T>::N ? 1 : VecN<T>::N))), dim3(256), 0, st_,
                        (const T*)g_out, (const T*)out, (const T*)y, mean, invstd, coef, fsc, fsh, M, C, relu, (T*)g_y, (T*)g_res);
     return hipGetLastError();
 }

@@ -281,12 +281,22 @@ class GradLink:
     Projection shortcut: the shortcut's convolution sends the gradient of ITS input (`link_x`) the same way.  Its backward
     has no dependency on the first conv's, so the order is the autograd engine's choice: a producer that arrives after the
     consumer has run (`closed`) simply returns its gradient to autograd."""
-    __slots__ = ("g", "closed", "leftover", "__weakref__")
+    __slots__ = ("g", "closed", "leftover", "bits", "takes_bits", "__weakref__")
 
     def __init__(self):
         self.g = None
         self.closed = False
         self.leftover = None
+        self.bits = None            # r4: `g` is the block output's UNMASKED gradient, `bits` the ReLU mask of the block's last BatchNorm
+        self.takes_bits = False     # set by the first conv's forward: its data-gradient epilogue can apply `bits` itself
+
+
+def _mask_with_bits(g, bits):
+    """g .* bits (bit i % 8 of byte i / 8 over the flat index) with stock operators -- the fallback of a bit-field shortcut gradient
+    whose consumer turned out not to fuse it"""
+    sh = torch.arange(8, device=g.device, dtype=torch.uint8)
+    keep = torch.bitwise_and(torch.bitwise_right_shift(bits.view(-1, 1), sh), 1).view(g.shape).to(torch.bool)
+    return torch.where(keep, g, torch.zeros((), dtype=g.dtype, device=g.device))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -637,6 +647,8 @@ class _ConvBNAct(torch.autograd.Function):
                                           _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout), m, cout, int(relu),
                                           _T(out, "BN output", bf=bf, numel=m * cout), _stream()), "vqseg_bn_apply_f")
         ctx.mask_bits = bits is not None
+        if link_in is not None:                                             # see backward: the zero-padded stride-1 data gradient + shortcut
+            link_in.takes_bits = bool(bf and x2r is None and stride == 1 and not reflect and cin % 8 == 0 and py_opt("py_gres_bits", 1))
         ctx.save_for_backward(xr, x2r, y, bits if bits is not None else out, coef, weight, gamma)
         ctx.stem_x = stem_x if stem_img else None                           # the image tensor OBJECT the patch matrix is shared under
         ctx.params = (weight, gamma, beta)                                  # the Parameter objects (see grad sinks)
@@ -665,7 +677,10 @@ class _ConvBNAct(torch.autograd.Function):
         if g.dtype != y.dtype:
             g = g.to(y.dtype)
         g_y = torch.empty_like(y)
-        g_res = torch.empty_like(y) if has_res else None
+        link_in, link_out, link_x = ctx.links
+        # r4: the residual branch's gradient g_out .* mask is not stored when the block's first conv will apply the mask bits itself
+        bits_to_link = bool(has_res and ctx.mask_bits and link_out is not None and link_out.takes_bits and not link_out.closed)
+        g_res = torch.empty_like(y) if (has_res and not bits_to_link) else None
         ws = torch.empty(L.vqseg_bn_backward_workspace_floats(m, cout), dtype=torch.float32, device=dev)
         p_w, p_g, p_b = ctx.params
         sink_bn = _sink_ready(p_g) and _sink_ready(p_b) and ctx.needs_input_grad[4] and ctx.needs_input_grad[5]
@@ -692,9 +707,9 @@ class _ConvBNAct(torch.autograd.Function):
                                            _T(_bn_sync(ctx.bn, True), "bn sync", dtype=torch.int32), _stream()), "vqseg_bn_backward_f", ctx.bn)
         if sink_bn:
             _sink_done(p_g), _sink_done(p_b)
-        link_in, link_out, link_x = ctx.links
         if link_out is not None and has_res:
-            link_out.g = g_res                                              # picked up by the block's first conv (GradLink)
+            link_out.g = g if bits_to_link else g_res                       # picked up by the block's first conv (GradLink)
+            link_out.bits = out if bits_to_link else None
         # ---- weight gradient.  With a grad sink (the result is ADDED into the trainer's bucket, nothing returns to autograd) and a
         # registered side stream, the weight-gradient kernel and its slab sum leave the network's stream: nothing downstream in
         # backward depends on them, and as filler work they cover the latency-bound links of the main chain (BatchNorm statistics
@@ -737,9 +752,12 @@ class _ConvBNAct(torch.autograd.Function):
             dpad = (kh - 1) if reflect else (kh - 1 - pad)
 
             extra = link_in.g if link_in is not None else None          # residual-branch gradient of the same block input
+            ebits = link_in.bits if link_in is not None else None
             if link_in is not None:
-                link_in.g = None
+                link_in.g = link_in.bits = None
                 link_in.closed = True
+            if ebits is not None and not (not reflect and stride == 1 and x2r is None and bf and extra.shape == (n, hp, wp, c1)):
+                extra, ebits = _mask_with_bits(extra, ebits), None       # not the fusing path below after all
 
             def dgrad(c_lo, c_cnt):
                 nonlocal extra
@@ -776,12 +794,21 @@ class _ConvBNAct(torch.autograd.Function):
                     gp = torch.empty((n, hp, wp, c_cnt), dtype=g_y.dtype, device=dev)
                     with _hip.on_device(dev):
                         tneed = c_cnt * kh * kw * ((cout + 31) // 32 * 32)
-                        _check(L.vqseg_conv2d_affine_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), None, cout,
-                                                       _w16(t_hi, "transposed image", tneed), _w16(t_lo, "transposed image (lo)", tneed),
-                                                       _f32(one, "unit scale", c_cnt), _f32(zero, "zero shift", c_cnt),
-                                                       _T(extra, "shortcut gradient", bf=bf, numel=n * hp * wp * c_cnt), 0,
-                                                       _T(gp, "input gradient", bf=bf, numel=n * hp * wp * c_cnt), n, ho, wo, cout, c_cnt,
-                                                       kh, kw, 1, dpad, 0, hp, wp, int(precise), _stream()), "vqseg_conv2d_affine_f")
+                        if ebits is not None:
+                            _check(L.vqseg_conv2d_affine_bits_f(
+                                _T(g_y, "conv output gradient", bf=1, numel=m * cout), _w16(t_hi, "transposed image", tneed),
+                                _f32(one, "unit scale", c_cnt), _f32(zero, "zero shift", c_cnt),
+                                _T(extra, "block output gradient", bf=1, numel=n * hp * wp * c_cnt),
+                                _T(ebits, "ReLU mask bits", dtype=torch.uint8, numel=n * hp * wp * c_cnt // 8),
+                                _T(gp, "input gradient", bf=1, numel=n * hp * wp * c_cnt), n, ho, wo, cout, c_cnt, kh, kw, dpad, hp, wp,
+                                _stream()), "vqseg_conv2d_affine_bits_f")
+                        else:
+                            _check(L.vqseg_conv2d_affine_f(_T(g_y, "conv output gradient", bf=bf, numel=m * cout), None, cout,
+                                                         _w16(t_hi, "transposed image", tneed), _w16(t_lo, "transposed image (lo)", tneed),
+                                                         _f32(one, "unit scale", c_cnt), _f32(zero, "zero shift", c_cnt),
+                                                         _T(extra, "shortcut gradient", bf=bf, numel=n * hp * wp * c_cnt), 0,
+                                                         _T(gp, "input gradient", bf=bf, numel=n * hp * wp * c_cnt), n, ho, wo, cout, c_cnt,
+                                                         kh, kw, 1, dpad, 0, hp, wp, int(precise), _stream()), "vqseg_conv2d_affine_f")
                     extra = None
                     return gp
                 if (stride == 2 and x2r is None and kh == 3 and kw == 3 and pad == 1 and bf and h == 2 * ho and w == 2 * wo and h >= 4 and w >= 4
