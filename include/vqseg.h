@@ -78,6 +78,8 @@ const char* vqseg_kernel_name(const char* entry_point);
  *   "stem_fused"                    1 (default): vqseg_stem7_conv_f available (r4); 0: it returns VQSEG_EINVAL (patch-matrix path)
  *   "conv_wgrad_xcd"                1 (default): a pixel slab's (ci, co) tiles of the LDS-DMA weight-gradient kernels on one XCD (r4); 0: 3-D grid
  *   "im2col_strip"                  1 (default): the stem's patch matrix from LDS-staged strips (r4, bit-identical); 0: the gather kernel
+ *   "bn_bwd_premask"                1 (default): vqseg_bn_backward_f with `out` and a g_res output (a residual layer): the reduce pass writes
+ *                                   g_res, the apply pass reads it instead of (g_out, out) (r4, bit-identical); 0: r3's two passes over both
  * The environment variable VQSEG_OPTS="key=value,..." applies options when the Python binding loads the library.
  * Returns the previous value, or VQSEG_EINVAL for an unknown key / negative value.  Not thread safe. */
 int vqseg_set_option(const char* key, int value);
