@@ -116,20 +116,35 @@ def bn_roofline(device):
         from vq_seg_amd import nnf as _nnf
         sync = torch.zeros(L.vqseg_bn_sync_ints(C), dtype=torch.int32, device=device) if _nnf.py_opt("py_bn_fused", 0) else None
         dg, gy = torch.empty(2, C, device=device), torch.empty_like(ys[0])
-        gres = torch.empty_like(ys[0]) if res else None
+        # residual layers as the step runs an identity Bottleneck's bn3: the ReLU mask travels as a bit field, the masked shortcut
+        # gradient is not stored (vqseg_bn_apply_bits_f / vqseg_bn_backward_bits_f with g_res = NULL)
+        bits = [torch.empty(M * C // 8, dtype=torch.uint8, device=device) for _ in range(sets)] if res else None
 
         def apply(i):
             k = i % sets
-            rc = L.vqseg_bn_apply_f(1, ys[k].data_ptr(), rs[k].data_ptr() if res else None, sc.data_ptr(), sh.data_ptr(), M, C, 1, outs[k].data_ptr(), st)
+            if res:
+                rc = L.vqseg_bn_apply_bits_f(ys[k].data_ptr(), rs[k].data_ptr(), sc.data_ptr(), sh.data_ptr(), M, C, outs[k].data_ptr(),
+                                             bits[k].data_ptr(), st)
+            else:
+                rc = L.vqseg_bn_apply_f(1, ys[k].data_ptr(), None, sc.data_ptr(), sh.data_ptr(), M, C, 1, outs[k].data_ptr(), st)
             assert rc == 0, L.vqseg_last_error()
 
         def bwd(i):
             k = i % sets
-            rc = L.vqseg_bn_backward_f(1, gs[k].data_ptr(), outs[k].data_ptr() if res else None, ys[k].data_ptr(), mean.data_ptr(), inv.data_ptr(),
-                                       gamma.data_ptr(), sc.data_ptr(), sh.data_ptr(), M, C, 1, 1, 0, ws.data_ptr(), dg[0].data_ptr(), dg[1].data_ptr(),
-                                       gy.data_ptr(), gres.data_ptr() if res else None, sync.data_ptr() if sync is not None else None, st)
+            if res:
+                rc = L.vqseg_bn_backward_bits_f(gs[k].data_ptr(), bits[k].data_ptr(), ys[k].data_ptr(), mean.data_ptr(), inv.data_ptr(),
+                                                gamma.data_ptr(), M, C, 1, 0, ws.data_ptr(), dg[0].data_ptr(), dg[1].data_ptr(), gy.data_ptr(), None,
+                                                sync.data_ptr() if sync is not None else None, st)
+            else:
+                rc = L.vqseg_bn_backward_f(1, gs[k].data_ptr(), None, ys[k].data_ptr(), mean.data_ptr(), inv.data_ptr(),
+                                           gamma.data_ptr(), sc.data_ptr(), sh.data_ptr(), M, C, 1, 1, 0, ws.data_ptr(), dg[0].data_ptr(), dg[1].data_ptr(),
+                                           gy.data_ptr(), None, sync.data_ptr() if sync is not None else None, st)
             assert rc == 0, L.vqseg_last_error()
-        for name, fn, nbytes in (("apply", apply, M * C * 2 * (3 if res else 2)), ("backward", bwd, M * C * 2 * (8 if res else 5))):
+        if res:
+            for k in range(sets):                                           # the backward legs read bits the apply legs wrote
+                apply(k)
+        for name, fn, nbytes in (("apply", apply, M * C * 2 * (3 if res else 2) + (M * C // 8 if res else 0)),
+                                 ("backward", bwd, M * C * 2 * 5 + (2 * (M * C // 8) if res else 0))):
             fn(0)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -142,13 +157,14 @@ def bn_roofline(device):
             tot_bytes += nbytes
             tot_us += us
             per[f"{name} M{M}xC{C}{'+res' if res else ''}"] = {"us": round(us, 1), "GBps": round(nbytes / us / 1e3, 1)}
-        del ys, gs, rs, outs, gy, gres
+        del ys, gs, rs, outs, gy, bits
     achieved = tot_bytes / tot_us / 1e3
     return {"kernel": "bn_apply_kernel / bn_bwd_reduce_kernel + bn_bwd_apply_kernel (bf16)", "bound": "hbm", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "per_shape": per,
-            "note": "algorithmic bytes (apply: y in [+ residual] + out; backward: (g, y) read by the reduce, (g, y) read + g_y [+ g_res] written "
-                    "by the apply) / in-stream event time, kernels alone on the chip, HBM-cold operands; the guide's achievable streaming rate is "
-                    "~6.3 TB/s of the 8 TB/s peak"}
+            "note": "algorithmic bytes (apply: y in [+ residual] + out [+ the ReLU mask bits of a residual layer, 1 bit per element]; "
+                    "backward: (g, y [, bits]) read by the reduce, (g, y [, bits]) read + g_y written by the apply -- r4: a residual layer's "
+                    "masked shortcut gradient is no longer stored, 5 1/8 tensor passes instead of r3's 8) / in-stream event time, kernels "
+                    "alone on the chip, HBM-cold operands; the guide's achievable streaming rate is ~6.3 TB/s of the 8 TB/s peak"}
 
 
 def pmc_traffic(shapes):
