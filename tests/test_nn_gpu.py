@@ -1063,3 +1063,37 @@ def test_bottleneck_shortcut_gradient_masked_by_the_first_convs_epilogue():
     keep = (o.reshape(-1, 8) > 0).to(torch.int32)
     bits = (keep << torch.arange(8, device=dev(), dtype=torch.int32)).sum(1).to(torch.uint8)
     assert torch.equal(nnf._mask_with_bits(gg, bits), torch.where(o > 0, gg, torch.zeros_like(gg)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,cin,cout,hw", [(1, 64, 256, (20, 12)), (3, 64, 64, (18, 22)), (3, 128, 256, (9, 16)), (1, 256, 72, (7, 5))])
+def test_conv_epilogue_masks_the_addend_with_a_bit_field(k, cin, cout, hw):
+    """vqseg_conv2d_affine_bits_f (y = conv + res .* bits) against vqseg_conv2d_affine_f on the pre-masked addend: bit-identical,
+    on the 1x1 kernels and the 3x3 patch kernel (one shared epilogue), incl. a channel count that is a multiple of 8 only and pixel
+    counts that end inside a tile; rejects Cout % 8 != 0 and null bit fields."""
+    from vq_seg_amd import nnf
+    L = nnf.lib()
+    h, w = hw
+    n = 3
+    conv = nn.Conv2d(cin, cout, k, 1, k // 2, bias=False).to(dev())
+    w_hi, _ = nnf.packed_weights(conv.weight, False, False)
+    x = synth.uniform(1, (n, h, w, cin), -1, 1).to(dev()).to(torch.bfloat16)
+    res = synth.uniform(2, (n, h, w, cout), -1, 1).to(dev()).to(torch.bfloat16)
+    o = synth.uniform(3, (n, h, w, cout), -1, 1).to(dev())
+    keep = (o.reshape(-1, 8) > 0).to(torch.int32)
+    bits = (keep << torch.arange(8, device=dev(), dtype=torch.int32)).sum(1).to(torch.uint8)
+    masked = torch.where(o > 0, res, torch.zeros_like(res))
+    one, zero = torch.ones(cout, device=dev()), torch.zeros(cout, device=dev())
+    y0, y1 = torch.empty_like(res), torch.empty_like(res)
+    s = torch.cuda.current_stream().cuda_stream
+    assert L.vqseg_conv2d_affine_f(x.data_ptr(), None, cin, w_hi.data_ptr(), None, one.data_ptr(), zero.data_ptr(), masked.data_ptr(), 0,
+                                   y0.data_ptr(), n, h, w, cin, cout, k, k, 1, k // 2, 0, h, w, 0, s) == 0, L.vqseg_last_error()
+    assert L.vqseg_conv2d_affine_bits_f(x.data_ptr(), w_hi.data_ptr(), one.data_ptr(), zero.data_ptr(), res.data_ptr(), bits.data_ptr(),
+                                        y1.data_ptr(), n, h, w, cin, cout, k, k, k // 2, h, w, s) == 0, L.vqseg_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    assert bool((y0.float() != 0).any())
+    assert L.vqseg_conv2d_affine_bits_f(x.data_ptr(), w_hi.data_ptr(), one.data_ptr(), zero.data_ptr(), res.data_ptr(), None,
+                                        y1.data_ptr(), n, h, w, cin, cout, k, k, k // 2, h, w, s) != 0
+    assert L.vqseg_conv2d_affine_bits_f(x.data_ptr(), w_hi.data_ptr(), one.data_ptr(), zero.data_ptr(), res.data_ptr(), bits.data_ptr(),
+                                        y1.data_ptr(), n, h, w, cin, cout - 4, k, k, k // 2, h, w, s) != 0
