@@ -80,6 +80,8 @@ const char* vqseg_kernel_name(const char* entry_point);
  *   "im2col_strip"                  1 (default): the stem's patch matrix from LDS-staged strips (r4, bit-identical); 0: the gather kernel
  *   "bn_bwd_premask"                1 (default): vqseg_bn_backward_f with `out` and a g_res output (a residual layer): the reduce pass writes
  *                                   g_res, the apply pass reads it instead of (g_out, out) (r4, bit-identical); 0: r3's two passes over both
+ *   "bilinear_up2"                  1 (default): exact-2x resizes on their own kernels (bit-identical to the generic ones), the backward with four
+ *                                   input rows per thread (r4); 2: one row per thread (r3); 0: the generic kernels
  * The environment variable VQSEG_OPTS="key=value,..." applies options when the Python binding loads the library.
  * Returns the previous value, or VQSEG_EINVAL for an unknown key / negative value.  Not thread safe. */
 int vqseg_set_option(const char* key, int value);

@@ -806,7 +806,7 @@ def test_one_launch_batchnorm_forms_match_the_two_launch_forms(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 8, 1, 4), (2, 128, 32, 8), (1, 1024, 2, 2)])
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 8, 1, 4), (2, 128, 32, 8), (1, 1024, 2, 2), (1, 16, 4, 8), (2, 32, 8, 2)])
 def test_exact_2x_bilinear_kernels_are_bit_identical_to_the_generic_ones(shape, dtype):
     """The decoder's resize to a skip of twice the size (align_corners = False) takes bilinear_up2_{fwd,bwd}_kernel on power-of-two
     extents: same expressions, values and order as the generic kernels (`vqseg_set_option("bilinear_up2", 0)`), so forward and
@@ -827,9 +827,12 @@ def test_exact_2x_bilinear_kernels_are_bit_identical_to_the_generic_ones(shape, 
     prev = L.vqseg_set_option(b"bilinear_up2", 0)
     try:
         generic = run()
+        L.vqseg_set_option(b"bilinear_up2", 2)                 # r3's backward: one input row per thread (r4 default: four, extents >= 4)
+        one_row = run()
     finally:
         L.vqseg_set_option(b"bilinear_up2", prev)
     assert torch.equal(fast[0], generic[0]) and torch.equal(fast[1], generic[1])
+    assert torch.equal(fast[0], one_row[0]) and torch.equal(fast[1], one_row[1])
     xr = x.float().cpu().requires_grad_(True)
     yr = F.interpolate(xr, size=(2 * h, 2 * w), mode="bilinear", align_corners=False)
     yr.backward(g.float().cpu())

@@ -1010,6 +1010,54 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd_kernel(const T* __restri
     }
 }
 
+// r4: R input rows per thread.  The one-row form reads four gradient rows for two fresh ones and leaves the re-use of the shared pair to
+// the L2 (measured: 1.7x the tensor fetched past the L2s); here a thread walks 2R + 2 rows for 2R fresh ones (R = 4: 1.25x at worst).
+// Every output's own fmaf chain runs in the same order (row, then column, ascending) as above: bit-identical.
+template <typename T, int VC, int R>
+__global__ __launch_bounds__(256) void bilinear_up2_bwd_rows_kernel(const T* __restrict__ g, int N, int H, int W, int C, int lcv, int lw_, int lhr,
+                                                                    T* __restrict__ gx) {
+    constexpr int V = VecN<T>::N;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long total = ((long)N << (lcv + lw_ + lhr));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = ((int)i & ((1 << lcv) - 1)) * VC;
+        const int iw = (int)(i >> lcv) & (W - 1), pr = (int)(i >> (lcv + lw_)) & ((H / R) - 1), n = (int)(i >> (lcv + lw_ + lhr));
+        float acc[R][V];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < VC; ++e) acc[r][e] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2 * R + 2; ++t) {
+            const int oh = 2 * R * pr - 1 + t;
+            if (oh < 0 || oh >= Ho) continue;
+#pragma unroll
+            for (int bq = 0; bq < 4; ++bq) {
+                const int ow = 2 * iw - 1 + bq;
+                if (ow < 0 || ow >= Wo) continue;
+                float ww = (bq == 0 || bq == 3) ? 0.25f : 0.75f;
+                if (bq == 1 && iw == 0) ww = 1.0f;
+                if (bq == 2 && iw == W - 1) ww = 0.75f + 0.25f;
+                float gv[V];
+                ldc<T, VC>(g, (((long)n * Ho + oh) * Wo + ow) * C + c, gv);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int a = t - 2 * r;                 // this gradient row's position in output row r's window
+                    if (a < 0 || a > 3) continue;
+                    const int ih = R * pr + r;
+                    float wh = (a == 0 || a == 3) ? 0.25f : 0.75f;
+                    if (a == 1 && ih == 0) wh = 1.0f;
+                    if (a == 2 && ih == H - 1) wh = 0.75f + 0.25f;
+#pragma unroll
+                    for (int e = 0; e < VC; ++e) acc[r][e] = __builtin_fmaf(wh * ww, gv[e], acc[r][e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) stc<T, VC>(gx, (((long)n * H + R * pr + r) * W + iw) * C + c, acc[r]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 1x1 segmentation head (Cin <= 64 -> Cout <= 4, no bias): forward, data gradient, weight gradient
 // ---------------------------------------------------------------------------------------------
@@ -1819,9 +1867,9 @@ static int g_bilinear_up2 = 1;                              // exact-2x fast ker
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-int bilinear_up2_option(int value) {
+int bilinear_up2_option(int value) {                        // 2: the fast kernels with one input row per thread in the backward (r3)
     const int prev = g_bilinear_up2;
-    g_bilinear_up2 = value ? 1 : 0;
+    g_bilinear_up2 = value > 2 ? 1 : value;
     return prev;
 }
 
@@ -1834,6 +1882,9 @@ static void bilinear_t(int backward, const void* src, int N, int H, int W, int C
         if (!backward)
             hipLaunchKernelGGL((bilinear_up2_fwd_kernel<T, VC>), dim3(grid_for((long)N * Ho * Wo * cv)), dim3(256), 0, st_, (const T*)src, N, H,
                                W, C, ilog2(cv), ilog2(Wo), ilog2(Ho), (T*)dst);
+        else if (g_bilinear_up2 == 1 && H >= 4)
+            hipLaunchKernelGGL((bilinear_up2_bwd_rows_kernel<T, VC, 4>), dim3(grid_for((long)N * (H / 4) * W * cv)), dim3(256), 0, st_,
+                               (const T*)src, N, H, W, C, ilog2(cv), ilog2(W), ilog2(H / 4), (T*)dst);
         else
             hipLaunchKernelGGL((bilinear_up2_bwd_kernel<T, VC>), dim3(grid_for((long)N * H * W * cv)), dim3(256), 0, st_, (const T*)src, N, H, W,
                                C, ilog2(cv), ilog2(W), ilog2(H), (T*)dst);
