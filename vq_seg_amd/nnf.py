@@ -635,7 +635,8 @@ class _ConvBNAct(torch.autograd.Function):
             out = torch.empty_like(y)
             # residual layers in bf16: the ReLU mask goes to the backward as a bit field (1/16 of `out`'s bytes), see vqseg.h
             bits = (torch.empty(m * cout // 8, dtype=torch.uint8, device=dev)
-                    if (rr is not None and relu and bf and cout % 8 == 0 and training and py_opt("py_bn_bits", 1)) else None)
+                    if (rr is not None and relu and bf and cout % 8 == 0 and training and any(ctx.needs_input_grad)
+                        and py_opt("py_bn_bits", 1)) else None)
             if bits is not None:
                 _check(L.vqseg_bn_apply_bits_f(_T(y, "conv output", bf=1, numel=m * cout), _T(rr, "residual", bf=1, numel=m * cout),
                                                _f32(coef[0], "scale", cout), _f32(coef[1], "shift", cout), m, cout,
