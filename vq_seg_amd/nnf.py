@@ -1019,10 +1019,11 @@ def stem_conv_bn_act(x, conv, bn):
     kp = (kh * kw * cin + 31) // 32 * 32
     dt = act_dtype()
     # r4: the convolution straight from the image (vqseg_stem7_conv_f) where its tiling fits: 128 output pixels of one row per workgroup.
-    # OPT-IN (VQSEG_OPTS=py_stem_fused=1): it removes 7.5 GB of patch-matrix traffic per step and its kernel takes 197 us against 318 us,
-    # but the step does not move (152.7 vs 152.5 ms, same-box A/B: LEDGER r4) -- the default stays the path the parity fixtures cover
+    # It removes 7.5 GB of patch-matrix traffic per step and its kernel takes 197 us against 318 us.  Measured +-0 in the step when it was
+    # built (152.7 vs 152.5 ms) and -0.9 ms on the final r4 build (145.3 vs 146.1 ms, LEDGER r4): default from then on; the patch-matrix
+    # path (VQSEG_OPTS=py_stem_fused=0) stays for output widths that are not multiples of 128 and for the weight gradient
     fused_ok = ((kh, kw, cin) == (7, 7, 3) and s == 2 and p == 3 and wo % 128 == 0 and h >= 4 and w >= 4 and conv.weight.shape[0] == 64
-                and py_opt("py_stem_fused", 0) == 1)
+                and py_opt("py_stem_fused", 1) == 1)
     if _S3_SCOPE and dt == torch.float32 and not bn.training and not torch.is_grad_enabled() and (kh, kw, cin) == (7, 7, 3):
         # fp32-precision eval forward: split-3 patch rows (64-column multiple: the LDS-DMA kernels), then everything stays split-3
         kp3 = (kh * kw * cin + 63) // 64 * 64
