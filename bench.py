@@ -177,11 +177,15 @@ def pmc_traffic(shapes):
     if not files:
         return {}, None
     table = json.load(open(files[-1]))["shapes"]
-    for t in (8, 4, 2, 1):                                             # vq_group_tiles (csrc/vq_kernels.hip)
-        if any(((k + 31) // 32) % t for _n, _c, k in shapes):
+    def plain_wgs(t):                                                  # vq_group_wgs (csrc/vq_kernels.hip): unpadded row blocks
+        return sum((n + 127) // 128 * (((k + 31) // 32) // t) for n, _c, k in shapes)
+    divides = lambda t: not any(((k + 31) // 32) % t for _n, _c, k in shapes)       # noqa: E731
+    fine = next((t for t in (8, 4) if divides(t) and plain_wgs(t) >= 4096), None)   # vq_group_tiles: r4's finer split first
+    for t in ((fine,) if fine else ()) + (8, 4, 2, 1):
+        if not divides(t):
             continue
-        wgs = sum(((n + 127) // 128 + 7) // 8 * 8 * (((k + 31) // 32) // t) for n, _c, k in shapes)
-        if wgs >= 512 or t == 1:
+        wgs = sum(((n + 127) // 128 + 7) // 8 * 8 * (((k + 31) // 32) // t) for n, _c, k in shapes)   # the launched grid (XCD-padded)
+        if t == fine or plain_wgs(t) >= 512 or t == 1:
             out = {}
             for rows in ("bf16", "f32"):
                 e = table.get(f"WG{wgs}_T{t}_{rows}")

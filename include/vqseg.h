@@ -82,6 +82,8 @@ const char* vqseg_kernel_name(const char* entry_point);
  *                                   g_res, the apply pass reads it instead of (g_out, out) (r4, bit-identical); 0: r3's two passes over both
  *   "bilinear_up2"                  1 (default): exact-2x resizes on their own kernels (bit-identical to the generic ones), the backward with four
  *                                   input rows per thread (r4); 2: one row per thread (r3); 0: the generic kernels
+ *   "vq_fine_split"                 1 (default, r4): the distance kernel takes 4 code tiles per wave instead of 8 when that brings a launch to
+ *                                   >= 4096 workgroups (a shorter last round: K = 512 on 172 k rows 0.76 -> 0.81 of the fp32 MFMA peak); 0: r3's choice
  * The environment variable VQSEG_OPTS="key=value,..." applies options when the Python binding loads the library.
  * Returns the previous value, or VQSEG_EINVAL for an unknown key / negative value.  Not thread safe. */
 int vqseg_set_option(const char* key, int value);

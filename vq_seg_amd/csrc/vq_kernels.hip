@@ -1296,6 +1296,7 @@ PreparedLayout prepared_layout(int C, int K) {
 size_t prepared_bytes(int C, int K) { return prepared_layout(C, K).bytes; }
 
 static int g_vq_max_tiles = 8;                              // cap on T (option "vq_max_tiles_per_wave": 8, 4, 2 or 1)
+static int g_vq_fine_split = 1;                             // option "vq_fine_split": 0 = r3's choice of T (see vq_group_tiles)
 static int g_vq_bf16_filter = 1;                            // bf16 rows: candidate filter + exact re-score (0: the exact kernel on every row)
 static int g_vq_filter_force_all = 0;                       // tests: 1 = every row is re-scored by the exact kernel (the filter decides nothing)
 static int g_vq_filter_launches = 0;                        // launches that took the filter path (tests read and reset it)
@@ -1303,6 +1304,11 @@ int vq_set_option(const char* key, int value) {
     if (key && !strcmp(key, "vq_max_tiles_per_wave") && (value == 8 || value == 4 || value == 2 || value == 1)) {
         const int prev = g_vq_max_tiles;
         g_vq_max_tiles = value;
+        return prev;
+    }
+    if (key && !strcmp(key, "vq_fine_split")) {
+        const int prev = g_vq_fine_split;
+        g_vq_fine_split = value ? 1 : 0;
         return prev;
     }
     if (key && !strcmp(key, "vq_bf16_filter")) {
@@ -1355,18 +1361,9 @@ VqPlan vq_plan(int64_t N, int C, int K) {
     p.bytes = (off + 255) & ~(size_t)255;
     long blocks = (N + GATHER_ROWS_PER_BLOCK - 1) / GATHER_ROWS_PER_BLOCK;
     p.gather_blocks = (int)(blocks < GATHER_BLOCKS_MAX ? (blocks > 0 ? blocks : 1) : GATHER_BLOCKS_MAX);
-    // tiles per wave: the largest T in {8,4,2,1} dividing Kp/32 that still yields >= 2 workgroups per CU;
-    // if none does, the smallest (most workgroups).
-    const long row_blocks = (N + ROWS_PER_WG - 1) / ROWS_PER_WG;
-    const int tiles = p.Kp / 32;
-    p.T = 1;
-    for (int t = g_vq_max_tiles; t >= 1; t >>= 1) {
-        if (tiles % t) continue;
-        if (row_blocks * (tiles / t) >= 512 || t == 1) {
-            p.T = t;
-            break;
-        }
-    }
+    // tiles per wave: see vq_group_tiles
+    const int k1 = K;
+    p.T = vq_group_tiles(1, &N, &k1);
     return p;
 }
 
@@ -1454,9 +1451,25 @@ static unsigned assign_workgroups(int64_t N, int Kp, int T) {
     return (unsigned)((row_tiles + 7) / 8 * 8 * (Kp / (32 * T)));               // see the id mapping in the kernel
 }
 
-// tiles per wave for a group of levels: the largest T in {8,4,2,1} that divides every level's tile count and still yields
-// >= 2 workgroups per CU over the whole launch; if none does, the smallest.
+// tiles per wave for a group of levels.  r4: first the largest T in {8,4} that divides every level's tile count and gives the launch
+// >= VQ_FINE_WGS workgroups -- the workgroups of a launch differ 4x in length between the levels, and with fewer, longer ones the
+// last round leaves the chip half empty (K = 512 on 172 k rows: T = 8 -> 2688 workgroups, 0.76 of the fp32 MFMA peak; T = 4 -> 5376,
+// 0.81; K = 256 / K = 1024 / twice the rows: T = 8 stays best, T = 2 loses 9 % of the per-wave rate: LEDGER r4).  Else, as before, the
+// largest T in {8,4,2,1} that still yields >= 2 workgroups per CU over the whole launch; if none does, the smallest.
+constexpr long VQ_FINE_WGS = 4096;
+static long vq_group_wgs(int n, const int64_t* N, const int* K, int t) {     // workgroups of the launch at T = t; -1: t does not divide
+    long wgs = 0;
+    for (int i = 0; i < n; ++i) {
+        const int tiles = round_up(K[i], 32) / 32;
+        if (tiles % t) return -1;
+        wgs += ((N[i] + ROWS_PER_WG - 1) / ROWS_PER_WG) * (tiles / t);
+    }
+    return wgs;
+}
 int vq_group_tiles(int n, const int64_t* N, const int* K) {
+    if (g_vq_fine_split)
+        for (int t = g_vq_max_tiles; t >= 4; t >>= 1)
+            if (vq_group_wgs(n, N, K, t) >= VQ_FINE_WGS) return t;
     for (int t = g_vq_max_tiles; t >= 1; t >>= 1) {
         bool ok = true;
         long wgs = 0;
