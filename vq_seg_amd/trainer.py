@@ -282,13 +282,14 @@ class CPSTrainer:
         # model's small, latency-bound kernels (statistics merges, reductions, packs) hide under the other's large ones
         import os as _os
         self._two_streams = device.type == "cuda" and cfg.two_streams and _os.environ.get("VQSEG_TWO_STREAMS", "1") == "1"
-        self._streams = [torch.cuda.Stream(device) for _ in self.models] if self._two_streams else []
+        prio = nnf.py_opt("py_stream_prio", 0) if device.type == "cuda" else 0      # A/B: 1 = the networks' streams above the weight-gradient side streams
+        self._streams = [torch.cuda.Stream(device, priority=-1 if prio == 1 else 0) for _ in self.models] if self._two_streams else []
         # weight-gradient kernels (+ their slab sums) run on a side stream per network (nnf.WGRAD_SIDE_STREAMS): nothing later in
         # backward depends on them, so they fill the chip under the latency-bound links of the main chain.  They add into the
         # buckets, so the side streams are producer streams of the buckets and are joined before the optimiser step.
         self._wgrad_streams = []
         if self._two_streams and cfg.wgrad_side_stream and nnf.py_opt("py_wgrad_side", 1):
-            self._wgrad_streams = [torch.cuda.Stream(device) for _ in self.models]
+            self._wgrad_streams = [torch.cuda.Stream(device, priority=-1 if prio == 2 else 0) for _ in self.models]
         for b, s_ in zip(self.buckets, self._streams):
             b.producer_streams = [s_]
         for b, s_, w_ in zip(self.buckets, self._streams, self._wgrad_streams):
