@@ -84,6 +84,7 @@ const char* vqseg_kernel_name(const char* entry_point);
  *                                   input rows per thread (r4); 2: one row per thread (r3); 0: the generic kernels
  *   "vq_fine_split"                 1 (default, r4): the distance kernel takes 4 code tiles per wave instead of 8 when that brings a launch to
  *                                   >= 4096 workgroups (a shorter last round: K = 512 on 172 k rows 0.76 -> 0.81 of the fp32 MFMA peak); 0: r3's choice
+ *   "nn_grid_cap"                   8192 (default): most workgroups a grid-stride elementwise kernel (BatchNorm passes, resizes, pools) is launched with
  * The environment variable VQSEG_OPTS="key=value,..." applies options when the Python binding loads the library.
  * Returns the previous value, or VQSEG_EINVAL for an unknown key / negative value.  Not thread safe. */
 int vqseg_set_option(const char* key, int value);

@@ -1693,7 +1693,9 @@ __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, lon
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-static inline unsigned grid_for(long work, int per_block = 256, long cap = 8192) {
+static long g_grid_cap = 8192;                              // workgroups of the grid-stride elementwise kernels (option "nn_grid_cap")
+static inline unsigned grid_for(long work, int per_block = 256, long cap = 0) {
+    if (cap == 0) cap = g_grid_cap;
     long b = (work + per_block - 1) / per_block;
     if (b < 1) b = 1;
     if (b > cap) b = cap;
@@ -1712,6 +1714,11 @@ int nn_set_option(const char* key, int value) {
     if (key && !strcmp(key, "bn_bwd_premask")) {
         extern int bn_bwd_premask_option(int);
         return bn_bwd_premask_option(value);
+    }
+    if (key && !strcmp(key, "nn_grid_cap") && value >= 256) {
+        const int prev = (int)g_grid_cap;
+        g_grid_cap = value;
+        return prev;
     }
     if (key && !strcmp(key, "im2col_strip")) {
         extern int im2col_strip_option(int);
