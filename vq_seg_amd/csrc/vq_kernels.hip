@@ -905,6 +905,33 @@ __global__ __launch_bounds__(256) void vq_exact_dist_kernel(const unsigned short
     dmin[row] = __builtin_sqrtf(d2);
 }
 
+// r4: everything a grouped launch wants pre-set, in ONE launch instead of up to three memsets per level (each a launch of its own, in a
+// phase where the chip runs nothing else): keys = all ones (the atomicMin identity), the filter's sub-list counters + overflow flag = 0,
+// the usage histogram = 0.
+struct VqInitLevel {
+    unsigned long long* keys;
+    long n;
+    int* amb;                   // 128 ints, or null
+    int* hist;
+    int kp;
+    unsigned end;               // cumulative workgroup count
+};
+struct VqInitGroup {
+    VqInitLevel lv[VQ_MAX_LEVELS];
+    int n;
+};
+__global__ __launch_bounds__(256) void vq_group_init_kernel(const VqInitGroup g) {
+    int q = 0;
+    while (q + 1 < g.n && blockIdx.x >= g.lv[q].end) ++q;
+    const VqInitLevel& L = g.lv[q];
+    const unsigned first = q ? g.lv[q - 1].end : 0u, nb = L.end - first, b = blockIdx.x - first;
+    for (long i = (long)b * 256 + threadIdx.x; i < L.n; i += (long)nb * 256) L.keys[i] = ~0ull;
+    if (b == 0) {
+        if (L.amb && threadIdx.x < 128) L.amb[threadIdx.x] = 0;
+        for (int k = threadIdx.x; k < L.kp; k += 256) L.hist[k] = 0;
+    }
+}
+
 // keys -> int64 code indices (+ the winning distance), and the code histogram of the dead-code statistic (vq_img.py:173-175):
 // counted per workgroup in LDS (few codes win most rows -- thousands of rows per address: global atomics would serialise in the
 // L2 atomic units; round 1 did that from the gather kernel and sat at ~1 TB/s), then one global add per NON-EMPTY bin and
@@ -1504,7 +1531,9 @@ hipError_t launch_assign_group(int n, const void* const* x, int x_bf16, const in
 #if VQ_TIMELINE
     g.tl = g_timeline;
 #endif
-    unsigned end = 0, fend = 0, rend = 0, send = 0;
+    unsigned end = 0, fend = 0, rend = 0, send = 0, iend = 0;
+    VqInitGroup ig;
+    ig.n = n;
     for (int q = 0; q < n; ++q) {
         const int i = order[q];
         const PreparedLayout pl = prepared_layout(C[i], K[i]);
@@ -1512,14 +1541,17 @@ hipError_t launch_assign_group(int n, const void* const* x, int x_bf16, const in
         const float* E4 = reinterpret_cast<const float*>(pb + pl.off_e4);
         const float* enorm = reinterpret_cast<const float*>(pb + pl.off_enorm);
         unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws[i] + plans[i].off_keys);
-        hipError_t e = hipMemsetAsync(keys, 0xff, (size_t)N[i] * sizeof(unsigned long long), st);
-        if (e != hipSuccess) return e;
+        {
+            long ib = (N[i] + 4095) / 4096;                      // 16 keys per thread
+            ib = ib < 1 ? 1 : (ib > 256 ? 256 : ib);
+            iend += (unsigned)ib;
+            ig.lv[q] = VqInitLevel{keys, (long)N[i], nullptr, reinterpret_cast<int*>(ws[i] + plans[i].off_hist), plans[i].Kp, iend};
+        }
         end += assign_workgroups(N[i], plans[i].Kp, T);
         g.lv[q] = VqLevel{x[i], E4, enorm, keys, (long)N[i], C[i], plans[i].Kp, end};
         if (filter) {
             int* amb = reinterpret_cast<int*>(ws[i] + plans[i].off_amb);
-            e = hipMemsetAsync(amb, 0, 512, st);                  // the sub-lists' counters and the overflow flag
-            if (e != hipSuccess) return e;
+            ig.lv[q].amb = amb;                                   // the sub-lists' counters and the overflow flag: zeroed by the init launch
             // a pair list that overflows (more than four candidates per row on average: degenerate codebooks) switches the level to the
             // exact kernel on every row -- the gated launch below
             g.lv[q].gate = amb + F_LISTS;                         // the overflow flag
@@ -1548,6 +1580,8 @@ hipError_t launch_assign_group(int n, const void* const* x, int x_bf16, const in
             fc[q].c_r = (float)(1.25 * tail);
         }
     }
+    static_assert(F_LISTS + 1 <= 128, "the init launch zeroes 128 ints of a level's counter block");
+    hipLaunchKernelGGL(vq_group_init_kernel, dim3(iend), dim3(256), 0, st, ig);
     const bool rec = g_prof.enabled && (int)g_prof.shape.size() + n <= g_prof.capacity;
     const size_t slot = g_prof.shape.size();
     if (rec) {
@@ -1576,9 +1610,7 @@ hipError_t launch_assign_group(int n, const void* const* x, int x_bf16, const in
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     for (int i = 0; i < n; ++i) {
-        int* hist = reinterpret_cast<int*>(ws[i] + plans[i].off_hist);
-        e = hipMemsetAsync(hist, 0, (size_t)plans[i].Kp * sizeof(int), st);
-        if (e != hipSuccess) return e;
+        int* hist = reinterpret_cast<int*>(ws[i] + plans[i].off_hist);       // (zeroed by the init launch)
         long blocks = (N[i] + 1023) / 1024;                      // >= 1024 rows per workgroup: the LDS histogram pays
         if (blocks > 512) blocks = 512;
         if (blocks < 1) blocks = 1;
